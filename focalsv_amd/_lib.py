@@ -1,0 +1,144 @@
+"""ctypes binding of libfocalsv_hip.so (include/focalsv_hip.h).
+
+The library is built in-tree by `make -C focalsv_amd/csrc` (see __graft_entry__.build).
+Nothing here falls back to a CPU implementation: a missing library or device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfocalsv_hip.so")
+
+FSV_WINDOW, FSV_K_FULL, FSV_K_MAX = 375, 15, 31
+
+WTASK_DTYPE = np.dtype(
+    [("x_word", "<u4"), ("y_word", "<u4"), ("x_start", "<i4"), ("y_start", "<i4"), ("y_len", "<i4"),
+     ("x_len", "<u2"), ("k", "u1"), ("y_rev", "u1"), ("ovl", "<u4"), ("win", "<u4")], align=False)
+WRES_DTYPE = np.dtype(
+    [("end_site", "<i4"), ("err", "<i4"), ("y_beg", "<i4"), ("extra_begin", "<i2"), ("extra_end", "<i2")], align=False)
+assert WTASK_DTYPE.itemsize == 32 and WRES_DTYPE.itemsize == 16
+
+
+class FsvError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {strerror(code)} ({code}){': ' + detail if detail else ''}")
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C focalsv_amd/csrc). focalsv_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u32p, u64p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    sig = {
+        "fsv_version": (C.c_int, []),
+        "fsv_strerror": (C.c_char_p, [C.c_int]),
+        "fsv_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "fsv_ctx_destroy": (None, [vp]),
+        "fsv_ctx_set_stream": (C.c_int, [vp, vp]),
+        "fsv_ctx_sync": (C.c_int, [vp]),
+        "fsv_last_error": (C.c_char_p, [vp]),
+        "fsv_device_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), u64p, C.c_char_p, C.c_size_t]),
+        "fsv_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "fsv_dev_free": (C.c_int, [vp, vp]),
+        "fsv_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "fsv_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "fsv_pack_bound": (C.c_size_t, [vp, C.c_uint32]),
+        "fsv_pack_reads": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_size_t, vp]),
+        "fsv_bpm_windows_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
+        "fsv_bpm_windows": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def strerror(code):
+    return load().fsv_strerror(code).decode()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pack_reads(reads):
+    """K0: list of str/bytes -> (words uint32[], word_off uint64[n+1], lens int32[n])."""
+    lib = load()
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    lens = np.array([len(b) for b in bs], dtype=np.int64)
+    seq_off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=seq_off[1:])
+    seqs = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, np.uint8)
+    cap = lib.fsv_pack_bound(_ptr(seq_off), len(bs))
+    words = np.empty(cap, dtype=np.uint32)
+    word_off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    rc = lib.fsv_pack_reads(_ptr(seqs), _ptr(seq_off), len(bs), _ptr(words), cap, _ptr(word_off))
+    if rc:
+        raise FsvError(rc, "fsv_pack_reads")
+    return words, word_off, lens.astype(np.int32)
+
+
+class Context:
+    """One fsv_ctx (= one GPU + one stream).  Raises FsvError(FSV_ENODEV) without an MI355X."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.fsv_ctx_create(int(device), C.byref(h))
+        if rc:
+            raise FsvError(rc, "fsv_ctx_create")
+        self._h = h
+        if stream is not None:
+            self.check(self._lib.fsv_ctx_set_stream(self._h, C.c_void_p(stream)), "fsv_ctx_set_stream")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fsv_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def check(self, rc, where):
+        if rc:
+            raise FsvError(rc, where, self._lib.fsv_last_error(self._h).decode())
+
+    def sync(self):
+        self.check(self._lib.fsv_ctx_sync(self._h), "fsv_ctx_sync")
+
+    def device_info(self):
+        ncu, clk, hbm = C.c_int(), C.c_int(), C.c_uint64()
+        name = C.create_string_buffer(128)
+        self.check(self._lib.fsv_device_info(self._h, C.byref(ncu), C.byref(clk), C.byref(hbm), name, 128), "fsv_device_info")
+        return {"n_cu": ncu.value, "clock_khz": clk.value, "hbm_bytes": hbm.value, "name": name.value.decode()}
+
+    # K5 -----------------------------------------------------------------------------
+    def bpm_windows(self, words, tasks):
+        """host arrays in, host results out (fsv_bpm_windows)."""
+        tasks = np.ascontiguousarray(tasks, dtype=WTASK_DTYPE)
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        res = np.empty(len(tasks), dtype=WRES_DTYPE)
+        self.check(self._lib.fsv_bpm_windows(self._h, _ptr(words), words.size, _ptr(tasks), len(tasks), _ptr(res)), "fsv_bpm_windows")
+        return res
+
+    def bpm_windows_dev(self, store_ptr, tasks_ptr, n_tasks, res_ptr):
+        self.check(self._lib.fsv_bpm_windows_dev(self._h, C.c_void_p(store_ptr), C.c_void_p(tasks_ptr), n_tasks, C.c_void_p(res_ptr)),
+                   "fsv_bpm_windows_dev")

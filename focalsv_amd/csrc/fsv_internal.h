@@ -1,0 +1,49 @@
+// fsv_internal.h -- shared by the HIP translation units of libfocalsv_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "focalsv_hip.h"
+
+struct fsv_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 0;
+    int clock_khz = 0;
+    uint64_t hbm_bytes = 0;
+    std::string name;
+    std::string last_error;
+};
+
+#define FSV_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);      \
+            return (e_ == hipErrorOutOfMemory) ? FSV_ENOMEM : FSV_EHIP;                 \
+        }                                                                               \
+    } while (0)
+
+static inline int fsv_fail(fsv_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) ctx->last_error = msg;
+    return code;
+}
+
+// ---- device helpers -----------------------------------------------------------------
+// 2-bit read store: 16 bases per uint32 word (see focalsv_hip.h).
+__device__ __forceinline__ uint32_t fsv_base_fwd(const uint32_t *__restrict__ store, uint32_t word_off, int pos)
+{
+    return (store[word_off + ((uint32_t)pos >> 4)] >> (((uint32_t)pos & 15u) << 1)) & 3u;
+}
+
+// base at strand coordinate p of a read of length len; rev = reverse complement strand.
+__device__ __forceinline__ uint32_t fsv_base_at(const uint32_t *__restrict__ store, uint32_t word_off, int len, int rev, int p)
+{
+    int q = rev ? (len - 1 - p) : p;
+    uint32_t b = fsv_base_fwd(store, word_off, q);
+    return rev ? (3u - b) : b;
+}
+
+static inline unsigned fsv_grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }

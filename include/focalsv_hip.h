@@ -1,0 +1,119 @@
+/* focalsv_hip.h -- C ABI of libfocalsv_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for FocalSV's per-region local-assembly +
+ * SV-calling hot path.  The reference has no plugin API: its boundary is
+ * "spawn a CPU binary and read its files back" (SURVEY.md 8b):
+ *
+ *   hifiasm -o <prefix> -t T <reads.fa>        focalsv/3_assembly/run_assembly.py:15-26
+ *       -> GFA 'S' lines -> HP1.fa/HP2.fa       focalsv/3_assembly/post_assembly.py:79-95, combine_fas.py:10-35
+ *   minimap2 -a -x asm5 --cs -r2k ref asm.fa   focalsv/4_sv_calling/Dippav/DipPAV_variant_call.py:103-108
+ *       -> BAM records read through pysam       focalsv/4_sv_calling/Dippav/extract_contig_signature_CCS.py:14-47,342-432
+ *
+ * The entry points below are what a binding at those two call sites would
+ * bind instead (INTEGRATION.md shows the ctypes stubs).  Conventions:
+ *   - plain C types, pointers + sizes, no ownership transfer: every buffer is
+ *     allocated by the caller (sized through the *_bound() calls) ;
+ *   - every function returns 0 or a negative FSV_E* code, never aborts; batch
+ *     calls also fill a per-unit status array;
+ *   - one fsv_ctx per GPU/stream; calls on different contexts are independent,
+ *     the library keeps no global state;
+ *   - "_dev" arguments are device pointers valid on the context's device
+ *     (hipMalloc / torch tensor data_ptr()); everything else is host memory.
+ *   - there is NO CPU fallback: without a usable gfx950 device
+ *     fsv_ctx_create() fails with FSV_ENODEV.
+ *
+ * Read store layout (hifiasm K0, Process_Read.h:108-137, restated for HBM):
+ * bases are 2-bit codes A=0 C=1 G=2 T=3, 16 per little-endian uint32 word,
+ * base i of a read in bits [2*(i%16), 2*(i%16)+1] of word (word_off + i/16).
+ * Every read starts on a word boundary.  'N' is stored as A (hifiasm keeps an
+ * N side list; the FocalSV read FASTAs come from BAM records and carry none).
+ */
+#ifndef FOCALSV_HIP_H
+#define FOCALSV_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSV_OK        0
+#define FSV_ENODEV   -1  /* no gfx950 device / HIP runtime unusable */
+#define FSV_EINVAL   -2  /* bad argument */
+#define FSV_ENOMEM   -3  /* device or host allocation failed */
+#define FSV_EHIP     -4  /* HIP runtime error (fsv_last_error gives the text) */
+#define FSV_ECAP     -5  /* caller buffer too small */
+#define FSV_EUNSUP   -6  /* input outside what this build supports */
+
+#define FSV_WINDOW          375 /* hifiasm WINDOW, Hash_Table.h:9 */
+#define FSV_K_FULL           15 /* hifiasm THRESHOLD, Hash_Table.h:13 */
+#define FSV_K_MAX            31 /* hifiasm THRESHOLD_MAX_SIZE, Hash_Table.h:17 */
+
+typedef struct fsv_ctx fsv_ctx;
+
+/* ---- context ----------------------------------------------------------- */
+int  fsv_ctx_create(int device, fsv_ctx **out);
+void fsv_ctx_destroy(fsv_ctx *ctx);
+/* use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); 0 = the context's own */
+int  fsv_ctx_set_stream(fsv_ctx *ctx, void *hip_stream);
+int  fsv_ctx_sync(fsv_ctx *ctx);
+const char *fsv_last_error(const fsv_ctx *ctx);
+const char *fsv_strerror(int code);
+int  fsv_version(void);
+/* device properties the benchmarks print: CU count, clock (kHz), HBM bytes */
+int  fsv_device_info(const fsv_ctx *ctx, int *n_cu, int *clock_khz, uint64_t *hbm_bytes, char *name, size_t name_cap);
+
+/* raw device memory helpers for callers without torch */
+int  fsv_dev_alloc(fsv_ctx *ctx, size_t bytes, void **dev_ptr);
+int  fsv_dev_free(fsv_ctx *ctx, void *dev_ptr);
+int  fsv_h2d(fsv_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int  fsv_d2h(fsv_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
+/* ---- K0: read store ------------------------------------------------------
+ * Replaces hifiasm's FASTA ingest + ha_compress_base (Assembly.cpp:21-65).
+ * Host-side packing of ASCII reads into the layout above.
+ *   seqs      concatenated ASCII bases of all reads
+ *   seq_off   n_reads+1 offsets into seqs
+ *   words     out, capacity words_cap (>= fsv_pack_bound)
+ *   word_off  out, n_reads+1 word offsets (read r occupies [word_off[r], word_off[r+1]))
+ */
+size_t fsv_pack_bound(const uint64_t *seq_off, uint32_t n_reads);
+int    fsv_pack_reads(const char *seqs, const uint64_t *seq_off, uint32_t n_reads,
+                      uint32_t *words, size_t words_cap, uint64_t *word_off);
+
+/* ---- K5: batched banded bit-parallel edit distance -------------------------
+ * Replaces Reserve_Banded_BPM / Reserve_Banded_BPM_4_SSE_only as driven by
+ * verify_window (hifiasm-0.14 Levenshtein_distance.h:274-461, 893-1198;
+ * Correct.cpp:203-250, 306-531).  One task = one (x window, overlapping read) pair.
+ */
+typedef struct fsv_wtask {
+    uint32_t x_word;   /* word offset of read x in the store */
+    uint32_t y_word;   /* word offset of read y */
+    int32_t  x_start;  /* first base of the window in x (forward strand) */
+    int32_t  y_start;  /* chain-predicted partner of x_start in y's strand coordinates (before the -k pad) */
+    int32_t  y_len;    /* length of read y */
+    uint16_t x_len;    /* 1..FSV_WINDOW */
+    uint8_t  k;        /* error threshold, band = 2k+1, <= FSV_K_MAX */
+    uint8_t  y_rev;    /* 1: y is read on its reverse-complement strand */
+    uint32_t ovl;      /* caller tag: overlap id */
+    uint32_t win;      /* caller tag: window index inside the overlap */
+} fsv_wtask;           /* 32 bytes */
+
+typedef struct fsv_wres {
+    int32_t end_site;    /* 0-based end offset inside the padded y window, -1 = no alignment within k */
+    int32_t err;         /* edit distance, -1 = none */
+    int32_t y_beg;       /* first y base covered by the padded window after clipping to the read (determine_overlap_region) */
+    int16_t extra_begin; /* 'N' columns padded in front (window starts before the read) */
+    int16_t extra_end;   /* 'N' columns padded behind */
+} fsv_wres;              /* 16 bytes */
+
+int fsv_bpm_windows_dev(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wtask *tasks_dev,
+                        uint32_t n_tasks, fsv_wres *res_dev);
+/* host convenience wrapper (copies in, runs, copies out) */
+int fsv_bpm_windows(fsv_ctx *ctx, const uint32_t *store, size_t store_words, const fsv_wtask *tasks,
+                    uint32_t n_tasks, fsv_wres *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOCALSV_HIP_H */
