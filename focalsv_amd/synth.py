@@ -1,0 +1,184 @@
+"""Seeded synthetic target regions: a reference window, two haplotypes
+with planted DEL/INS, and HiFi-like (or ONT-like) reads delivered pre-phased exactly as
+focalsv/2_phasing/output_fas.py:63-73 writes them (PS1_hp1.fa / PS1_hp2.fa, one line per read).
+
+Region i uses seed 1000+i.  numpy's PCG64 is used instead of random.Random so that 256
+regions (~400 Mbase of reads) generate in seconds; the stream is fully determined by the seed.
+"""
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+
+_ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_a] = _b
+
+
+@dataclass
+class TruthSV:
+    svtype: str   # 'DEL' | 'INS'
+    pos: int      # 0-based offset of the first affected reference base (DEL) / base after which... see vcf_pos
+    length: int
+    gt: str       # '1/1' | '0/1'
+    hap: int      # 1, 2 or 3 (both)
+    seq: str = ""
+
+
+@dataclass
+class Region:
+    index: int
+    chrom: str
+    start: int
+    ref: bytes
+    haps: Tuple[bytes, bytes]
+    reads: Tuple[List[bytes], List[bytes]]
+    truth: List[TruthSV] = field(default_factory=list)
+
+
+def _rand_seq(rng, n):
+    return _ALPHA[rng.integers(0, 4, size=n)]
+
+
+def revcomp(b: bytes) -> bytes:
+    return _COMP[np.frombuffer(b, dtype=np.uint8)][::-1].tobytes()
+
+
+def _loguniform_int(rng, lo, hi):
+    return int(round(float(np.exp(rng.uniform(np.log(lo), np.log(hi))))))
+
+
+def _add_errors(rng, seq: np.ndarray, rate: float) -> np.ndarray:
+    """substitution : insertion : deletion = 1:1:1 at total rate `rate`."""
+    n = seq.size
+    if rate <= 0 or n == 0:
+        return seq
+    r = rng.random(n)
+    sub = r < rate / 3
+    ins = (r >= rate / 3) & (r < 2 * rate / 3)
+    dele = (r >= 2 * rate / 3) & (r < rate)
+    out = seq.copy()
+    ns = int(sub.sum())
+    if ns:
+        out[sub] = _ALPHA[(np.searchsorted(_ALPHA, seq[sub]) + rng.integers(1, 4, size=ns)) % 4]
+    keep = ~dele
+    reps = np.ones(n, dtype=np.int64)
+    reps[ins] = 2
+    reps[~keep] = 0
+    idx = np.repeat(np.arange(n), reps)
+    res = out[idx]
+    # the second copy of an "ins" position becomes a random base
+    first = np.ones(idx.size, dtype=bool)
+    first[1:] = idx[1:] != idx[:-1]
+    nins = int((~first).sum())
+    if nins:
+        res[~first] = _ALPHA[rng.integers(0, 4, size=nins)]
+    return res
+
+
+def _sample_reads(rng, hap: np.ndarray, depth: float, len_lo: int, len_hi: int, err: float, min_keep: int = 3000):
+    reads = []
+    total, target = 0, depth * hap.size
+    H = hap.size
+    while total < target:
+        L = int(rng.integers(len_lo, len_hi + 1))
+        s = int(rng.integers(-L + min_keep, H - min_keep + 1))
+        a, b = max(0, s), min(H, s + L)
+        if b - a < min_keep:
+            continue
+        seg = _add_errors(rng, hap[a:b], err)
+        if rng.random() < 0.5:
+            seg = _COMP[seg][::-1]
+        reads.append(seg.tobytes())
+        total += b - a
+    return reads
+
+
+def make_region(i: int, width: int = 50_000, profile: str = "hifi", depth_per_hap: float = 15.0,
+                chrom: str = "chr21", start: int = 0) -> Region:
+    rng = np.random.default_rng(1000 + i)
+    ref = _rand_seq(rng, width)
+    edge = min(5000, width // 5)
+    tandem = None
+    if i % 8 == 7 and width >= 20000:
+        unit = _rand_seq(rng, int(rng.integers(20, 61)))
+        tpos = int(rng.integers(edge + 1000, width - edge - 3000))
+        block = np.tile(unit, 2000 // unit.size + 1)[:2000]
+        ref[tpos:tpos + 2000] = block
+        tandem = (tpos, unit.size)
+
+    # hap1: one DEL + one INS, >= edge from the ends and >= edge apart
+    while True:
+        dlen = _loguniform_int(rng, 50, 2000)
+        ilen = _loguniform_int(rng, 50, 2000)
+        dpos = int(rng.integers(edge, width - edge - dlen))
+        ipos = int(rng.integers(edge, width - edge))
+        if tandem is not None:
+            # VNTR contraction: delete whole repeat units inside the block (gap placement is ambiguous there)
+            units = max(1, min(dlen // tandem[1], 1500 // tandem[1]))
+            dlen = units * tandem[1]
+            dpos = tandem[0] + tandem[1] * int(rng.integers(1, max(2, (2000 - dlen) // tandem[1] - 1)))
+        if abs(ipos - dpos) >= edge and abs(ipos - (dpos + dlen)) >= edge:
+            if tandem is None or not (tandem[0] - 100 <= ipos <= tandem[0] + 2100):
+                break
+    iseq = _rand_seq(rng, ilen)
+    truth = []
+    homo_del = (i % 3 == 0)
+    truth.append(TruthSV("DEL", dpos, dlen, "1/1" if homo_del else "0/1", 3 if homo_del else 1))
+    truth.append(TruthSV("INS", ipos, ilen, "0/1", 1, iseq.tobytes().decode()))
+
+    def apply(refarr, events):
+        # events: list of (pos, kind, payload) applied right-to-left
+        out = refarr
+        for pos, kind, payload in sorted(events, key=lambda e: -e[0]):
+            if kind == "DEL":
+                out = np.concatenate([out[:pos], out[pos + payload:]])
+            else:
+                out = np.concatenate([out[:pos], payload, out[pos:]])
+        return out
+
+    hap1 = apply(ref, [(dpos, "DEL", dlen), (ipos, "INS", iseq)])
+    ref2 = ref.copy()
+    snp_pos = np.arange(500, width, 1000)
+    ref2[snp_pos] = _ALPHA[(np.searchsorted(_ALPHA, ref2[snp_pos]) + 1 + (snp_pos // 1000) % 3) % 4]
+    ev2 = []
+    if homo_del:
+        ev2.append((dpos, "DEL", dlen))
+    if i % 4 == 0:
+        while True:
+            p2 = int(rng.integers(edge, width - edge))
+            if abs(p2 - dpos) >= 3000 and abs(p2 - dpos - dlen) >= 3000 and abs(p2 - ipos) >= 3000:
+                break
+        l2 = _loguniform_int(rng, 50, 2000)
+        s2 = _rand_seq(rng, l2)
+        ev2.append((p2, "INS", s2))
+        truth.append(TruthSV("INS", p2, l2, "0/1", 2, s2.tobytes().decode()))
+    hap2 = apply(ref2, ev2)
+
+    if profile == "hifi":
+        lo, hi, err = 10_000, 20_000, 0.002
+    elif profile == "ont":
+        lo, hi, err = 10_000, 30_000, 0.10
+    elif profile == "clean":
+        lo, hi, err = 10_000, 20_000, 0.0
+    else:
+        raise ValueError(profile)
+    lo, hi = min(lo, max(1000, width // 2)), min(hi, width)
+    keep = min(3000, max(500, width // 8))
+    r1 = _sample_reads(rng, hap1, depth_per_hap, lo, hi, err, keep)
+    r2 = _sample_reads(rng, hap2, depth_per_hap, lo, hi, err, keep)
+    truth.sort(key=lambda t: t.pos)
+    return Region(i, chrom, start, ref.tobytes(), (hap1.tobytes(), hap2.tobytes()), (r1, r2), truth)
+
+
+def write_region_dir(region: Region, out_dir: str) -> str:
+    """Region_<chr>_S<s>_E<e>/PS1_hp{1,2}.fa as output_fas.py writes them (read name line, one sequence line)."""
+    import os
+    d = os.path.join(out_dir, f"Region_{region.chrom}_S{region.start}_E{region.start + len(region.ref)}")
+    os.makedirs(d, exist_ok=True)
+    for h in (0, 1):
+        with open(os.path.join(d, f"PS1_hp{h + 1}.fa"), "w") as f:
+            for j, r in enumerate(region.reads[h]):
+                f.write(f">r{region.index}_h{h + 1}_{j}\n{r.decode()}\n")
+    return d

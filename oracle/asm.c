@@ -1,0 +1,672 @@
+/* oracle/asm.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, scalar, ASCII reads) of the per-read-set local
+ * assembly that FocalSV obtains from `hifiasm -o X.asm -t T X.fa`
+ * (focalsv/3_assembly/run_assembly.py:15-26), stage by stage:
+ *
+ *   S1 sketch            ha_sketch, k=w=51 HPC            sketch.cpp:39-137          (oracle/sketch.c)
+ *   S2 per-read index    occurrence filter                htab.cpp:917-998 (ha_ft_gen/ha_pt_gen) -- restated as
+ *                        "hash occurs once in the read"; the global count filter needs a whole-genome histogram
+ *   S3 anchors + chain   ha_get_candidates_interface      anchor.cpp:60-178, 207-300
+ *                        chain_DP                         Hash_Table.cpp:425-616
+ *                        extension to the read ends       Hash_Table.cpp:83-243
+ *   S4 window verify     verify_window + K5               Correct.cpp:203-250, 306-531     (oracle/bpm.c)
+ *   S5 rescue + accept   recalcate_window_advance         Correct.cpp:2629-3023 (right-extension pass, 0.9 filter,
+ *                        non_trim_error_rate <= 0.03      Correct.cpp:725)
+ *   S6 window paths      Reserve_Banded_BPM_PATH + generate_cigar   (oracle/bpm.c)
+ *   S7 consensus         generate_consensus/window_consensus/get_seq_from_Graph  Correct.cpp:4731-4808, 4132-4195, 4010-4130
+ *                        restated as a per-column vote: thresholds 0.60 / 0.515 in homopolymers,
+ *                        coverage >= 3 (Correct.h:11-15)
+ *   S8 apply + RC        worker_ec_save                   Assembly.cpp:706-767 (reads are reverse-complemented after
+ *                        every non-final round, :747-757)
+ *   S9 final overlaps    worker_ov_final / if_exact_match Assembly.cpp:1284-1306, 894-974
+ *   S10 layout           containment removal, best-overlap string graph, unitig walk;
+ *                        contig = concatenated read prefixes (ma_ug_seq, Overlaps.cpp:8969-9034)
+ *
+ * All decisions are integer arithmetic so that the HIP path can be compared bit for bit.
+ * Deviations from hifiasm that are deliberate and documented in DESIGN.md: no global k-mer
+ * count table (S2), a fixed chain look-back instead of max_skip heuristics, no left-extension
+ * rescue / fix_boundary / boundary re-alignment (junction insertions are voted directly),
+ * no haplotype partition (K7) and no bubble/tip cleaning (read sets are single-haplotype).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "oracle.h"
+
+/* ---------------------------------------------------------------- helpers */
+static char comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+
+static void revcomp_inplace(char *s, int n)
+{
+    int i;
+    for (i = 0; i < n / 2; i++) { char a = comp(s[i]), b = comp(s[n - 1 - i]); s[i] = b; s[n - 1 - i] = a; }
+    if (n & 1) s[n / 2] = comp(s[n / 2]);
+}
+
+/* base of read y at strand coordinate p */
+static inline char ybase(const char *y, int ylen, int rev, int p) { return rev ? comp(y[ylen - 1 - p]) : y[p]; }
+
+int orc_thr_for_len(int x_len)
+{
+    /* verify_window: threshold = x_len * max_ov_diff_ec (0.04), Adjust_Threshold (Correct.h:39) */
+    int t;
+    if (x_len == ORC_WINDOW) return ORC_K_FULL;
+    t = (int)(x_len * 0.04);
+    if (t == 0 && x_len >= 4) t = 1;
+    return t;
+}
+
+int orc_double_thr(int pre, int x_len)
+{
+    /* double_error_threshold, Correct.cpp:658-676 */
+    int t;
+    if (pre == 0 && x_len >= 4) pre = 1;
+    t = pre * 2;
+    if (x_len >= 300 && t < ORC_K_MAX) t = ORC_K_MAX;
+    if (t > ORC_K_MAX) t = ORC_K_MAX;
+    return t;
+}
+
+/* ---------------------------------------------------------------- S2: unique-in-read minimizers sorted by hash */
+static int mz_cmp(const void *a, const void *b)
+{
+    const orc_mz *x = (const orc_mz *)a, *y = (const orc_mz *)b;
+    if (x->hash != y->hash) return x->hash < y->hash ? -1 : 1;
+    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+    return 0;
+}
+
+int orc_unique_sorted(orc_mz *mz, int n)
+{
+    int i, j, m = 0;
+    qsort(mz, (size_t)n, sizeof(orc_mz), mz_cmp);
+    for (i = 0; i < n; i = j) {
+        for (j = i + 1; j < n && mz[j].hash == mz[i].hash; j++) {}
+        if (j - i == 1) mz[m++] = mz[i];
+    }
+    return m;
+}
+
+/* ---------------------------------------------------------------- S3: anchors + chain for one ordered pair */
+typedef struct { int32_t qe, te; } anchor_t;
+
+static int anchor_cmp(const void *a, const void *b)
+{
+    const anchor_t *x = (const anchor_t *)a, *y = (const anchor_t *)b;
+    if (x->qe != y->qe) return x->qe < y->qe ? -1 : 1;
+    if (x->te != y->te) return x->te < y->te ? -1 : 1;
+    return 0;
+}
+
+/* returns 1 and fills *o (+ chain anchors, sorted by qe) when the pair overlaps */
+int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, int lent, const orc_asm_params *P,
+                   int bw_per_mille, orc_ovl *o, int32_t *chain_qe, int32_t *chain_te, int chain_cap)
+{
+    anchor_t *a;
+    int32_t *f, *pre, *ind, *sl;
+    int i, j, n = 0, nf = 0, nr = 0, rev, best = -1, ok = 0;
+    int cap = nq < nt ? nq : nt;
+    if (cap <= 0) return 0;
+    a = (anchor_t *)malloc(sizeof(anchor_t) * (size_t)cap * 2);
+    {
+        /* merge join on hash (both lists sorted, hashes unique inside each read) */
+        uint8_t *srev = (uint8_t *)malloc((size_t)cap);
+        anchor_t *raw = a + cap;
+        int32_t *tspan = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+        i = j = 0;
+        while (i < nq && j < nt) {
+            if (q[i].hash < t[j].hash) i++;
+            else if (q[i].hash > t[j].hash) j++;
+            else {
+                srev[n] = q[i].rev ^ t[j].rev;
+                raw[n].qe = (int32_t)q[i].pos;
+                raw[n].te = (int32_t)t[j].pos;
+                tspan[n] = t[j].span;
+                if (srev[n]) nr++; else nf++;
+                n++; i++; j++;
+            }
+        }
+        rev = nr > nf;
+        for (i = 0, j = 0; i < n; i++) {
+            if (srev[i] != rev) continue;
+            a[j].qe = raw[i].qe;
+            a[j].te = rev ? (lent - 1) - (raw[i].te - tspan[i] + 1) : raw[i].te;
+            j++;
+        }
+        n = j;
+        free(srev); free(tspan);
+    }
+    if (n < P->min_anchors) { free(a); return 0; }
+    qsort(a, (size_t)n, sizeof(anchor_t), anchor_cmp);
+
+    f = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 4);
+    pre = f + n; ind = pre + n; sl = ind + n;
+    for (i = 0; i < n; i++) {
+        int32_t bs = P->k, bp = -1, bi = 0, bl = 0;
+        int lo = i - P->lookback < 0 ? 0 : i - P->lookback;
+        for (j = i - 1; j >= lo; j--) { /* nearest predecessor first; strict '>' keeps the nearest on ties */
+            int32_t dq = a[i].qe - a[j].qe, dt = a[i].te - a[j].te, gap, ti, tl, sc;
+            if (dq <= 0 || dt <= 0) continue;
+            gap = dq > dt ? dq - dt : dt - dq;
+            ti = ind[j] + gap; tl = sl[j] + dq;
+            if ((int64_t)ti * 1000 > (int64_t)tl * bw_per_mille) continue;
+            sc = dq < dt ? dq : dt;
+            if (sc > P->k) sc = P->k;
+            sc -= (int32_t)(((int64_t)ti * sc * 1000) / ((int64_t)tl * bw_per_mille));
+            sc += f[j];
+            if (sc > bs) { bs = sc; bp = j; bi = ti; bl = tl; }
+        }
+        f[i] = bs; pre[i] = bp; ind[i] = bi; sl[i] = bl;
+    }
+    for (i = 0; i < n; i++) if (best < 0 || f[i] > f[best]) best = i;
+    {
+        int cnt = 0, c;
+        for (c = best; c >= 0; c = pre[c]) cnt++;
+        if (cnt >= P->min_anchors && cnt <= chain_cap) {
+            int first = best, k2 = cnt;
+            for (c = best; c >= 0; c = pre[c]) { k2--; chain_qe[k2] = a[c].qe; chain_te[k2] = a[c].te; first = c; }
+            {
+                int32_t xs = a[first].qe, ys = a[first].te, xe = a[best].qe, ye = a[best].te, m, r;
+                m = xs < ys ? xs : ys; xs -= m; ys -= m;
+                r = (lenq - 1 - xe) < (lent - 1 - ye) ? (lenq - 1 - xe) : (lent - 1 - ye);
+                xe += r; ye += r;
+                if (xe - xs + 1 >= P->min_ovlp) {
+                    memset(o, 0, sizeof(*o));
+                    o->x_s = xs; o->x_e = xe; o->y_s = ys; o->y_e = ye; o->rev = (uint8_t)rev;
+                    o->score = f[best]; o->n_chain = cnt;
+                    ok = 1;
+                }
+            }
+        }
+    }
+    free(f); free(a);
+    return ok;
+}
+
+/* diagonal (te - qe) predicted for query position x: last chain anchor with qe <= x, else the first anchor */
+static int32_t diag_at(const int32_t *cq, const int32_t *ct, int n, int32_t x)
+{
+    int lo = 0, hi = n; /* first index with cq > x */
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (cq[mid] <= x) lo = mid + 1; else hi = mid; }
+    if (lo == 0) return ct[0] - cq[0];
+    return ct[lo - 1] - cq[lo - 1];
+}
+
+/* ---------------------------------------------------------------- S4: one window */
+/* determine_overlap_region + fill_subregion + K5.  Returns 1 when the window is geometrically valid. */
+static int window_verify(const char *x, const char *y, int ylen, int rev, orc_win *w, char *ybuf)
+{
+    int n = w->x_len, k = w->k, wlen = n + 2 * k, j, win0, err;
+    w->end_site = -1; w->err = -1; w->y_beg = -1; w->extra_begin = -1; w->extra_end = -1;
+    if (w->y_start < 0 || ylen <= w->y_start || ylen - w->y_start + 2 * k + ORC_K_MAX < wlen) return 0;
+    win0 = w->y_start - k;
+    {
+        int ys = win0, olen = wlen < ylen - ys ? wlen : ylen - ys;
+        w->extra_end = (int16_t)(wlen - olen); w->extra_begin = 0;
+        if (ys < 0) { w->extra_begin = (int16_t)(-ys); ys = 0; }
+        w->y_beg = ys;
+    }
+    for (j = 0; j < wlen; j++) { int p = win0 + j; ybuf[j] = (p < 0 || p >= ylen) ? 'N' : ybase(y, ylen, rev, p); }
+    w->end_site = orc_bpm(ybuf, wlen, x + w->x_start, n, k, &err);
+    w->err = err;
+    if (err < 0) w->end_site = -1;
+    return 1;
+}
+
+/* absolute strand coordinate of padded column c */
+static inline int win_abs(const orc_win *w, int c) { return w->y_start - w->k + c; }
+
+/* ---------------------------------------------------------------- S6: path of one matched window */
+/* Fills w->path (start-to-end ops), w->path_len, w->ry_start / w->ry_end (absolute, inclusive), w->err (after gap shifting). */
+static void window_path(const char *x, const char *y, int ylen, int rev, orc_win *w, char *ybuf, uint64_t *cols, uint8_t *tmp,
+                        int *rl, uint8_t *ro)
+{
+    int n = w->x_len, k = w->k, wlen = n + 2 * k, j, win0 = w->y_start - k, err, start = 0, plen = 0, end, nrun, i, pl;
+    for (j = 0; j < wlen; j++) { int p = win0 + j; ybuf[j] = (p < 0 || p >= ylen) ? 'N' : ybase(y, ylen, rev, p); }
+    end = w->end_site; err = w->err;
+    if (err == 0) {
+        start = end - n + 1;
+        for (i = 0; i < n; i++) tmp[i] = 0;
+        plen = n;
+    } else if (!orc_try_cigar(ybuf, x + w->x_start, n, end, err, tmp, &start, &plen)) {
+        int e2;
+        end = orc_bpm_path(ybuf, wlen, x + w->x_start, n, k, &e2, &start, &plen, tmp, cols);
+        err = e2;
+    }
+    if (err > 0) nrun = orc_generate_cigar(tmp, plen, n, x + w->x_start, ybuf, &start, &end, &err, rl, ro);
+    else { nrun = 1; rl[0] = n; ro[0] = 0; }
+    pl = 0;
+    for (i = 0; i < nrun; i++) for (j = 0; j < rl[i]; j++) w->path[pl++] = ro[i];
+    w->path_len = (int16_t)pl;
+    w->err = err;
+    w->ry_start = win_abs(w, start);
+    w->ry_end = win_abs(w, end);
+}
+
+/* ---------------------------------------------------------------- S7: consensus of one grid window of read x */
+typedef struct { uint32_t key; int32_t cnt; } ins_slot;
+#define INS_SLOTS 4
+#define INS_MAXLEN 12
+
+static inline int base2(char c) { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 0; } }
+
+static void ins_vote(ins_slot *s, uint32_t key)
+{
+    int i;
+    for (i = 0; i < INS_SLOTS; i++) {
+        if (s[i].cnt && s[i].key == key) { s[i].cnt++; return; }
+        if (!s[i].cnt) { s[i].key = key; s[i].cnt = 1; return; }
+    }
+    /* table full: the vote still counts in the column total (caller), but cannot win */
+}
+
+static int is_homopolymer_site(const char *x, int xlen, int p)
+{
+    /* if_is_homopolymer_strict (Correct.cpp): the base equals a neighbour */
+    if (p > 0 && x[p - 1] == x[p]) return 1;
+    if (p + 1 < xlen && x[p + 1] == x[p]) return 1;
+    return 0;
+}
+
+static inline int wins(int cnt, int total, int homo)
+{
+    if (cnt * 5 >= total * 3) return 1;                  /* >= 0.60 */
+    if (homo && cnt * 1000 >= total * 515) return 1;     /* >= 0.515 inside a homopolymer */
+    return 0;
+}
+
+/* ---------------------------------------------------------------- one correction round over a read set */
+typedef struct {
+    int n;
+    char **seq;
+    int *len;
+} readset;
+
+static void collect_overlaps(const readset *R, const orc_asm_params *P, int bw, orc_mz **uq, int *nuq, orc_ovl **ovl_out,
+                             int32_t **cq_out, int32_t **ct_out, int *n_out)
+{
+    int q, t, n = 0, cap = 1024, chain_cap = 0, ccap = 1 << 16, cused = 0;
+    orc_ovl *ov = (orc_ovl *)malloc(sizeof(orc_ovl) * (size_t)cap);
+    int32_t *cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)ccap), *ct = (int32_t *)malloc(sizeof(int32_t) * (size_t)ccap);
+    for (q = 0; q < R->n; q++) if (nuq[q] > chain_cap) chain_cap = nuq[q];
+    for (q = 0; q < R->n; q++)
+        for (t = 0; t < R->n; t++) {
+            orc_ovl o;
+            if (q == t) continue;
+            if (cused + chain_cap > ccap) {
+                ccap = (cused + chain_cap) * 2;
+                cq = (int32_t *)realloc(cq, sizeof(int32_t) * (size_t)ccap);
+                ct = (int32_t *)realloc(ct, sizeof(int32_t) * (size_t)ccap);
+            }
+            if (!orc_chain_pair(uq[q], nuq[q], R->len[q], uq[t], nuq[t], R->len[t], P, bw, &o, cq + cused, ct + cused, chain_cap)) continue;
+            o.q = (uint32_t)q; o.t = (uint32_t)t; o.chain_off = cused;
+            cused += o.n_chain;
+            if (n == cap) { cap *= 2; ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)cap); }
+            ov[n++] = o;
+        }
+    *ovl_out = ov; *cq_out = cq; *ct_out = ct; *n_out = n;
+}
+
+static void sketch_set(const readset *R, const orc_asm_params *P, orc_mz ***uq_out, int **nuq_out)
+{
+    int r;
+    orc_mz **uq = (orc_mz **)malloc(sizeof(orc_mz *) * (size_t)R->n);
+    int *nuq = (int *)malloc(sizeof(int) * (size_t)R->n);
+    for (r = 0; r < R->n; r++) {
+        int cap = R->len[r] + 8, n;
+        uq[r] = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)cap);
+        n = orc_sketch(R->seq[r], R->len[r], P->w, P->k, P->hpc, uq[r], cap);
+        nuq[r] = orc_unique_sorted(uq[r], n);
+    }
+    *uq_out = uq; *nuq_out = nuq;
+}
+
+static void free_sketch(const readset *R, orc_mz **uq, int *nuq)
+{
+    int r;
+    for (r = 0; r < R->n; r++) free(uq[r]);
+    free(uq); free(nuq);
+}
+
+/* Build + verify + rescue + accept + path every window of every overlap of the set.
+ * Returns the window array (owned by caller); ov[].first_win/n_win index into it. */
+static orc_win *align_overlaps(const readset *R, orc_ovl *ov, int n_ov, const int32_t *cq, const int32_t *ct, int *n_win_out)
+{
+    int i, j, total = 0, wi;
+    orc_win *W;
+    char ybuf[ORC_WINDOW + 2 * ORC_K_MAX + 8];
+    uint64_t cols[5 * (ORC_WINDOW + 4)];
+    uint8_t tmp[2 * ORC_WINDOW + 4 * ORC_K_MAX + 16];
+    int rl[2 * ORC_WINDOW + 64];
+    uint8_t ro[2 * ORC_WINDOW + 64];
+    for (i = 0; i < n_ov; i++) {
+        ov[i].first_win = total;
+        ov[i].n_win = ov[i].x_e / ORC_WINDOW - ov[i].x_s / ORC_WINDOW + 1;
+        total += ov[i].n_win;
+    }
+    W = (orc_win *)calloc((size_t)total + 1, sizeof(orc_win));
+    for (i = 0; i < n_ov; i++) {
+        orc_ovl *o = &ov[i];
+        const char *x = R->seq[o->q], *y = R->seq[o->t];
+        int ylen = R->len[o->t], w0 = o->x_s / ORC_WINDOW;
+        int64_t tlen = 0, terr = 0;
+        o->align_len = 0;
+        for (j = 0; j < o->n_win; j++) {
+            orc_win *w = &W[o->first_win + j];
+            int gs = (w0 + j) * ORC_WINDOW, ge = gs + ORC_WINDOW - 1;
+            w->ovl = (uint32_t)i; w->win = (uint32_t)j;
+            w->x_start = gs > o->x_s ? gs : o->x_s;
+            w->x_len = (int16_t)((ge < o->x_e ? ge : o->x_e) - w->x_start + 1);
+            w->k = (uint8_t)orc_thr_for_len(w->x_len);
+            w->y_start = w->x_start + diag_at(cq + o->chain_off, ct + o->chain_off, o->n_chain, w->x_start);
+            window_verify(x, y, ylen, o->rev, w, ybuf);
+            if (w->err >= 0) o->align_len += w->x_len;
+        }
+        /* rescue, right-extension pass (Correct.cpp:2655-2744) */
+        for (j = o->n_win - 1; j >= 0; j--) {
+            orc_win *w = &W[o->first_win + j];
+            int k2, next;
+            if (w->err < 0) continue;
+            next = w->y_beg + w->end_site - w->extra_begin + 1;
+            for (k2 = j + 1; k2 < o->n_win && W[o->first_win + k2].err < 0; k2++) {
+                orc_win *u = &W[o->first_win + k2], trial = *u;
+                if (next >= ylen) break;
+                trial.k = (uint8_t)orc_double_thr(u->k, u->x_len);
+                trial.y_start = next;
+                if (!window_verify(x, y, ylen, o->rev, &trial, ybuf)) break;
+                if ((trial.x_len + 2 * trial.k - trial.extra_begin - trial.extra_end) + trial.k < trial.x_len) break;
+                if (trial.err < 0) break;
+                trial.rescued = 1;
+                *u = trial;
+                o->align_len += u->x_len;
+                next = u->y_beg + u->end_site - u->extra_begin + 1;
+            }
+        }
+        /* accept: 0.9 coverage filter, then error rate <= 0.03 with unmatched windows charged in full */
+        o->is_match = 0;
+        for (j = 0; j < o->n_win; j++) {
+            orc_win *w = &W[o->first_win + j];
+            tlen += w->x_len;
+            terr += w->err >= 0 ? w->err : w->x_len;
+        }
+        o->err_sum = (int32_t)terr;
+        if ((int64_t)(o->x_e - o->x_s + 1) * 9 <= (int64_t)o->align_len * 10 && terr * 100 <= tlen * 3) o->is_match = 1;
+        if (!o->is_match) continue;
+        for (j = 0; j < o->n_win; j++) {
+            orc_win *w = &W[o->first_win + j];
+            if (w->err >= 0) window_path(x, y, ylen, o->rev, w, ybuf, cols, tmp, rl, ro);
+        }
+    }
+    (void)wi;
+    *n_win_out = total;
+    return W;
+}
+
+/* consensus of read q given all accepted overlaps; returns new length, writes into out (cap >= 2*len+64) */
+static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, const orc_win *W, char *out)
+{
+    const char *x = R->seq[q];
+    int xlen = R->len[q], nwin = (xlen + ORC_WINDOW - 1) / ORC_WINDOW, g, i, outn = 0;
+    int32_t (*cnt)[6] = (int32_t (*)[6])malloc(sizeof(int32_t[6]) * (ORC_WINDOW + 1));
+    ins_slot (*ins)[INS_SLOTS] = (ins_slot (*)[INS_SLOTS])malloc(sizeof(ins_slot[INS_SLOTS]) * (ORC_WINDOW + 1));
+    int32_t *instot = (int32_t *)malloc(sizeof(int32_t) * (ORC_WINDOW + 1));
+    /* overlaps of q are contiguous in ov[] (generated q-major) */
+    int o0 = 0, o1;
+    while (o0 < n_ov && (int)ov[o0].q != q) o0++;
+    o1 = o0;
+    while (o1 < n_ov && (int)ov[o1].q == q) o1++;
+
+    for (g = 0; g < nwin; g++) {
+        int gs = g * ORC_WINDOW, glen = (gs + ORC_WINDOW <= xlen ? ORC_WINDOW : xlen - gs), cover = 0, c;
+        memset(cnt, 0, sizeof(int32_t[6]) * (ORC_WINDOW + 1));
+        memset(ins, 0, sizeof(ins_slot[INS_SLOTS]) * (ORC_WINDOW + 1));
+        memset(instot, 0, sizeof(int32_t) * (ORC_WINDOW + 1));
+        for (i = o0; i < o1; i++) {
+            const orc_ovl *o = &ov[i];
+            const orc_win *w;
+            const char *y = R->seq[o->t];
+            int ylen = R->len[o->t], j = g - o->x_s / ORC_WINDOW, xp, yp, p, pend;
+            if (!o->is_match || j < 0 || j >= o->n_win) continue;
+            w = &W[o->first_win + j];
+            if (w->err < 0) continue;
+            cover++;
+            xp = w->x_start - gs; yp = w->ry_start;
+            /* junction with the previous window of the same overlap: y bases skipped by both end-free
+             * alignments are an insertion in front of this window's first column */
+            pend = 0;
+            if (j > 0 && W[o->first_win + j - 1].err >= 0) {
+                int gap = w->ry_start - W[o->first_win + j - 1].ry_end - 1;
+                if (gap > 0 && xp == 0) {
+                    pend = 1;
+                    if (gap <= INS_MAXLEN) {
+                        uint32_t key = (uint32_t)gap << 24; int b;
+                        for (b = 0; b < gap; b++) key |= (uint32_t)base2(ybase(y, ylen, o->rev, w->ry_start - gap + b)) << (2 * b);
+                        ins_vote(ins[0], key);
+                    }
+                }
+            }
+            for (p = 0; p < w->path_len; ) {
+                int op = w->path[p];
+                if (op == 2) { /* run of y-only bases in front of column xp */
+                    int L = 0;
+                    while (p + L < w->path_len && w->path[p + L] == 2) L++;
+                    if (xp < glen) {
+                        pend = 1;
+                        if (L <= INS_MAXLEN) {
+                            uint32_t key = (uint32_t)L << 24; int b;
+                            for (b = 0; b < L; b++) key |= (uint32_t)base2(ybase(y, ylen, o->rev, yp + b)) << (2 * b);
+                            ins_vote(ins[xp], key);
+                        }
+                    }
+                    yp += L; p += L;
+                    continue;
+                }
+                cnt[xp][5]++;               /* reads arriving at this column */
+                if (pend) { instot[xp]++; pend = 0; } /* ... of which after an insertion */
+                if (op == 3) cnt[xp][4]++;  /* x base without partner: deletion vote */
+                else { cnt[xp][base2(ybase(y, ylen, o->rev, yp))]++; yp++; }
+                xp++; p++;
+            }
+        }
+        if (cover < 3) { /* MIN_COVERAGE_THRESHOLD: copy verbatim */
+            memcpy(out + outn, x + gs, (size_t)glen); outn += glen;
+            continue;
+        }
+        for (c = 0; c < glen; c++) {
+            int homo = is_homopolymer_site(x, xlen, gs + c), b, bestb, bestc, total;
+            /* (1) what sits between column c-1 and c: nothing, or an inserted string */
+            {
+                int none = cnt[c][5] - instot[c] + 1; /* + the read itself */
+                int bi = -1, s;
+                total = cnt[c][5] + 1;
+                for (s = 0; s < INS_SLOTS; s++) if (ins[c][s].cnt && (bi < 0 || ins[c][s].cnt > ins[c][bi].cnt)) bi = s;
+                if (bi >= 0 && ins[c][bi].cnt > none && wins(ins[c][bi].cnt, total, homo)) {
+                    int L = (int)(ins[c][bi].key >> 24);
+                    for (b = 0; b < L; b++) out[outn++] = "ACGT"[(ins[c][bi].key >> (2 * b)) & 3];
+                }
+            }
+            /* (2) the column itself: A/C/G/T or deleted */
+            {
+                int own = base2(x[gs + c]);
+                int v[5];
+                for (b = 0; b < 5; b++) v[b] = cnt[c][b];
+                v[own]++; /* backbone's own base starts with weight 1 (POA.cpp:269-307) */
+                total = v[0] + v[1] + v[2] + v[3] + v[4];
+                bestb = own; bestc = v[own];
+                for (b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
+                if (bestb != own && !wins(bestc, total, homo)) bestb = own;
+                if (bestb < 4) out[outn++] = "ACGT"[bestb];
+            }
+        }
+    }
+    free(cnt); free(ins); free(instot);
+    (void)i;
+    return outn;
+}
+
+/* one correction round: R -> corrected reads (new buffers); returns total windows examined */
+static void correction_round(readset *R, const orc_asm_params *P, int do_rc)
+{
+    orc_mz **uq; int *nuq, n_ov, n_win, q;
+    orc_ovl *ov; int32_t *cq, *ct; orc_win *W;
+    char **nseq = (char **)malloc(sizeof(char *) * (size_t)R->n);
+    int *nlen = (int *)malloc(sizeof(int) * (size_t)R->n);
+    sketch_set(R, P, &uq, &nuq);
+    collect_overlaps(R, P, P->bw_ec, uq, nuq, &ov, &cq, &ct, &n_ov);
+    W = align_overlaps(R, ov, n_ov, cq, ct, &n_win);
+    for (q = 0; q < R->n; q++) {
+        nseq[q] = (char *)malloc((size_t)R->len[q] * 2 + 64 + (size_t)ORC_WINDOW * 16);
+        nlen[q] = correct_read(R, q, ov, n_ov, W, nseq[q]);
+        if (do_rc) revcomp_inplace(nseq[q], nlen[q]);
+    }
+    for (q = 0; q < R->n; q++) { free(R->seq[q]); R->seq[q] = nseq[q]; R->len[q] = nlen[q]; }
+    free(nseq); free(nlen); free(W); free(ov); free(cq); free(ct);
+    free_sketch(R, uq, nuq);
+}
+
+/* ---------------------------------------------------------------- S9 + S10 */
+typedef struct { int to, to_rev, ovl; } arc_t; /* best successor of an oriented read */
+
+void orc_asm_default_params(orc_asm_params *P)
+{
+    P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
+    P->bw_ec = 20; P->bw_final = 1; P->min_contig_reads = 2;
+}
+
+/* Exact overlaps of the corrected reads; returns the accepted hits (exact == 1) in ov[] */
+static int final_overlaps(const readset *R, const orc_asm_params *P, orc_ovl **out)
+{
+    orc_mz **uq; int *nuq, n_ov, i, m = 0;
+    orc_ovl *ov; int32_t *cq, *ct;
+    sketch_set(R, P, &uq, &nuq);
+    collect_overlaps(R, P, P->bw_final, uq, nuq, &ov, &cq, &ct, &n_ov);
+    for (i = 0; i < n_ov; i++) {
+        orc_ovl *o = &ov[i];
+        const char *x = R->seq[o->q], *y = R->seq[o->t];
+        int ylen = R->len[o->t], L = o->x_e - o->x_s + 1, p, same = (L == o->y_e - o->y_s + 1);
+        for (p = 0; same && p < L; p++) if (x[o->x_s + p] != ybase(y, ylen, o->rev, o->y_s + p)) same = 0;
+        o->exact = (uint8_t)same;
+        if (same) ov[m++] = *o;
+    }
+    free(cq); free(ct);
+    free_sketch(R, uq, nuq);
+    *out = ov;
+    return m;
+}
+
+/* Layout.  Oriented node v = 2*read + strand.  A hit (q fwd, t strand rev) with x_e == lenq-1, y_s == 0 is the arc
+ * (q,+) -> (t,rev) and, complemented, (t,!rev) -> (q,-).  Contained reads are dropped first (ma_hit_contained),
+ * every node keeps its longest out-arc (what transitive reduction leaves on error-free linear data), and arcs
+ * that are mutually best are walked into unitigs. */
+int orc_layout(const int *len, int n, const orc_ovl *hit, int n_hit, int min_reads, int32_t *piece_read, uint8_t *piece_rev,
+               int32_t *piece_len, int32_t *contig_first, int piece_cap, int contig_cap)
+{
+    uint8_t *contained = (uint8_t *)calloc((size_t)n, 1), *used = (uint8_t *)calloc((size_t)n, 1);
+    int32_t *succ = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 2), *sovl = (int32_t *)calloc((size_t)n * 2, sizeof(int32_t));
+    int32_t *pred = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 2);
+    int i, v, n_piece = 0, n_contig = 0, pass;
+    for (i = 0; i < n_hit; i++) {
+        const orc_ovl *h = &hit[i];
+        int qfull = h->x_s == 0 && h->x_e == len[h->q] - 1, tfull = h->y_s == 0 && h->y_e == len[h->t] - 1;
+        if (qfull && tfull) { if (h->q > h->t) contained[h->q] = 1; } /* identical reads: keep the lower index */
+        else if (qfull) contained[h->q] = 1;
+    }
+    for (v = 0; v < 2 * n; v++) { succ[v] = -1; pred[v] = -1; }
+    for (i = 0; i < n_hit; i++) {
+        const orc_ovl *h = &hit[i];
+        int L = h->x_e - h->x_s + 1, a, b;
+        if (contained[h->q] || contained[h->t]) continue;
+        if (h->x_e == len[h->q] - 1 && h->y_s == 0 && h->x_s > 0) { a = 2 * (int)h->q; b = 2 * (int)h->t + h->rev; }       /* (q,+) -> (t,rev) */
+        else if (h->x_s == 0 && h->y_e == len[h->t] - 1 && h->x_e < len[h->q] - 1) { a = 2 * (int)h->t + h->rev; b = 2 * (int)h->q; } /* (t,rev) -> (q,+) */
+        else continue;
+        /* the arc and its complement */
+        for (pass = 0; pass < 2; pass++) {
+            int from = pass ? (b ^ 1) : a, to = pass ? (a ^ 1) : b;
+            if (L > sovl[from] || (L == sovl[from] && succ[from] >= 0 && to < succ[from])) { succ[from] = to; sovl[from] = L; }
+        }
+    }
+    /* keep mutually-best arcs only: v -> w is kept when the best out-arc of ~w is ~v */
+    for (v = 0; v < 2 * n; v++) {
+        int w = succ[v];
+        if (w >= 0 && succ[w ^ 1] != (v ^ 1)) succ[v] = -1;
+    }
+    for (v = 0; v < 2 * n; v++) if (succ[v] >= 0) pred[succ[v]] = v;
+    for (pass = 0; pass < 2; pass++) { /* pass 0: paths with a free start; pass 1: leftovers (cycles) */
+        for (v = 0; v < 2 * n; v++) {
+            int r = v >> 1, cnt = 0, w, first = n_piece;
+            if (contained[r] || used[r]) continue;
+            if (pass == 0 && pred[v] >= 0) continue;
+            for (w = v; w >= 0 && !used[w >> 1]; w = succ[w]) cnt++;
+            if (cnt < min_reads) { if (pass == 0 && succ[v] < 0 && pred[v] < 0 && (v & 1) == 0) {} continue; }
+            if (n_contig >= contig_cap || n_piece + cnt > piece_cap) break;
+            for (w = v; w >= 0 && !used[w >> 1]; w = succ[w]) {
+                used[w >> 1] = 1;
+                piece_read[n_piece] = w >> 1; piece_rev[n_piece] = (uint8_t)(w & 1);
+                piece_len[n_piece] = (succ[w] >= 0 && !used[succ[w] >> 1]) ? len[w >> 1] - sovl[w] : len[w >> 1];
+                n_piece++;
+            }
+            contig_first[n_contig++] = first;
+        }
+    }
+    if (n_contig == 0) { /* nothing chained: fall back to the longest uncontained read so the region is not silently empty */
+        int bestr = -1;
+        for (i = 0; i < n; i++) if (!contained[i] && (bestr < 0 || len[i] > len[bestr])) bestr = i;
+        if (bestr >= 0 && piece_cap > 0 && contig_cap > 0) {
+            piece_read[0] = bestr; piece_rev[0] = 0; piece_len[0] = len[bestr]; contig_first[0] = 0; n_piece = 1; n_contig = 1;
+        }
+    }
+    contig_first[n_contig] = n_piece;
+    free(contained); free(used); free(succ); free(sovl); free(pred);
+    return n_contig;
+}
+
+int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const orc_asm_params *P,
+                 char *contigs, uint64_t contigs_cap, uint64_t *contig_off, int contig_cap, int *n_contigs,
+                 char *corrected, uint64_t corrected_cap, uint64_t *corrected_off)
+{
+    readset R;
+    orc_ovl *hits; int n_hit, r, i, c, nc;
+    int32_t *piece_read, *piece_len, *contig_first; uint8_t *piece_rev;
+    uint64_t used = 0;
+    R.n = n_reads;
+    R.seq = (char **)malloc(sizeof(char *) * (size_t)n_reads);
+    R.len = (int *)malloc(sizeof(int) * (size_t)n_reads);
+    for (r = 0; r < n_reads; r++) {
+        R.len[r] = (int)(seq_off[r + 1] - seq_off[r]);
+        R.seq[r] = (char *)malloc((size_t)R.len[r] + 1);
+        for (i = 0; i < R.len[r]; i++) { char ch = seqs[seq_off[r] + i]; R.seq[r][i] = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? ch : 'A'; }
+    }
+    for (i = 0; i < P->n_rounds; i++) correction_round(&R, P, i + 1 < P->n_rounds);
+    if (corrected && corrected_off) {
+        uint64_t u = 0;
+        for (r = 0; r < n_reads; r++) {
+            corrected_off[r] = u;
+            if (u + (uint64_t)R.len[r] <= corrected_cap) memcpy(corrected + u, R.seq[r], (size_t)R.len[r]);
+            u += (uint64_t)R.len[r];
+        }
+        corrected_off[n_reads] = u;
+    }
+    n_hit = final_overlaps(&R, P, &hits);
+    piece_read = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 1));
+    piece_len = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 1));
+    piece_rev = (uint8_t *)malloc((size_t)n_reads + 1);
+    contig_first = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 2));
+    nc = orc_layout(R.len, n_reads, hits, n_hit, P->min_contig_reads, piece_read, piece_rev, piece_len, contig_first, n_reads, contig_cap < n_reads ? contig_cap : n_reads);
+    for (c = 0; c < nc; c++) {
+        contig_off[c] = used;
+        for (i = contig_first[c]; i < contig_first[c + 1]; i++) {
+            int rd = piece_read[i], L = piece_len[i], p;
+            if (used + (uint64_t)L > contigs_cap) { nc = c; goto done; }
+            for (p = 0; p < L; p++) contigs[used + p] = ybase(R.seq[rd], R.len[rd], piece_rev[i], p);
+            used += (uint64_t)L;
+        }
+    }
+done:
+    contig_off[nc] = used;
+    *n_contigs = nc;
+    for (r = 0; r < n_reads; r++) free(R.seq[r]);
+    free(R.seq); free(R.len); free(hits); free(piece_read); free(piece_len); free(piece_rev); free(contig_first);
+    return 0;
+}

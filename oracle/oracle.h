@@ -1,0 +1,69 @@
+/* oracle/oracle.h -- TEST INFRASTRUCTURE ONLY: shared types of the CPU restatement. */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+
+typedef struct {
+    uint64_t hash;
+    uint32_t pos;   /* index of the k-mer's last base in the read */
+    uint8_t  rev;   /* strand with the smaller encoding */
+    uint8_t  span;  /* uncompressed bases covered */
+    uint16_t pad;
+} orc_mz;           /* 16 bytes, same layout as fsv_mz */
+
+#define ORC_WINDOW 375
+#define ORC_K_FULL 15
+#define ORC_K_MAX  31
+#define ORC_PATH_CAP 448
+
+typedef struct {
+    int32_t k, w, hpc;        /* minimizer scheme: 51, 51, 1 (hifiasm defaults, CommandLines.cpp:109-166) */
+    int32_t n_rounds;         /* correction rounds: 3 */
+    int32_t min_ovlp;         /* shortest overlap kept: 500 */
+    int32_t min_anchors;      /* shortest chain kept: 3 */
+    int32_t lookback;         /* chain DP predecessors examined: 64 */
+    int32_t bw_ec;            /* chain indel budget per mille in correction rounds: 20 (0.02) */
+    int32_t bw_final;         /* ... in the final overlap pass: 1 (0.001) */
+    int32_t min_contig_reads; /* contigs built from fewer reads are dropped unless none is left: 2 */
+} orc_asm_params;
+
+typedef struct {
+    uint32_t q, t;            /* read indices inside the set */
+    int32_t x_s, x_e;         /* inclusive range on q (forward strand) */
+    int32_t y_s, y_e;         /* inclusive range on t in strand coordinates */
+    int32_t score, n_chain;
+    int32_t chain_off;        /* offset of this overlap's anchors in the chain arrays */
+    int32_t first_win, n_win;
+    int32_t align_len, err_sum;
+    uint8_t rev, is_match, exact, pad;
+} orc_ovl;                    /* 56 bytes, same layout as fsv_ovl */
+
+typedef struct {
+    uint32_t ovl, win;
+    int32_t x_start, y_start; /* y_start: predicted partner of x_start (before the -k pad) */
+    int32_t y_beg;            /* first in-read base covered by the padded window */
+    int32_t end_site, err;
+    int32_t ry_start, ry_end; /* absolute strand coordinates of the aligned y interval (after S6) */
+    int16_t x_len, extra_begin, extra_end, path_len;
+    uint8_t k, rescued, pad[2];
+    uint8_t path[ORC_PATH_CAP]; /* start-to-end ops: 0 match 1 mismatch 2 y-only 3 x-only */
+} orc_win;
+
+int orc_thr_for_len(int x_len);
+int orc_double_thr(int pre, int x_len);
+int orc_unique_sorted(orc_mz *mz, int n);
+int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, int lent, const orc_asm_params *P,
+                   int bw_per_mille, orc_ovl *o, int32_t *chain_qe, int32_t *chain_te, int chain_cap);
+void orc_asm_default_params(orc_asm_params *P);
+/* whole path for one read set; see oracle/asm.c */
+int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const orc_asm_params *P,
+                 char *contigs, uint64_t contigs_cap, uint64_t *contig_off, int contig_cap, int *n_contigs,
+                 char *corrected, uint64_t corrected_cap, uint64_t *corrected_off);
+int orc_sketch(const char *s, int len, int w, int k, int hpc, orc_mz *out, int cap);
+int orc_bpm(const char *y, int m, const char *x, int n, int k, int *err);
+int orc_bpm_path(const char *y, int m, const char *x, int n, int k, int *err, int *start_site, int *path_len,
+                 uint8_t *path, uint64_t *cols);
+int orc_try_cigar(const char *y, const char *x, int n, int end_site, int error, uint8_t *path, int *start_site, int *path_len);
+int orc_generate_cigar(uint8_t *path, int plen, int n, const char *x, const char *y, int *start, int *end, int *err,
+                       int *run_len, uint8_t *run_op);
+#endif

@@ -47,3 +47,48 @@ def generate_cigar(path: bytes, x: str, y: str, start: int, end: int, err: int):
     nrun = lib().orc_generate_cigar(p, len(path), n, x.encode(), y.encode(), C.byref(st), C.byref(en), C.byref(er), rl, ro)
     s = "".join(f"{rl[i]}{'MXID'[ro[i]]}" for i in range(nrun))
     return st.value, en.value, er.value, s
+
+
+import numpy as np
+
+MZ_DTYPE = np.dtype([("hash", "<u8"), ("pos", "<u4"), ("rev", "u1"), ("span", "u1"), ("pad", "<u2")])
+
+
+def sketch(seq: str, w=51, k=51, hpc=1):
+    cap = len(seq) + 8
+    out = np.zeros(cap, dtype=MZ_DTYPE)
+    n = lib().orc_sketch(seq.encode(), len(seq), w, k, hpc, out.ctypes.data_as(C.c_void_p), cap)
+    assert n <= cap
+    return out[:n]
+
+
+class AsmParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads")]
+
+
+def default_params():
+    p = AsmParams()
+    lib().orc_asm_default_params(C.byref(p))
+    return p
+
+
+def assemble(reads, params=None):
+    """reads: list of bytes -> (contigs list[bytes], corrected list[bytes])"""
+    p = params or default_params()
+    n = len(reads)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in reads], out=off[1:])
+    seqs = b"".join(reads)
+    cap = int(off[-1]) * 2 + 1024
+    contigs = C.create_string_buffer(cap)
+    corrected = C.create_string_buffer(cap)
+    coff = np.zeros(n + 2, dtype=np.uint64)
+    roff = np.zeros(n + 1, dtype=np.uint64)
+    nc = C.c_int(0)
+    rc = lib().orc_assemble(seqs, off.ctypes.data_as(C.c_void_p), n, C.byref(p), contigs, C.c_uint64(cap),
+                            coff.ctypes.data_as(C.c_void_p), n, C.byref(nc), corrected, C.c_uint64(cap), roff.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    raw = contigs.raw
+    craw = corrected.raw
+    return ([raw[int(coff[i]):int(coff[i + 1])] for i in range(nc.value)],
+            [craw[int(roff[i]):int(roff[i + 1])] for i in range(n)])
