@@ -151,10 +151,10 @@ int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, i
             if (dq <= 0 || dt <= 0) continue;
             gap = dq > dt ? dq - dt : dt - dq;
             ti = ind[j] + gap; tl = sl[j] + dq;
-            if ((int64_t)ti * 1000 > (int64_t)tl * bw_per_mille) continue;
+            if ((int64_t)ti * 1000 > (int64_t)tl * bw_per_mille) continue; /* bw 0 = co-linear anchors only */
             sc = dq < dt ? dq : dt;
             if (sc > P->k) sc = P->k;
-            sc -= (int32_t)(((int64_t)ti * sc * 1000) / ((int64_t)tl * bw_per_mille));
+            if (ti) sc -= (int32_t)(((int64_t)ti * sc * 1000) / ((int64_t)tl * bw_per_mille));
             sc += f[j];
             if (sc > bs) { bs = sc; bp = j; bi = ti; bl = tl; }
         }
@@ -532,7 +532,7 @@ typedef struct { int to, to_rev, ovl; } arc_t; /* best successor of an oriented 
 void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
-    P->bw_ec = 20; P->bw_final = 1; P->min_contig_reads = 2;
+    P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 2;
 }
 
 /* Exact overlaps of the corrected reads; returns the accepted hits (exact == 1) in ov[] */
@@ -591,6 +591,9 @@ int orc_layout(const int *len, int n, const orc_ovl *hit, int n_hit, int min_rea
     for (v = 0; v < 2 * n; v++) {
         int w = succ[v];
         if (w >= 0 && succ[w ^ 1] != (v ^ 1)) succ[v] = -1;
+    }
+    if (getenv("ORC_DEBUG_LAYOUT")) {
+        for (i = 0; i < n; i++) fprintf(stderr, "read %d len %d contained %d succ+ %d(%d) succ- %d(%d)\n", i, len[i], contained[i], succ[2*i], sovl[2*i], succ[2*i+1], sovl[2*i+1]);
     }
     for (v = 0; v < 2 * n; v++) if (succ[v] >= 0) pred[succ[v]] = v;
     for (pass = 0; pass < 2; pass++) { /* pass 0: paths with a free start; pass 1: leftovers (cycles) */

@@ -23,7 +23,9 @@ typedef struct {
     int32_t min_anchors;      /* shortest chain kept: 3 */
     int32_t lookback;         /* chain DP predecessors examined: 64 */
     int32_t bw_ec;            /* chain indel budget per mille in correction rounds: 20 (0.02) */
-    int32_t bw_final;         /* ... in the final overlap pass: 1 (0.001) */
+    int32_t bw_final;         /* ... in the final overlap pass: 0 = co-linear anchors only (hifiasm: 0.001; a read that ends inside a
+                                 homopolymer run yields an HPC k-mer whose end is off by the truncated bases, which a non-zero
+                                 budget lets into the chain and shifts the exact-overlap interval by one) */
     int32_t min_contig_reads; /* contigs built from fewer reads are dropped unless none is left: 2 */
 } orc_asm_params;
 
