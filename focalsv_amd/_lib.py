@@ -21,6 +21,27 @@ WRES_DTYPE = np.dtype(
 assert WTASK_DTYPE.itemsize == 32 and WRES_DTYPE.itemsize == 16
 
 
+class AsmParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final",
+                                         "min_contig_reads")]
+
+
+class ReadSets(C.Structure):
+    _fields_ = [("store_dev", C.c_void_p), ("word_off", C.c_void_p), ("read_len", C.c_void_p), ("set_start", C.c_void_p),
+                ("n_reads", C.c_uint32), ("n_sets", C.c_uint32)]
+
+
+class Contigs(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("seq_cap", C.c_uint64), ("off", C.c_void_p), ("set", C.c_void_p), ("n_reads", C.c_void_p),
+                ("contig_cap", C.c_uint32), ("n_contigs", C.c_uint32), ("set_status", C.c_void_p)]
+
+
+class AsmStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_pairs", "n_overlaps", "n_windows", "n_windows_matched", "n_paths", "n_path_dp",
+                                          "dp_columns", "algo_bytes", "n_exact_overlaps")] + \
+               [(n, C.c_double) for n in ("ms_sketch", "ms_chain", "ms_verify", "ms_path", "ms_consensus", "ms_final", "ms_total")]
+
+
 class FsvError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -58,6 +79,11 @@ def load():
         "fsv_pack_reads": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_size_t, vp]),
         "fsv_bpm_windows_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
         "fsv_bpm_windows": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp]),
+        "fsv_asm_default_params": (None, [C.POINTER(AsmParams)]),
+        "fsv_assemble_batch_bound": (C.c_int, [C.POINTER(ReadSets), u64p, u32p]),
+        "fsv_assemble_batch": (C.c_int, [vp, C.POINTER(ReadSets), C.POINTER(AsmParams), C.POINTER(Contigs)]),
+        "fsv_asm_last_stats": (C.c_int, [vp, C.POINTER(AsmStats)]),
+        "fsv_asm_fetch_reads": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -142,3 +168,53 @@ class Context:
     def bpm_windows_dev(self, store_ptr, tasks_ptr, n_tasks, res_ptr):
         self.check(self._lib.fsv_bpm_windows_dev(self._h, C.c_void_p(store_ptr), C.c_void_p(tasks_ptr), n_tasks, C.c_void_p(res_ptr)),
                    "fsv_bpm_windows_dev")
+
+
+    # assembler boundary -------------------------------------------------------------
+    def default_asm_params(self):
+        p = AsmParams()
+        self._lib.fsv_asm_default_params(C.byref(p))
+        return p
+
+    def upload(self, arr):
+        """numpy array -> device pointer (caller frees with dev_free)."""
+        arr = np.ascontiguousarray(arr)
+        ptr = C.c_void_p()
+        self.check(self._lib.fsv_dev_alloc(self._h, arr.nbytes + 64, C.byref(ptr)), "fsv_dev_alloc")
+        self.check(self._lib.fsv_h2d(self._h, ptr, _ptr(arr), arr.nbytes), "fsv_h2d")
+        return ptr.value
+
+    def dev_free(self, ptr):
+        self.check(self._lib.fsv_dev_free(self._h, C.c_void_p(ptr)), "fsv_dev_free")
+
+    def assemble_batch(self, store_dev, word_off, read_len, set_start, params=None):
+        """fsv_assemble_batch.  store_dev: device pointer of the 2-bit store; the rest are host numpy arrays.
+        -> (contigs: list[bytes], contig_set: ndarray, contig_n_reads: ndarray, set_status: ndarray)"""
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        read_len = np.ascontiguousarray(read_len, dtype=np.int32)
+        set_start = np.ascontiguousarray(set_start, dtype=np.uint32)
+        rs = ReadSets(C.c_void_p(store_dev), _ptr(word_off).value, _ptr(read_len).value, _ptr(set_start).value, len(read_len), len(set_start) - 1)
+        cap, ccap = C.c_uint64(), C.c_uint32()
+        self.check(self._lib.fsv_assemble_batch_bound(C.byref(rs), C.byref(cap), C.byref(ccap)), "fsv_assemble_batch_bound")
+        seq = np.empty(cap.value, dtype=np.uint8)
+        off = np.zeros(ccap.value + 1, dtype=np.uint64)
+        cset = np.zeros(ccap.value, dtype=np.uint32)
+        cnr = np.zeros(ccap.value, dtype=np.uint32)
+        status = np.zeros(max(1, rs.n_sets), dtype=np.int32)
+        out = Contigs(_ptr(seq).value, cap.value, _ptr(off).value, _ptr(cset).value, _ptr(cnr).value, ccap.value, 0, _ptr(status).value)
+        p = params if params is not None else self.default_asm_params()
+        self.check(self._lib.fsv_assemble_batch(self._h, C.byref(rs), C.byref(p), C.byref(out)), "fsv_assemble_batch")
+        n = out.n_contigs
+        contigs = [seq[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
+        return contigs, cset[:n].copy(), cnr[:n].copy(), status[:rs.n_sets].copy()
+
+    def asm_stats(self):
+        st = AsmStats()
+        self.check(self._lib.fsv_asm_last_stats(self._h, C.byref(st)), "fsv_asm_last_stats")
+        return {n: getattr(st, n) for n, _ in AsmStats._fields_}
+
+    def fetch_reads(self, n_reads, total_cap):
+        seq = np.empty(total_cap, dtype=np.uint8)
+        off = np.zeros(n_reads + 1, dtype=np.uint64)
+        self.check(self._lib.fsv_asm_fetch_reads(self._h, _ptr(seq), total_cap, _ptr(off), n_reads), "fsv_asm_fetch_reads")
+        return [seq[int(off[i]):int(off[i + 1])].tobytes() for i in range(n_reads)]

@@ -1,0 +1,466 @@
+// asm.hip -- host orchestration of the batched per-read-set assembly (fsv_assemble_batch).
+//
+// Replaces the process boundary `hifiasm -o <prefix> -t T <reads.fa>` + GFA read-back
+// (focalsv/3_assembly/run_assembly.py:15-44, post_assembly.py:79-95).  All base-level work runs in the
+// kernels of asm_kernels.h; the host only sizes buffers between stages and walks the (tiny, <= a few
+// hundred nodes per set) overlap graph, which is host code in hifiasm as well (Overlaps.cpp).
+#include "asm_kernels.h"
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct AsmWs {
+    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
+        cols, tmp, gwin_off, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+    // state of the last run (for fsv_asm_fetch_reads / stats)
+    std::vector<uint32_t> h_word_off;
+    std::vector<int32_t> h_len;
+    const uint32_t *cur_store = nullptr;
+    uint32_t n_reads = 0;
+    fsv_asm_stats stats;
+    std::vector<DevBuf *> all()
+    {
+        return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+    }
+};
+
+void ws_free(fsv_ctx *ctx)
+{
+    AsmWs *w = (AsmWs *)ctx->asm_ws;
+    if (!w) return;
+    for (DevBuf *b : w->all()) if (b->p) (void)hipFree(b->p);
+    delete w;
+    ctx->asm_ws = nullptr;
+}
+
+AsmWs *ws_get(fsv_ctx *ctx)
+{
+    if (!ctx->asm_ws) { ctx->asm_ws = new AsmWs(); ctx->asm_ws_free = ws_free; memset(&((AsmWs *)ctx->asm_ws)->stats, 0, sizeof(fsv_asm_stats)); }
+    return (AsmWs *)ctx->asm_ws;
+}
+
+int ensure(fsv_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return FSV_OK;
+    if (b.p) { FSV_HIP(ctx, hipStreamSynchronize(ctx->stream)); FSV_HIP(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    FSV_HIP(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return FSV_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != FSV_OK) return rc_; } while (0)
+
+template <class T> int upload(fsv_ctx *ctx, DevBuf &b, const std::vector<T> &v)
+{
+    TRY(ensure(ctx, b, v.size() * sizeof(T)));
+    FSV_HIP(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return FSV_OK;
+}
+
+struct Timer {
+    std::chrono::steady_clock::time_point t0;
+    fsv_ctx *ctx;
+    explicit Timer(fsv_ctx *c) : ctx(c) { (void)hipStreamSynchronize(c->stream); t0 = std::chrono::steady_clock::now(); }
+    double stop() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+uint8_t thr_for_len_host(int x_len)
+{
+    // verify_window: threshold = x_len * max_ov_diff_ec (0.04 as a double, truncated), Adjust_Threshold (Correct.h:39)
+    if (x_len == FSV_WINDOW) return FSV_K_FULL;
+    int t = (int)(x_len * 0.04);
+    if (t == 0 && x_len >= 4) t = 1;
+    return (uint8_t)t;
+}
+
+struct Batch {
+    uint32_t n_reads = 0, n_sets = 0, n_pairs = 0;
+    std::vector<uint32_t> set_start, read_set, pair_base;
+};
+
+// per-round geometry derived from the current read lengths
+struct Geometry {
+    std::vector<uint32_t> word_off, mz_off, gwin_off;
+    uint64_t task_bound = 0;
+};
+
+int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len, Geometry &G)
+{
+    G.word_off.assign(B.n_reads + 1, 0); G.mz_off.assign(B.n_reads + 1, 0); G.gwin_off.assign(B.n_reads + 1, 0);
+    uint64_t w = 0, m = 0, g = 0;
+    for (uint32_t r = 0; r < B.n_reads; r++) {
+        G.word_off[r] = (uint32_t)w; G.mz_off[r] = (uint32_t)m; G.gwin_off[r] = (uint32_t)g;
+        w += (uint64_t)(len[r] + 15) / 16;
+        m += (uint64_t)len[r] / 8 + 64;
+        g += (uint64_t)(len[r] + FSV_WINDOW - 1) / FSV_WINDOW;
+    }
+    if (w + 4 >= (1ull << 32) || m >= (1ull << 32) || g >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "batch too large for 32-bit offsets; split it");
+    G.word_off[B.n_reads] = (uint32_t)w; G.mz_off[B.n_reads] = (uint32_t)m; G.gwin_off[B.n_reads] = (uint32_t)g;
+    G.task_bound = 0;
+    for (uint32_t s = 0; s < B.n_sets; s++) {
+        uint64_t nw = 0;
+        uint32_t ns = B.set_start[s + 1] - B.set_start[s];
+        for (uint32_t r = B.set_start[s]; r < B.set_start[s + 1]; r++) nw += G.gwin_off[r + 1] - G.gwin_off[r];
+        if (ns > 1) G.task_bound += nw * (ns - 1);
+    }
+    return FSV_OK;
+}
+
+// sketch + per-read index + chaining on the current store; fills ws.ovl (and ws.tasks when emit_tasks)
+int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, const uint32_t *store, const fsv_asm_params &P, int bw,
+                  bool emit_tasks, uint32_t task_cap)
+{
+    Timer ts(ctx);
+    TRY(ensure(ctx, W.mz, (size_t)G.mz_off[B.n_reads] * sizeof(fsv_mz)));
+    TRY(ensure(ctx, W.mz_cnt, (size_t)B.n_reads * 4));
+    TRY(ensure(ctx, W.ovl, (size_t)std::max(1u, B.n_pairs) * sizeof(fsv_ovl)));
+    TRY(ensure(ctx, W.counters, 64));
+    FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_sketch, dim3(fsv_grid_for(B.n_reads, 64)), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
+                       (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
+                       P.hpc, (uint32_t *)W.warn.p);
+    FSV_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_uniq, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
+                       (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p);
+    FSV_HIP(ctx, hipGetLastError());
+    W.stats.ms_sketch += ts.stop();
+    if (B.n_pairs == 0) return FSV_OK;
+    Timer tc(ctx);
+    ChainArgs A;
+    A.store = store; A.word_off = (const uint32_t *)W.word_off.p; A.read_len = (const int32_t *)W.len.p;
+    A.set_start = (const uint32_t *)W.set_start.p; A.pair_base = (const uint32_t *)W.pair_base.p;
+    A.mz = (const fsv_mz *)W.mz.p; A.mz_off = (const uint32_t *)W.mz_off.p; A.mz_cnt = (const uint32_t *)W.mz_cnt.p;
+    A.ovl = (fsv_ovl *)W.ovl.p; A.tasks = (fsv_wtask *)W.tasks.p; A.task_counter = (uint32_t *)W.counters.p; A.task_cap = task_cap;
+    A.overflow = (uint32_t *)W.counters.p + 1; A.warn = (uint32_t *)W.warn.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
+    A.n_sets = B.n_sets; A.k_score = P.k; A.min_anchors = P.min_anchors; A.min_ovlp = P.min_ovlp; A.bw = bw; A.emit_tasks = emit_tasks ? 1 : 0;
+    hipLaunchKernelGGL(k_chain, dim3(B.n_pairs), dim3(64), 0, ctx->stream, A);
+    FSV_HIP(ctx, hipGetLastError());
+    W.stats.ms_chain += tc.stop();
+    return FSV_OK;
+}
+
+// ---- layout (host): containment removal, longest mutual out-arcs, unitig walk ------------------------------
+// Oriented node v = 2*read + strand.  A hit (q forward, t on strand rev) with x_e == len(q)-1 and y_s == 0 is the
+// arc (q,+) -> (t,rev); its complement is (t,!rev) -> (q,-).  Mirrors ma_hit_contained / ma_hit2arc / asg_arc_del_trans
+// on error-free linear data (Overlaps.cpp:1198, 2152, 4531; Overlaps.h:178-246) and ma_ug_seq for the sequence.
+struct Piece { uint32_t read, rev, len; };
+void layout_set(const int32_t *len, uint32_t n, const fsv_ovl *hit, uint32_t n_hit, int min_reads, std::vector<std::vector<Piece>> &contigs,
+                bool &fallback)
+{
+    std::vector<uint8_t> contained(n, 0), used(n, 0);
+    std::vector<int32_t> succ(2 * n, -1), sovl(2 * n, 0), pred(2 * n, -1);
+    fallback = false;
+    for (uint32_t i = 0; i < n_hit; i++) {
+        const fsv_ovl &h = hit[i];
+        if (!h.valid || !h.exact) continue;
+        bool qfull = h.x_s == 0 && h.x_e == len[h.q] - 1, tfull = h.y_s == 0 && h.y_e == len[h.t] - 1;
+        if (qfull && tfull) { if (h.q > h.t) contained[h.q] = 1; }
+        else if (qfull) contained[h.q] = 1;
+    }
+    for (uint32_t i = 0; i < n_hit; i++) {
+        const fsv_ovl &h = hit[i];
+        if (!h.valid || !h.exact || contained[h.q] || contained[h.t]) continue;
+        const int L = h.x_e - h.x_s + 1;
+        int a, b;
+        if (h.x_e == len[h.q] - 1 && h.y_s == 0 && h.x_s > 0) { a = 2 * (int)h.q; b = 2 * (int)h.t + h.rev; }
+        else if (h.x_s == 0 && h.y_e == len[h.t] - 1 && h.x_e < len[h.q] - 1) { a = 2 * (int)h.t + h.rev; b = 2 * (int)h.q; }
+        else continue;
+        for (int pass = 0; pass < 2; pass++) {
+            const int from = pass ? (b ^ 1) : a, to = pass ? (a ^ 1) : b;
+            if (L > sovl[from] || (L == sovl[from] && succ[from] >= 0 && to < succ[from])) { succ[from] = to; sovl[from] = L; }
+        }
+    }
+    for (uint32_t v = 0; v < 2 * n; v++) { int w = succ[v]; if (w >= 0 && succ[w ^ 1] != (int)(v ^ 1)) succ[v] = -1; }
+    for (uint32_t v = 0; v < 2 * n; v++) if (succ[v] >= 0) pred[succ[v]] = (int)v;
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t v = 0; v < 2 * n; v++) {
+            const uint32_t r = v >> 1;
+            if (contained[r] || used[r]) continue;
+            if (pass == 0 && pred[v] >= 0) continue;
+            int cnt = 0;
+            for (int w = (int)v; w >= 0 && !used[w >> 1]; w = succ[w]) { cnt++; if (cnt > (int)n) break; }
+            if (cnt < min_reads) continue;
+            std::vector<Piece> c;
+            for (int w = (int)v; w >= 0 && !used[w >> 1]; w = succ[w]) {
+                used[w >> 1] = 1;
+                const bool more = succ[w] >= 0 && !used[succ[w] >> 1];
+                c.push_back(Piece{(uint32_t)(w >> 1), (uint32_t)(w & 1), (uint32_t)(more ? len[w >> 1] - sovl[w] : len[w >> 1])});
+            }
+            contigs.push_back(std::move(c));
+        }
+    if (contigs.empty()) {
+        int best = -1;
+        for (uint32_t i = 0; i < n; i++) if (!contained[i] && (best < 0 || len[i] > len[best])) best = (int)i;
+        if (best >= 0) { contigs.push_back({Piece{(uint32_t)best, 0u, (uint32_t)len[best]}}); fallback = true; }
+    }
+}
+
+} // namespace
+
+extern "C" void fsv_asm_default_params(fsv_asm_params *p)
+{
+    if (!p) return;
+    p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
+    p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 2;
+}
+
+extern "C" int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap)
+{
+    if (!sets || !sets->read_len) return FSV_EINVAL;
+    uint64_t tot = 0;
+    for (uint32_t r = 0; r < sets->n_reads; r++) tot += (uint64_t)sets->read_len[r];
+    // a contig is a concatenation of prefixes of distinct (corrected) reads; consensus can lengthen a read slightly
+    if (seq_cap) *seq_cap = tot + tot / 8 + 1024 * (uint64_t)sets->n_sets + 4096;
+    if (contig_cap) *contig_cap = sets->n_reads + sets->n_sets + 1;
+    return FSV_OK;
+}
+
+extern "C" int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out)
+{
+    if (!ctx || !out || !ctx->asm_ws) return FSV_EINVAL;
+    *out = ((const AsmWs *)ctx->asm_ws)->stats;
+    return FSV_OK;
+}
+
+extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params *params, fsv_contigs *out)
+{
+    if (!ctx || !sets || !out || !sets->store_dev || !sets->word_off || !sets->read_len || !sets->set_start) return FSV_EINVAL;
+    if (!out->seq || !out->off || !out->set || !out->n_reads || !out->set_status) return FSV_EINVAL;
+    fsv_asm_params P;
+    if (params) P = *params; else fsv_asm_default_params(&P);
+    if (P.k < 1 || P.k > 63 || P.w < 1 || P.w > 64 || P.lookback != 64 || P.n_rounds < 0 || P.n_rounds > 16 || P.min_anchors < 1)
+        return fsv_fail(ctx, FSV_EINVAL, "fsv_asm_params out of range (k<=63, w<=64, lookback==64)");
+    FSV_HIP(ctx, hipSetDevice(ctx->device));
+    AsmWs &W = *ws_get(ctx);
+    memset(&W.stats, 0, sizeof(W.stats));
+    Timer ttotal(ctx);
+
+    Batch B;
+    B.n_reads = sets->n_reads; B.n_sets = sets->n_sets;
+    out->n_contigs = 0;
+    out->off[0] = 0;
+    for (uint32_t s = 0; s < B.n_sets; s++) out->set_status[s] = 0;
+    if (B.n_reads == 0 || B.n_sets == 0) return FSV_OK;
+    B.set_start.assign(sets->set_start, sets->set_start + B.n_sets + 1);
+    if (B.set_start[0] != 0 || B.set_start[B.n_sets] != B.n_reads) return fsv_fail(ctx, FSV_EINVAL, "set_start must span [0, n_reads]");
+    B.read_set.resize(B.n_reads); B.pair_base.resize(B.n_sets + 1);
+    uint64_t np = 0;
+    for (uint32_t s = 0; s < B.n_sets; s++) {
+        if (B.set_start[s + 1] < B.set_start[s]) return fsv_fail(ctx, FSV_EINVAL, "set_start not monotone");
+        uint64_t ns = B.set_start[s + 1] - B.set_start[s];
+        B.pair_base[s] = (uint32_t)np;
+        np += ns > 1 ? ns * (ns - 1) : 0;
+        for (uint32_t r = B.set_start[s]; r < B.set_start[s + 1]; r++) B.read_set[r] = s;
+    }
+    if (np >= (1ull << 31)) return fsv_fail(ctx, FSV_EUNSUP, "too many read pairs in one batch; split it");
+    B.pair_base[B.n_sets] = (uint32_t)np; B.n_pairs = (uint32_t)np;
+    std::vector<int32_t> len(sets->read_len, sets->read_len + B.n_reads);
+    for (uint32_t r = 0; r < B.n_reads; r++) if (len[r] < 1 || len[r] >= (1 << 24)) return fsv_fail(ctx, FSV_EUNSUP, "read length must be in [1, 2^24)");
+
+    std::vector<uint8_t> thr(FSV_WINDOW + 1);
+    for (int i = 0; i <= FSV_WINDOW; i++) thr[i] = thr_for_len_host(i);
+    TRY(upload(ctx, W.thr_tab, thr));
+    TRY(upload(ctx, W.set_start, B.set_start));
+    TRY(upload(ctx, W.read_set, B.read_set));
+    TRY(upload(ctx, W.pair_base, B.pair_base));
+    TRY(ensure(ctx, W.warn, (size_t)B.n_reads * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+
+    Geometry G;
+    TRY(make_geometry(ctx, B, len, G));
+    // round 0 reads the caller's store through the caller's word offsets
+    std::vector<uint32_t> woff0(B.n_reads + 1);
+    for (uint32_t r = 0; r <= B.n_reads; r++) {
+        if (sets->word_off[r] >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "store larger than 2^32 words; split the batch");
+        woff0[r] = (uint32_t)sets->word_off[r];
+    }
+    G.word_off = woff0;
+    const uint32_t *store = sets->store_dev;
+    uint64_t reads_in_bytes = 0;
+    for (uint32_t r = 0; r < B.n_reads; r++) reads_in_bytes += (uint64_t)(len[r] + 3) / 4;
+
+    for (int round = 0; round < P.n_rounds; round++) {
+        TRY(upload(ctx, W.word_off, G.word_off));
+        TRY(upload(ctx, W.len, len));
+        TRY(upload(ctx, W.mz_off, G.mz_off));
+        TRY(upload(ctx, W.gwin_off, G.gwin_off));
+        if (G.task_bound >= (1ull << 31)) return fsv_fail(ctx, FSV_EUNSUP, "window task bound exceeds 2^31; split the batch");
+        const uint32_t task_cap = (uint32_t)std::max<uint64_t>(G.task_bound, 1);
+        TRY(ensure(ctx, W.tasks, (size_t)task_cap * sizeof(fsv_wtask)));
+        TRY(ensure(ctx, W.res, (size_t)task_cap * sizeof(fsv_wres)));
+        TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_ec, true, task_cap));
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        FSV_HIP(ctx, hipMemcpyAsync(cnt, W.counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (cnt[1]) return fsv_fail(ctx, FSV_ECAP, "internal window task buffer overflow");
+        const uint32_t n_tasks = cnt[0];
+        W.stats.n_pairs += B.n_pairs;
+        W.stats.n_windows += n_tasks;
+        if (n_tasks) {
+            Timer tv(ctx);
+            TRY(fsv_bpm_windows_dev(ctx, store, (const fsv_wtask *)W.tasks.p, n_tasks, (fsv_wres *)W.res.p));
+            hipLaunchKernelGGL(k_rescue_accept, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
+                               B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)((uint32_t *)W.counters.p + 4));
+            FSV_HIP(ctx, hipGetLastError());
+            W.stats.ms_verify += tv.stop();
+            Timer tp(ctx);
+            TRY(ensure(ctx, W.paths, (size_t)n_tasks * sizeof(fsv_wpath)));
+            TRY(ensure(ctx, W.dp_list, (size_t)n_tasks * 4));
+            hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
+                               (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, n_tasks, (fsv_wpath *)W.paths.p,
+                               (uint32_t *)W.dp_list.p, (uint32_t *)W.counters.p + 2);
+            FSV_HIP(ctx, hipGetLastError());
+            FSV_HIP(ctx, hipMemcpyAsync(cnt, W.counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const uint32_t n_dp = cnt[2];
+            W.stats.n_path_dp += n_dp;
+            if (n_dp) {
+                // the DP list order depends on atomics; sort it so that scratch slots (and nothing else) are reproducible
+                const uint32_t chunk = std::min<uint32_t>(n_dp, 1u << 18);
+                const uint32_t stride = (chunk + 63) / 64 * 64;
+                TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * 8));
+                TRY(ensure(ctx, W.tmp, (size_t)stride * (FSV_PATH_CAP + 64)));
+                for (uint32_t b = 0; b < n_dp; b += chunk) {
+                    const uint32_t e = std::min(n_dp, b + chunk);
+                    hipLaunchKernelGGL(k_path_dp, dim3(fsv_grid_for(e - b, 64)), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                                       (const uint32_t *)W.dp_list.p, b, e, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p, (uint8_t *)W.tmp.p, stride);
+                    FSV_HIP(ctx, hipGetLastError());
+                }
+            }
+            W.stats.ms_path += tp.stop();
+        }
+        // consensus -> corrected windows -> new read store
+        Timer tcs(ctx);
+        const uint32_t n_gwin = G.gwin_off[B.n_reads];
+        TRY(ensure(ctx, W.cwin, (size_t)n_gwin * FSV_CW_STRIDE));
+        TRY(ensure(ctx, W.cwin_len, (size_t)n_gwin * 2));
+        TRY(ensure(ctx, W.new_len, (size_t)B.n_reads * 4));
+        if (!n_tasks) { TRY(ensure(ctx, W.paths, sizeof(fsv_wpath))); }
+        ConsArgs C;
+        C.store = store; C.word_off = (const uint32_t *)W.word_off.p; C.read_len = (const int32_t *)W.len.p;
+        C.read_set = (const uint32_t *)W.read_set.p; C.set_start = (const uint32_t *)W.set_start.p; C.pair_base = (const uint32_t *)W.pair_base.p;
+        C.gwin_off = (const uint32_t *)W.gwin_off.p; C.ovl = (const fsv_ovl *)W.ovl.p; C.tasks = (const fsv_wtask *)W.tasks.p;
+        C.paths = (const fsv_wpath *)W.paths.p; C.cwin = (uint8_t *)W.cwin.p; C.cwin_len = (uint16_t *)W.cwin_len.p; C.warn = (uint32_t *)W.warn.p;
+        C.n_reads = B.n_reads;
+        hipLaunchKernelGGL(k_consensus, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
+        FSV_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
+                           (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p);
+        FSV_HIP(ctx, hipGetLastError());
+        std::vector<int32_t> nlen(B.n_reads);
+        FSV_HIP(ctx, hipMemcpyAsync(nlen.data(), W.new_len.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        Geometry G2;
+        TRY(make_geometry(ctx, B, nlen, G2));
+        DevBuf &dst = W.store[round & 1];
+        const uint32_t total_words = G2.word_off[B.n_reads];
+        TRY(ensure(ctx, dst, ((size_t)total_words + 8) * 4));
+        // k_repack needs the new offsets/lengths while the old ones are still in use by nothing else: stage them in mz_cnt/new_len
+        TRY(upload(ctx, W.unpack_off, G2.word_off));
+        hipLaunchKernelGGL(k_repack, dim3(fsv_grid_for(total_words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
+                           (const uint16_t *)W.cwin_len.p, (const uint8_t *)W.cwin.p, (const uint32_t *)W.unpack_off.p,
+                           (const int32_t *)W.new_len.p, B.n_reads, total_words, round + 1 < P.n_rounds ? 1 : 0, (uint32_t *)dst.p);
+        FSV_HIP(ctx, hipGetLastError());
+        FSV_HIP(ctx, hipMemsetAsync((uint8_t *)dst.p + (size_t)total_words * 4, 0, 32, ctx->stream));
+        W.stats.ms_consensus += tcs.stop();
+        store = (const uint32_t *)dst.p;
+        len = nlen;
+        G = G2;
+    }
+
+    // final overlaps on the corrected reads
+    Timer tf(ctx);
+    TRY(upload(ctx, W.word_off, G.word_off));
+    TRY(upload(ctx, W.len, len));
+    TRY(upload(ctx, W.mz_off, G.mz_off));
+    TRY(ensure(ctx, W.tasks, 64));
+    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0));
+    std::vector<fsv_ovl> hovl(B.n_pairs);
+    if (B.n_pairs) {
+        hipLaunchKernelGGL(k_exact, dim3(B.n_pairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
+                           (const uint32_t *)W.set_start.p, (const uint32_t *)W.pair_base.p, B.n_sets, (fsv_ovl *)W.ovl.p);
+        FSV_HIP(ctx, hipGetLastError());
+        FSV_HIP(ctx, hipMemcpyAsync(hovl.data(), W.ovl.p, (size_t)B.n_pairs * sizeof(fsv_ovl), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    std::vector<uint32_t> hwarn(B.n_reads);
+    FSV_HIP(ctx, hipMemcpyAsync(hwarn.data(), W.warn.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    // layout per set (host), then stitch on the device
+    std::vector<fsv_piece> pieces;
+    uint64_t used = 0;
+    uint32_t nc = 0;
+    int rc_out = FSV_OK;
+    for (uint32_t s = 0; s < B.n_sets && rc_out == FSV_OK; s++) {
+        const uint32_t r0 = B.set_start[s], ns = B.set_start[s + 1] - r0;
+        int32_t st = 0;
+        for (uint32_t r = r0; r < r0 + ns; r++) st |= (int32_t)(hwarn[r] & 3u);
+        if (ns == 0) { out->set_status[s] = st; continue; }
+        std::vector<std::vector<Piece>> contigs;
+        bool fallback = false;
+        const uint32_t npairs_s = B.pair_base[s + 1] - B.pair_base[s];
+        for (uint32_t i = 0; i < npairs_s; i++) W.stats.n_exact_overlaps += (hovl[B.pair_base[s] + i].valid && hovl[B.pair_base[s] + i].exact);
+        layout_set(len.data() + r0, ns, npairs_s ? hovl.data() + B.pair_base[s] : nullptr, npairs_s, P.min_contig_reads, contigs, fallback);
+        if (fallback) st |= FSV_W_NO_LAYOUT;
+        for (auto &c : contigs) {
+            uint64_t clen = 0;
+            for (auto &pc : c) clen += pc.len;
+            if (nc >= out->contig_cap || used + clen > out->seq_cap) { rc_out = fsv_fail(ctx, FSV_ECAP, "contig output buffers too small (use fsv_assemble_batch_bound)"); break; }
+            for (auto &pc : c) { pieces.push_back(fsv_piece{r0 + pc.read, pc.rev, pc.len, 0u, used}); used += pc.len; }
+            out->set[nc] = s; out->n_reads[nc] = (uint32_t)c.size();
+            out->off[++nc] = used;
+        }
+        out->set_status[s] = st;
+    }
+    if (rc_out != FSV_OK) return rc_out;
+    out->n_contigs = nc;
+    if (!pieces.empty()) {
+        TRY(upload(ctx, W.pieces, pieces));
+        TRY(ensure(ctx, W.contig_out, used + 16));
+        hipLaunchKernelGGL(k_stitch, dim3((uint32_t)pieces.size()), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const fsv_piece *)W.pieces.p, (char *)W.contig_out.p);
+        FSV_HIP(ctx, hipGetLastError());
+        FSV_HIP(ctx, hipMemcpyAsync(out->seq, W.contig_out.p, used, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    W.stats.ms_final += tf.stop();
+    W.h_word_off = G.word_off; W.h_len = len; W.cur_store = store; W.n_reads = B.n_reads;
+    // algorithmic bytes: 2-bit operands + result of every DP task, reads in once per pass, contigs out
+    W.stats.algo_bytes = W.stats.n_windows * 212ull + reads_in_bytes * (uint64_t)(P.n_rounds + 1) + used;
+    W.stats.ms_total = ttotal.stop();
+    return FSV_OK;
+}
+
+extern "C" int fsv_asm_fetch_reads(fsv_ctx *ctx, char *seq, uint64_t seq_cap, uint64_t *off, uint32_t n_reads)
+{
+    if (!ctx || !ctx->asm_ws || !seq || !off) return FSV_EINVAL;
+    AsmWs &W = *(AsmWs *)ctx->asm_ws;
+    if (n_reads != W.n_reads || !W.cur_store) return fsv_fail(ctx, FSV_EINVAL, "no assembled batch with that many reads on this context");
+    FSV_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> o(n_reads + 1, 0);
+    for (uint32_t r = 0; r < n_reads; r++) o[r + 1] = o[r] + (uint64_t)W.h_len[r];
+    if (o[n_reads] > seq_cap) return FSV_ECAP;
+    DevBuf d_off, d_out;
+    int rc = upload(ctx, d_off, o);
+    if (rc == FSV_OK) rc = ensure(ctx, d_out, o[n_reads] + 16);
+    if (rc == FSV_OK) {
+        hipLaunchKernelGGL(k_unpack_reads, dim3(n_reads), dim3(256), 0, ctx->stream, W.cur_store, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const uint64_t *)d_off.p, (char *)d_out.p);
+        if (hipGetLastError() != hipSuccess) rc = FSV_EHIP;
+    }
+    if (rc == FSV_OK) rc = fsv_d2h(ctx, seq, d_out.p, o[n_reads]);
+    if (d_off.p) (void)hipFree(d_off.p);
+    if (d_out.p) (void)hipFree(d_out.p);
+    memcpy(off, o.data(), (n_reads + 1) * sizeof(uint64_t));
+    return rc;
+}

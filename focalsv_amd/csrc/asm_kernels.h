@@ -1,0 +1,832 @@
+// asm_kernels.h -- device kernels of the per-read-set assembly (gfx950).  Included once by asm.hip.
+//
+// Stage map (reference = hifiasm-0.14 under software/, restated in oracle/asm.c which these kernels
+// must match bit for bit):
+//   k_sketch          ha_sketch                                  sketch.cpp:39-137
+//   k_uniq            per-read index (hash occurs once)          htab.cpp:917-998 restated
+//   k_chain           anchors, chain_DP, extension, window list  anchor.cpp:60-178; Hash_Table.cpp:425-616, 83-243; Correct.cpp:306-531
+//   k5 (bpm_device.h) Reserve_Banded_BPM                         Levenshtein_distance.h:274-461
+//   k_rescue_accept   recalcate_window_advance (right pass), 0.9 / 0.03 filters   Correct.cpp:2629-3023, 725
+//   k_path_fast/_dp   try_cigar, Reserve_Banded_BPM_PATH, generate_cigar          Levenshtein_distance.h:465-888; Correct.cpp:1302-1536
+//   k_consensus       window_consensus / get_seq_from_Graph as a column vote       Correct.cpp:4010-4195
+//   k_newlen/k_repack worker_ec_save (+ reverse complement)      Assembly.cpp:706-767
+//   k_exact           if_exact_match                             Assembly.cpp:894-974
+//   k_stitch          ma_ug_seq                                  Overlaps.cpp:8969-9034
+#pragma once
+#include "bpm_device.h"
+
+#define FSV_AMAX       1024  // anchors per read pair held in LDS
+#define FSV_UQ_MAX     4096  // minimizers per read sorted in LDS
+#define FSV_PATH_CAP    448  // ops per window path (x_len + k + slack)
+#define FSV_CW_STRIDE   448  // bytes reserved per corrected grid window
+#define FSV_INS_MAXLEN   12
+#define FSV_EV_CAP     2048  // insertion events per grid window
+
+struct fsv_wpath {           // 128 bytes per window task
+    int32_t ry_start, ry_end;   // absolute strand coordinates of the aligned y interval
+    int16_t path_len, err;
+    uint8_t state;              // 0 none, 1 path present, 2 queued for DP
+    uint8_t pad[3];
+    uint8_t ops[112];           // 2-bit ops start-to-end: 0 match 1 mismatch 2 y-only 3 x-only
+};
+static_assert(sizeof(fsv_wpath) == 128, "fsv_wpath layout");
+
+struct AsmDims {
+    uint32_t n_reads, n_sets, n_pairs;
+};
+
+// ------------------------------------------------------------------------------------------------ k_sketch
+__device__ __forceinline__ uint64_t mix64(uint64_t key)
+{
+    key = ~key + (key << 21);
+    key = key ^ key >> 24;
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ key >> 14;
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ key >> 28;
+    key = key + (key << 31);
+    return key;
+}
+
+// One thread walks one read (the minimizer recurrence is sequential); the w-slot ring and the k-slot
+// run-length queue live in LDS, transposed ([slot][lane]) so that lanes never share a bank.
+__global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                               const int32_t *__restrict__ read_len, const uint32_t *__restrict__ mz_off,
+                                               fsv_mz *__restrict__ mz, uint32_t *__restrict__ mz_cnt, uint32_t n_reads, int w, int k,
+                                               int hpc, uint32_t *__restrict__ warn)
+{
+    __shared__ uint64_t r_hash[64][64];
+    __shared__ uint32_t r_meta[64][64]; // pos << 1 | rev
+    __shared__ uint16_t r_span[64][64];
+    __shared__ uint16_t q_run[64][64];
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x * 64 + lane;
+    if (r >= n_reads) return;
+    const uint32_t woff = word_off[r];
+    const int len = read_len[r];
+    const uint32_t cap = mz_off[r + 1] - mz_off[r];
+    fsv_mz *out = mz + mz_off[r];
+    const uint64_t NONE = ~0ull;
+    const uint64_t mask = (1ull << k) - 1;
+    uint64_t km0 = 0, km1 = 0, km2 = 0, km3 = 0;
+    uint64_t best_h = NONE; uint32_t best_meta = 0; uint16_t best_span = 0;
+    int run_head = 0, run_cnt = 0, l = 0, slot = 0, best_slot = 0, span = 0;
+    uint32_t n = 0;
+    for (int j = 0; j < w; j++) { r_hash[j][lane] = NONE; r_meta[j][lane] = 0; r_span[j][lane] = 0; }
+
+#define EMIT(H, M, S)                                                                                      \
+    do {                                                                                                   \
+        if (n < cap) { fsv_mz m_; m_.hash = (H); m_.pos = (M) >> 1; m_.rev = (uint8_t)((M) & 1u); m_.span = (uint8_t)(S); m_.pad = 0; out[n] = m_; } \
+        n++;                                                                                               \
+    } while (0)
+
+    for (int i = 0; i < len; i++) {
+        const uint32_t c = fsv_base_fwd(store, woff, i);
+        uint64_t cur_h = NONE; uint32_t cur_meta = 0; uint16_t cur_span = 0;
+        {
+            if (hpc) {
+                int run = 1;
+                while (i + run < len && fsv_base_fwd(store, woff, i + run) == c) run++;
+                i += run - 1;
+                q_run[(run_head + run_cnt++) & 63][lane] = (uint16_t)min(run, 65535);
+                span += run;
+                if (run_cnt > k) { span -= q_run[run_head][lane]; run_head = (run_head + 1) & 63; run_cnt--; }
+            } else {
+                span = l + 1 < k ? l + 1 : k;
+            }
+            km0 = (km0 << 1 | (uint64_t)(c & 1u)) & mask;
+            km1 = (km1 << 1 | (uint64_t)(c >> 1)) & mask;
+            km2 = km2 >> 1 | (uint64_t)(1u - (c & 1u)) << (k - 1);
+            km3 = km3 >> 1 | (uint64_t)(1u - (c >> 1)) << (k - 1);
+            if (km1 == km3) continue; // palindrome: ring and slot are not advanced (sketch.cpp:84)
+            const int z = km1 < km3 ? 0 : 1;
+            ++l;
+            if (l >= k && span < 256) {
+                cur_h = z ? mix64(km2) + mix64(km3) : mix64(km0) + mix64(km1);
+                cur_meta = ((uint32_t)i << 1) | (uint32_t)z;
+                cur_span = (uint16_t)span;
+            }
+        }
+        r_hash[slot][lane] = cur_h; r_meta[slot][lane] = cur_meta; r_span[slot][lane] = cur_span;
+        if (l == w + k - 1 && best_h != NONE) {
+            for (int j = slot + 1; j < w; j++) if (best_h == r_hash[j][lane] && r_meta[j][lane] != best_meta) EMIT(r_hash[j][lane], r_meta[j][lane], r_span[j][lane]);
+            for (int j = 0; j < slot; j++)     if (best_h == r_hash[j][lane] && r_meta[j][lane] != best_meta) EMIT(r_hash[j][lane], r_meta[j][lane], r_span[j][lane]);
+        }
+        if (cur_h <= best_h) {
+            if (l >= w + k && best_h != NONE) EMIT(best_h, best_meta, best_span);
+            best_h = cur_h; best_meta = cur_meta; best_span = cur_span; best_slot = slot;
+        } else if (slot == best_slot) {
+            if (l >= w + k - 1 && best_h != NONE) EMIT(best_h, best_meta, best_span);
+            best_h = NONE;
+            for (int j = slot + 1; j < w; j++) if (best_h >= r_hash[j][lane]) { best_h = r_hash[j][lane]; best_meta = r_meta[j][lane]; best_span = r_span[j][lane]; best_slot = j; }
+            for (int j = 0; j <= slot; j++)    if (best_h >= r_hash[j][lane]) { best_h = r_hash[j][lane]; best_meta = r_meta[j][lane]; best_span = r_span[j][lane]; best_slot = j; }
+            if (l >= w + k - 1 && best_h != NONE) {
+                for (int j = slot + 1; j < w; j++) if (best_h == r_hash[j][lane] && best_meta != r_meta[j][lane]) EMIT(r_hash[j][lane], r_meta[j][lane], r_span[j][lane]);
+                for (int j = 0; j <= slot; j++)    if (best_h == r_hash[j][lane] && best_meta != r_meta[j][lane]) EMIT(r_hash[j][lane], r_meta[j][lane], r_span[j][lane]);
+            }
+        }
+        if (++slot == w) slot = 0;
+    }
+    if (best_h != NONE) EMIT(best_h, best_meta, best_span);
+#undef EMIT
+    if (n > cap) { atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = cap; }
+    mz_cnt[r] = n;
+}
+
+// ------------------------------------------------------------------------------------------------ k_uniq
+// One workgroup per read: bitonic sort of (hash, pos) in LDS, keep hashes that occur exactly once.
+__global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
+                                              uint32_t *__restrict__ warn)
+{
+    __shared__ uint64_t s_hash[FSV_UQ_MAX];
+    __shared__ uint64_t s_pay[FSV_UQ_MAX]; // pos | rev << 32 | span << 40
+    __shared__ uint32_t s_scan[256];
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    fsv_mz *a = mz + mz_off[r];
+    uint32_t n = mz_cnt[r];
+    if (n > FSV_UQ_MAX) { if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = FSV_UQ_MAX; }
+    uint32_t np = 1;
+    while (np < n) np <<= 1;
+    for (uint32_t i = tid; i < np; i += 256) {
+        if (i < n) { fsv_mz m = a[i]; s_hash[i] = m.hash; s_pay[i] = (uint64_t)m.pos | (uint64_t)m.rev << 32 | (uint64_t)m.span << 40; }
+        else { s_hash[i] = ~0ull; s_pay[i] = ~0ull; }
+    }
+    __syncthreads();
+    for (uint32_t sz = 2; sz <= np; sz <<= 1)
+        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+            for (uint32_t i = tid; i < np; i += 256) {
+                uint32_t j = i ^ st;
+                if (j > i) {
+                    bool up = (i & sz) == 0;
+                    uint64_t hi = s_hash[i], hj = s_hash[j], pi = s_pay[i], pj = s_pay[j];
+                    bool gt = hi > hj || (hi == hj && (uint32_t)pi > (uint32_t)pj);
+                    if (gt == up) { s_hash[i] = hj; s_hash[j] = hi; s_pay[i] = pj; s_pay[j] = pi; }
+                }
+            }
+            __syncthreads();
+        }
+    // unique flags + block compaction (each thread owns a contiguous chunk)
+    const uint32_t per = (n + 255) / 256;
+    const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+    uint32_t cnt = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        bool u = (i == 0 || s_hash[i - 1] != s_hash[i]) && (i + 1 >= n || s_hash[i + 1] != s_hash[i]);
+        cnt += u;
+    }
+    s_scan[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) { uint32_t acc = 0; for (int i = 0; i < 256; i++) { uint32_t c = s_scan[i]; s_scan[i] = acc; acc += c; } mz_cnt[r] = acc; }
+    __syncthreads();
+    uint32_t o = s_scan[tid];
+    for (uint32_t i = lo; i < hi; i++) {
+        bool u = (i == 0 || s_hash[i - 1] != s_hash[i]) && (i + 1 >= n || s_hash[i + 1] != s_hash[i]);
+        if (u) { fsv_mz m; m.hash = s_hash[i]; uint64_t p = s_pay[i]; m.pos = (uint32_t)p; m.rev = (uint8_t)(p >> 32); m.span = (uint8_t)(p >> 40); m.pad = 0; a[o++] = m; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_chain
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ long long wave_max_i64(long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) { long long o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
+__device__ __forceinline__ int thr_for_len(int x_len, const uint8_t *__restrict__ thr_tab) { return thr_tab[x_len]; }
+
+struct ChainArgs {
+    const uint32_t *store;
+    const uint32_t *word_off;
+    const int32_t *read_len;
+    const uint32_t *set_start;   // n_sets + 1
+    const uint32_t *pair_base;   // n_sets + 1
+    const fsv_mz *mz;
+    const uint32_t *mz_off;
+    const uint32_t *mz_cnt;
+    fsv_ovl *ovl;                // one slot per ordered pair
+    fsv_wtask *tasks;
+    uint32_t *task_counter;
+    uint32_t task_cap;
+    uint32_t *overflow;          // set to 1 when the task array is full
+    uint32_t *warn;              // per read
+    const uint8_t *thr_tab;      // 376 entries: threshold for a window of that length
+    uint32_t n_sets;
+    int32_t k_score, min_anchors, min_ovlp, bw, emit_tasks;
+};
+
+// One wavefront per ordered read pair (q, t) of a set.
+__global__ __launch_bounds__(64) void k_chain(ChainArgs A)
+{
+    __shared__ uint64_t s_key[FSV_AMAX];  // qe << 32 | te   (raw te first, strand-corrected later)
+    __shared__ uint16_t s_aux[FSV_AMAX];  // t span | strand << 8 ; later: predecessor index
+    __shared__ int32_t s_f[FSV_AMAX], s_ind[FSV_AMAX], s_sl[FSV_AMAX];
+    __shared__ uint16_t s_chain[FSV_AMAX];
+    const int lane = threadIdx.x;
+    const uint32_t p = blockIdx.x;
+    // locate the set: largest s with pair_base[s] <= p
+    uint32_t lo = 0, hi = A.n_sets;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (A.pair_base[mid] <= p) lo = mid; else hi = mid; }
+    const uint32_t s = lo, r0 = A.set_start[s], ns = A.set_start[s + 1] - r0;
+    const uint32_t idx = p - A.pair_base[s];
+    const uint32_t q = idx / (ns - 1);
+    uint32_t t = idx % (ns - 1);
+    t += (t >= q);
+    const uint32_t rq = r0 + q, rt = r0 + t;
+    const int lenq = A.read_len[rq], lent = A.read_len[rt];
+    const fsv_mz *mq = A.mz + A.mz_off[rq], *mt = A.mz + A.mz_off[rt];
+    const int nq = (int)A.mz_cnt[rq], nt = (int)A.mz_cnt[rt];
+    fsv_ovl o;
+    o.q = q; o.t = t; o.x_s = o.x_e = o.y_s = o.y_e = 0; o.score = 0; o.n_chain = 0; o.chain_off = 0; o.first_win = 0; o.n_win = 0;
+    o.align_len = 0; o.err_sum = 0; o.rev = 0; o.is_match = 0; o.exact = 0; o.valid = 0;
+
+    // 1. anchors: binary-search every q minimizer in t's sorted unique list
+    int n = 0, nrev = 0, nfwd = 0;
+    for (int base = 0; base < nq; base += 64) {
+        int i = base + lane;
+        bool hit = false; uint64_t key = 0; uint16_t aux = 0;
+        if (i < nq) {
+            fsv_mz a = mq[i];
+            int l2 = 0, h2 = nt;
+            while (l2 < h2) { int mid = (l2 + h2) >> 1; if (mt[mid].hash < a.hash) l2 = mid + 1; else h2 = mid; }
+            if (l2 < nt) {
+                fsv_mz b = mt[l2];
+                if (b.hash == a.hash) { hit = true; key = (uint64_t)a.pos << 32 | b.pos; aux = (uint16_t)(b.span | ((a.rev ^ b.rev) << 8)); }
+            }
+        }
+        uint64_t m = __ballot(hit);
+        int at = n + __popcll(m & ((1ull << lane) - 1));
+        if (hit && at < FSV_AMAX) { s_key[at] = key; s_aux[at] = aux; }
+        nrev += __popcll(__ballot(hit && (aux >> 8)));
+        nfwd += __popcll(__ballot(hit && !(aux >> 8)));
+        n += __popcll(m);
+    }
+    if (n > FSV_AMAX) { if (lane == 0) atomicOr(&A.warn[rq], (uint32_t)FSV_W_ANCHOR_TRUNC); n = FSV_AMAX; }
+    __syncthreads();
+    // 2. majority strand, strand-corrected te, compaction
+    const int rev = nrev > nfwd;
+    int m2 = 0;
+    for (int base = 0; base < n; base += 64) {
+        int i = base + lane;
+        bool keep = false; uint64_t key = 0;
+        if (i < n) {
+            uint16_t aux = s_aux[i];
+            key = s_key[i];
+            if ((aux >> 8) == rev) {
+                keep = true;
+                if (rev) { int te = (int)(uint32_t)key, span = aux & 0xff; te = (lent - 1) - (te - span + 1); key = (key & 0xffffffff00000000ull) | (uint32_t)te; }
+            }
+        }
+        uint64_t m = __ballot(keep);
+        int at = m2 + __popcll(m & ((1ull << lane) - 1));
+        __syncthreads();
+        if (keep) s_key[at] = key;
+        m2 += __popcll(m);
+        __syncthreads();
+    }
+    n = m2;
+    if (n < A.min_anchors) { if (lane == 0) A.ovl[p] = o; return; }
+    // 3. sort by (qe, te)
+    int np = 1;
+    while (np < n) np <<= 1;
+    for (int i = n + lane; i < np; i += 64) s_key[i] = ~0ull;
+    __syncthreads();
+    for (int sz = 2; sz <= np; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = lane; i < np; i += 64) {
+                int j = i ^ st;
+                if (j > i) {
+                    bool up = (i & sz) == 0;
+                    uint64_t a = s_key[i], b = s_key[j];
+                    if ((a > b) == up) { s_key[i] = b; s_key[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // 4. chain DP: lane l examines predecessor i-1-l (nearest first on ties)
+    for (int i = 0; i < n; i++) {
+        const uint64_t ki = s_key[i];
+        const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
+        const int j = i - 1 - lane;
+        int cand = -1, ti = 0, tl = 0;
+        if (j >= 0) {
+            const uint64_t kj = s_key[j];
+            const int dq = qe - (int)(kj >> 32), dt = te - (int)(uint32_t)kj;
+            if (dq > 0 && dt > 0) {
+                const int gap = dq > dt ? dq - dt : dt - dq;
+                ti = s_ind[j] + gap; tl = s_sl[j] + dq;
+                if ((long long)ti * 1000 <= (long long)tl * A.bw) {
+                    int sc = min(min(dq, dt), A.k_score);
+                    if (ti) sc -= (int)(((long long)ti * sc * 1000) / ((long long)tl * A.bw));
+                    cand = sc + s_f[j];
+                }
+            }
+        }
+        // pack so that the max prefers the higher score, then the nearer predecessor
+        const int packed = cand < 0 ? -1 : cand * 64 + (63 - lane);
+        const int bestp = wave_max_i32(packed);
+        const int bests = bestp < 0 ? -1 : bestp >> 6;
+        if (bests > A.k_score) {
+            if (packed == bestp) { s_f[i] = bests; s_aux[i] = (uint16_t)j; s_ind[i] = ti; s_sl[i] = tl; }
+        } else if (lane == 0) { s_f[i] = A.k_score; s_aux[i] = 0xffff; s_ind[i] = 0; s_sl[i] = 0; }
+        __syncthreads();
+    }
+    // 5. best chain end: highest score, smallest index on ties
+    long long bk = -1;
+    for (int i = lane; i < n; i += 64) { long long v = (long long)s_f[i] * 4096 + (4095 - i); bk = v > bk ? v : bk; }
+    bk = wave_max_i64(bk);
+    const int best = 4095 - (int)(bk & 4095);
+    // 6. walk back (lane 0), chain stored end-to-start in s_chain
+    int cnt = 0;
+    if (lane == 0) { int c = best; while (c != 0xffff) { s_chain[cnt++] = (uint16_t)c; c = s_aux[c]; } }
+    cnt = __shfl(cnt, 0, 64);
+    __syncthreads();
+    if (cnt < A.min_anchors) { if (lane == 0) A.ovl[p] = o; return; }
+    const int first = s_chain[cnt - 1];
+    int xs = (int)(s_key[first] >> 32), ys = (int)(uint32_t)s_key[first];
+    int xe = (int)(s_key[best] >> 32), ye = (int)(uint32_t)s_key[best];
+    { int m = min(xs, ys); xs -= m; ys -= m; int r = min(lenq - 1 - xe, lent - 1 - ye); xe += r; ye += r; }
+    if (xe - xs + 1 < A.min_ovlp) { if (lane == 0) A.ovl[p] = o; return; }
+    o.x_s = xs; o.x_e = xe; o.y_s = ys; o.y_e = ye; o.rev = (uint8_t)rev; o.score = s_f[best]; o.n_chain = cnt; o.valid = 1;
+    o.n_win = xe / FSV_WINDOW - xs / FSV_WINDOW + 1;
+    if (!A.emit_tasks) { o.n_win = 0; if (lane == 0) A.ovl[p] = o; return; }
+    // 7. window tasks
+    uint32_t first_win = 0;
+    if (lane == 0) first_win = atomicAdd(A.task_counter, (uint32_t)o.n_win);
+    first_win = __shfl(first_win, 0, 64);
+    if ((uint64_t)first_win + (uint32_t)o.n_win > A.task_cap) {
+        if (lane == 0) { atomicExch(A.overflow, 1u); o.valid = 0; o.n_win = 0; A.ovl[p] = o; }
+        return;
+    }
+    o.first_win = (int32_t)first_win;
+    const int w0 = xs / FSV_WINDOW;
+    const uint32_t xw = A.word_off[rq], yw = A.word_off[rt];
+    for (int j = lane; j < o.n_win; j += 64) {
+        const int gs = (w0 + j) * FSV_WINDOW, ge = gs + FSV_WINDOW - 1;
+        const int x_start = max(gs, xs);
+        const int x_len = min(ge, xe) - x_start + 1;
+        // diagonal of the last chain anchor with qe <= x_start (chain is stored end-to-start)
+        int lo2 = 0, hi2 = cnt; // in start-to-end order: element e = s_chain[cnt-1-e]
+        while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; int qe = (int)(s_key[s_chain[cnt - 1 - mid]] >> 32); if (qe <= x_start) lo2 = mid + 1; else hi2 = mid; }
+        const uint64_t ka = s_key[s_chain[cnt - 1 - (lo2 == 0 ? 0 : lo2 - 1)]];
+        const int diag = (int)(uint32_t)ka - (int)(ka >> 32);
+        fsv_wtask w;
+        w.x_word = xw; w.y_word = yw; w.x_start = x_start; w.y_start = x_start + diag; w.y_len = lent;
+        w.x_len = (uint16_t)x_len; w.k = A.thr_tab[x_len]; w.y_rev = (uint8_t)rev; w.ovl = p; w.win = (uint32_t)j;
+        A.tasks[first_win + j] = w;
+    }
+    if (lane == 0) A.ovl[p] = o;
+}
+
+// ------------------------------------------------------------------------------------------------ k_rescue_accept
+// One lane per overlap slot: right-extension rescue of unmatched windows (Correct.cpp:2655-2744),
+// then the 0.9 coverage filter and the 0.03 error-rate filter (Correct.cpp:2899-3021, 725).
+__device__ __forceinline__ int double_thr(int pre, int x_len)
+{
+    if (pre == 0 && x_len >= 4) pre = 1;
+    int t = pre * 2;
+    if (x_len >= 300 && t < FSV_K_MAX) t = FSV_K_MAX;
+    if (t > FSV_K_MAX) t = FSV_K_MAX;
+    return t;
+}
+
+__global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict__ store, fsv_ovl *__restrict__ ovl, uint32_t n_pairs,
+                                                      fsv_wtask *__restrict__ tasks, fsv_wres *__restrict__ res,
+                                                      unsigned long long *__restrict__ stat_cols)
+{
+    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n_pairs) return;
+    fsv_ovl o = ovl[p];
+    if (!o.valid) return;
+    fsv_wtask *T = tasks + o.first_win;
+    fsv_wres *R = res + o.first_win;
+    int align = 0;
+    unsigned long long cols = 0;
+    for (int j = 0; j < o.n_win; j++) if (R[j].err >= 0) align += T[j].x_len;
+    for (int j = o.n_win - 1; j >= 0; j--) {
+        if (R[j].err < 0) continue;
+        int next = R[j].y_beg + R[j].end_site - R[j].extra_begin + 1;
+        for (int k2 = j + 1; k2 < o.n_win && R[k2].err < 0; k2++) {
+            fsv_wtask u = T[k2];
+            if (next >= u.y_len) break;
+            u.k = (uint8_t)double_thr(u.k, u.x_len);
+            u.y_start = next;
+            fsv_wres r;
+            if (!bpm_window_geometry(u, r)) break;
+            if ((u.x_len + 2 * u.k - r.extra_begin - r.extra_end) + u.k < u.x_len) break;
+            bpm_run(store, u, r, BpmNoSink());
+            cols += u.x_len;
+            if (r.err < 0) break;
+            T[k2] = u; R[k2] = r;
+            align += u.x_len;
+            next = r.y_beg + r.end_site - r.extra_begin + 1;
+        }
+    }
+    long long tlen = 0, terr = 0;
+    for (int j = 0; j < o.n_win; j++) { tlen += T[j].x_len; terr += R[j].err >= 0 ? R[j].err : T[j].x_len; }
+    o.align_len = align; o.err_sum = (int32_t)terr;
+    o.is_match = ((long long)(o.x_e - o.x_s + 1) * 9 <= (long long)align * 10 && terr * 100 <= tlen * 3) ? 1 : 0;
+    ovl[p] = o;
+    if (cols) atomicAdd(stat_cols, cols);
+}
+
+// ------------------------------------------------------------------------------------------------ K6 paths
+__device__ __forceinline__ void ops_set(uint8_t *ops, int i, uint32_t v) { ops[i >> 2] = (uint8_t)((ops[i >> 2] & ~(3u << ((i & 3) << 1))) | (v << ((i & 3) << 1))); }
+__device__ __forceinline__ uint32_t ops_get(const uint8_t *ops, int i) { return (ops[i >> 2] >> ((i & 3) << 1)) & 3u; }
+
+// y base of the padded window column c for a task
+__device__ __forceinline__ uint32_t task_ybase(const uint32_t *__restrict__ store, const fsv_wtask &t, int c)
+{
+    return bpm_ywin_base(store, t, t.y_start - t.k, c);
+}
+
+// Fast paths of Reserve_Banded_BPM_PATH (Levenshtein_distance.h:516-531): err == 0, or a gap-free placement with
+// exactly err mismatches (try_cigar).  Everything else is queued for the DP kernel.
+__global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ store, const fsv_ovl *__restrict__ ovl,
+                                                   const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res, uint32_t n_tasks,
+                                                   fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list, uint32_t *__restrict__ dp_count)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n_tasks) return;
+    const fsv_wtask t = tasks[tid];
+    const fsv_wres r = res[tid];
+    fsv_wpath *P = paths + tid;
+    P->state = 0;
+    if (r.err < 0 || !ovl[t.ovl].is_match) return;
+    const int n = t.x_len;
+    const int start = r.end_site - n + 1;
+    bool ok = false;
+    int err = r.err;
+    if (r.err == 0) ok = true;
+    else if (start >= 0) {
+        int mm = 0;
+        for (int i = 0; i < n && mm <= r.err; i++) mm += (fsv_base_fwd(store, t.x_word, t.x_start + i) != task_ybase(store, t, start + i));
+        ok = (mm == r.err);
+    }
+    if (!ok) {
+        P->state = 2;
+        uint32_t at = atomicAdd(dp_count, 1u);
+        dp_list[at] = tid;
+        return;
+    }
+    // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops and
+    // moves the y interval inwards; there are no gaps to shift.
+    int s2 = start, e2 = r.end_site;
+    uint8_t ops[112];
+    for (int i = 0; i < 112; i++) ops[i] = 0;
+    if (err > 0) {
+        for (int i = 0; i < n; i++) {
+            uint32_t mmf = fsv_base_fwd(store, t.x_word, t.x_start + i) != task_ybase(store, t, start + i);
+            if (mmf) ops_set(ops, i, 1u);
+        }
+        // same order as the reference: the alignment end first, then its start
+        for (int i = n - 1; i >= 0 && ops_get(ops, i) == 1u; i--) { ops_set(ops, i, 3u); e2--; }
+        for (int i = 0; i < n && ops_get(ops, i) == 1u; i++) { ops_set(ops, i, 3u); s2++; }
+    }
+    P->ry_start = t.y_start - t.k + s2;
+    P->ry_end = t.y_start - t.k + e2;
+    P->path_len = (int16_t)n; P->err = (int16_t)err; P->state = 1;
+    for (int i = 0; i < 112; i++) P->ops[i] = ops[i];
+}
+
+// Full K6: forward pass keeping {D0, VP, VN} per column in a per-lane slice of an HBM scratch
+// ([column][word][lane], coalesced), the reference's walk back, generate_cigar's end trimming and greedy
+// gap left-shift, then the path is packed start-to-end.
+struct PathSink {
+    uint64_t *cols; uint32_t stride, lane;
+    __device__ __forceinline__ void operator()(int i, uint64_t d0, uint64_t vp, uint64_t vn) const
+    {
+        uint64_t *c = cols + (size_t)(i + 1) * 3 * stride + lane;
+        c[0] = d0; c[stride] = vp; c[2 * (size_t)stride] = vn;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
+                                                const uint32_t *__restrict__ dp_list, uint32_t list_begin, uint32_t list_end,
+                                                fsv_wpath *__restrict__ paths, uint64_t *__restrict__ cols, uint8_t *__restrict__ tmp,
+                                                uint32_t stride)
+{
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t li = list_begin + slot;
+    if (li >= list_end) return;
+    const uint32_t tid = dp_list[li];
+    const fsv_wtask t = tasks[tid];
+    fsv_wpath *P = paths + tid;
+    const int n = t.x_len, k = t.k, band = 2 * k + 1;
+    fsv_wres r;
+    PathSink sink{cols, stride, slot};
+    bpm_run(store, t, r, sink);
+    if (r.err < 0) { P->state = 0; return; } // cannot happen: K5 matched this window
+#define COL(c, w) cols[((size_t)(c) * 3 + (w)) * stride + slot]
+#define TMP(i) tmp[(size_t)(i) * stride + slot]
+    int end = r.end_site, err = r.err;
+    int cur = err, col = n, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
+    while (col > 0 && cur != 0) {
+        const uint64_t d0 = COL(col, 0), vp = COL(col, 1), vn = COL(col, 2);
+        const uint64_t vpi = col > 1 ? COL(col - 1, 1) : 0ull, vni = col > 1 ? COL(col - 1, 2) : 0ull;
+        const uint64_t hn = vpi & d0, hp = vni | ~(vpi | d0);
+        const int diag = cur - (int)((~(d0 >> row)) & 1ull);
+        const bool can_up = row != 0, can_left = row == 0 || row != band - 1;
+        int left = cur, up = cur;
+        if (can_left) left = cur - (int)((hp >> row) & 1ull) + (int)((hn >> row) & 1ull);
+        if (can_up) up = cur - (int)((vp >> (row - 1)) & 1ull) + (int)((vn >> (row - 1)) & 1ull);
+        int best = diag; dir = 0;
+        if (can_up && up < best) { best = up; dir = 2; }
+        if (can_left && left < best) { best = left; dir = 3; }
+        if (dir == 0) { if (diag != cur) dir = 1; col--; start--; }
+        else if (dir == 2) { row--; start--; }
+        else { col--; row++; }
+        TMP(plen) = (uint8_t)dir; plen++;
+        cur = best;
+    }
+    if (col > 0) { for (int i = 0; i < col; i++) TMP(plen + i) = 0; start -= col; plen += col; dir = 0; }
+    if (dir != 3) start++;
+    // generate_cigar: TMP is stored end-to-start
+    if (err > 0) {
+        int stop = -1;
+        for (int i = 0; i < plen && TMP(i) == 1; i++) { TMP(i) = 3; end--; stop = i; }
+        for (int i = plen - 1; i >= 0 && TMP(i) == 1; i--) { TMP(i) = 3; start++; }
+        int xi = 0, yi = 0;
+        for (int i = plen - 1; i > stop; i--) {
+            const uint8_t op = TMP(i);
+            if (op < 2) { xi++; yi++; continue; }
+            // shift this gap towards the alignment start while the bases it passes still pair up (move_gap_greedy)
+            int pi = i + 1, x2 = xi, y2 = yi;
+            if (op == 3) y2--; else x2--;
+            for (; pi < plen && x2 >= 0 && y2 >= 0; pi++, x2--, y2--) {
+                const uint8_t pv = TMP(pi);
+                const bool same = fsv_base_fwd(store, t.x_word, t.x_start + x2) == task_ybase(store, t, start + y2);
+                if (pv >= 2 || (pv == 0 && !same)) break;
+                if (pv == 1 && same) { TMP(pi - 1) = 0; err--; }
+                else TMP(pi - 1) = pv;
+                TMP(pi) = op;
+            }
+            if (op == 2) yi++; else xi++;
+        }
+    }
+    uint8_t ops[112];
+    for (int i = 0; i < 112; i++) ops[i] = 0;
+    const int pl = min(plen, FSV_PATH_CAP);
+    for (int i = 0; i < pl; i++) ops_set(ops, i, TMP(plen - 1 - i));
+    P->ry_start = t.y_start - t.k + start;
+    P->ry_end = t.y_start - t.k + end;
+    P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1;
+    for (int i = 0; i < 112; i++) P->ops[i] = ops[i];
+#undef COL
+#undef TMP
+}
+
+// ------------------------------------------------------------------------------------------------ k_consensus
+// One wavefront per (read, 375-bp grid window).  Lanes walk the window paths of the accepted overlaps
+// and vote into LDS histograms (per column: A C G T deleted arrived after-insertion); inserted strings are
+// kept as (column, key) events.  Then lanes take columns, decide, and the corrected window is written out.
+struct ConsArgs {
+    const uint32_t *store;
+    const uint32_t *word_off;
+    const int32_t *read_len;
+    const uint32_t *read_set;    // read -> set
+    const uint32_t *set_start;
+    const uint32_t *pair_base;
+    const uint32_t *gwin_off;    // n_reads + 1: first grid window of every read
+    const fsv_ovl *ovl;
+    const fsv_wtask *tasks;
+    const fsv_wpath *paths;
+    uint8_t *cwin;               // FSV_CW_STRIDE bytes per grid window (2-bit codes, one per byte)
+    uint16_t *cwin_len;
+    uint32_t *warn;
+    uint32_t n_reads;
+};
+
+__device__ __forceinline__ bool vote_wins(int cnt, int total, bool homo)
+{
+    if (cnt * 5 >= total * 3) return true;
+    return homo && cnt * 1000 >= total * 515;
+}
+
+__global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
+{
+    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][7];
+    __shared__ uint16_t s_evcol[FSV_EV_CAP];
+    __shared__ uint32_t s_evkey[FSV_EV_CAP];
+    __shared__ uint32_t s_evn, s_cover;
+    __shared__ uint8_t s_out[FSV_WINDOW][14]; // per column: [0] = n bytes, then bytes
+    __shared__ uint32_t s_scan[64];
+    const int lane = threadIdx.x;
+    const uint32_t gw = blockIdx.x;
+    if (gw >= n_gwin) return;
+    // read of this grid window: largest r with gwin_off[r] <= gw
+    uint32_t lo = 0, hi = A.n_reads;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (A.gwin_off[mid] <= gw) lo = mid; else hi = mid; }
+    const uint32_t r = lo;
+    const int g = (int)(gw - A.gwin_off[r]);
+    const int xlen = A.read_len[r];
+    const int gs = g * FSV_WINDOW, glen = min(FSV_WINDOW, xlen - gs);
+    const uint32_t xw = A.word_off[r];
+    const uint32_t s = A.read_set[r], r0 = A.set_start[s], ns = A.set_start[s + 1] - r0, q = r - r0;
+    const uint32_t pbase = A.pair_base[s] + q * (ns - 1);
+    for (int i = lane; i < (FSV_WINDOW + 1) * 7; i += 64) (&s_cnt[0][0])[i] = 0;
+    if (lane == 0) { s_evn = 0; s_cover = 0; }
+    __syncthreads();
+    for (uint32_t oi = lane; oi < ns - 1; oi += 64) {
+        const fsv_ovl o = A.ovl[pbase + oi];
+        if (!o.valid || !o.is_match) continue;
+        const int j = g - o.x_s / FSV_WINDOW;
+        if (j < 0 || j >= o.n_win) continue;
+        const uint32_t ti = (uint32_t)o.first_win + (uint32_t)j;
+        const fsv_wpath *P = A.paths + ti;
+        if (P->state != 1) continue;
+        const fsv_wtask t = A.tasks[ti];
+        atomicAdd(&s_cover, 1u);
+        int xp = t.x_start - gs, yp = P->ry_start;
+        bool pend = false;
+        if (j > 0 && A.paths[ti - 1].state == 1) {
+            const int gap = P->ry_start - A.paths[ti - 1].ry_end - 1;
+            if (gap > 0 && xp == 0) {
+                pend = true;
+                if (gap <= FSV_INS_MAXLEN) {
+                    uint32_t key = (uint32_t)gap << 24;
+                    for (int b = 0; b < gap; b++) key |= fsv_base_at(A.store, t.y_word, t.y_len, t.y_rev, P->ry_start - gap + b) << (2 * b);
+                    uint32_t e = atomicAdd(&s_evn, 1u);
+                    if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
+                }
+            }
+        }
+        const int plen = P->path_len;
+        for (int p = 0; p < plen;) {
+            const uint32_t op = ops_get(P->ops, p);
+            if (op == 2u) {
+                int L = 0;
+                while (p + L < plen && ops_get(P->ops, p + L) == 2u) L++;
+                if (xp < glen) {
+                    pend = true;
+                    if (L <= FSV_INS_MAXLEN) {
+                        uint32_t key = (uint32_t)L << 24;
+                        for (int b = 0; b < L; b++) key |= fsv_base_at(A.store, t.y_word, t.y_len, t.y_rev, yp + b) << (2 * b);
+                        uint32_t e = atomicAdd(&s_evn, 1u);
+                        if (e < FSV_EV_CAP) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
+                    }
+                }
+                yp += L; p += L;
+                continue;
+            }
+            atomicAdd(&s_cnt[xp][5], 1u);
+            if (pend) { atomicAdd(&s_cnt[xp][6], 1u); pend = false; }
+            if (op == 3u) atomicAdd(&s_cnt[xp][4], 1u);
+            else { atomicAdd(&s_cnt[xp][fsv_base_at(A.store, t.y_word, t.y_len, t.y_rev, yp)], 1u); yp++; }
+            xp++; p++;
+        }
+    }
+    __syncthreads();
+    uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
+    const bool verbatim = s_cover < 3u;
+    const uint32_t evn = min(s_evn, (uint32_t)FSV_EV_CAP);
+    if (s_evn > FSV_EV_CAP && lane == 0) atomicOr(&A.warn[r], 8u);
+    // per-column decision
+    for (int c = lane; c < glen; c += 64) {
+        const uint32_t own = fsv_base_fwd(A.store, xw, gs + c);
+        uint8_t nb = 0;
+        if (verbatim) { s_out[c][1] = (uint8_t)own; nb = 1; }
+        else {
+            const int p = gs + c;
+            bool homo = (p > 0 && fsv_base_fwd(A.store, xw, p - 1) == own) || (p + 1 < xlen && fsv_base_fwd(A.store, xw, p + 1) == own);
+            const int arrived = (int)s_cnt[c][5], instot = (int)s_cnt[c][6];
+            if (instot) {
+                int bc = 0; uint32_t bk = 0;
+                for (uint32_t i = 0; i < evn; i++) {
+                    if (s_evcol[i] != c) continue;
+                    const uint32_t key = s_evkey[i];
+                    int cn = 0;
+                    for (uint32_t j2 = 0; j2 < evn; j2++) cn += (s_evcol[j2] == c && s_evkey[j2] == key);
+                    if (cn > bc || (cn == bc && key < bk)) { bc = cn; bk = key; }
+                }
+                const int none = arrived - instot + 1, total = arrived + 1;
+                if (bc > none && vote_wins(bc, total, homo)) {
+                    const int L = (int)(bk >> 24);
+                    for (int b = 0; b < L; b++) s_out[c][1 + nb++] = (uint8_t)((bk >> (2 * b)) & 3u);
+                }
+            }
+            int v[5];
+            for (int b = 0; b < 5; b++) v[b] = (int)s_cnt[c][b];
+            v[own]++;
+            const int total = v[0] + v[1] + v[2] + v[3] + v[4];
+            int bestb = (int)own, bestc = v[own];
+            for (int b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
+            if (bestb != (int)own && !vote_wins(bestc, total, homo)) bestb = (int)own;
+            if (bestb < 4) s_out[c][1 + nb++] = (uint8_t)bestb;
+        }
+        s_out[c][0] = nb;
+    }
+    __syncthreads();
+    // output offsets: each lane owns a contiguous chunk of columns
+    const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
+    uint32_t mine = 0;
+    for (int c = c0; c < c1; c++) mine += s_out[c][0];
+    s_scan[lane] = mine;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (int i = 0; i < 64; i++) { uint32_t v = s_scan[i]; if (i < lane) off += v; tot += v; }
+    if (tot > FSV_CW_STRIDE) { // cannot happen with <= 12-base insertions winning at a few columns; keep the read as it is
+        for (int c = lane; c < glen; c += 64) dst[c] = (uint8_t)fsv_base_fwd(A.store, xw, gs + c);
+        if (lane == 0) { A.cwin_len[gw] = (uint16_t)glen; atomicOr(&A.warn[r], 16u); }
+        return;
+    }
+    for (int c = c0; c < c1; c++) for (int b = 0; b < s_out[c][0]; b++) dst[off++] = s_out[c][1 + b];
+    if (lane == 0) A.cwin_len[gw] = (uint16_t)tot;
+}
+
+// ------------------------------------------------------------------------------------------------ k_newlen / k_repack
+__global__ void k_newlen(const uint32_t *__restrict__ gwin_off, const uint16_t *__restrict__ cwin_len, uint32_t n_reads, int32_t *__restrict__ new_len)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int32_t L = 0;
+    for (uint32_t g = gwin_off[r]; g < gwin_off[r + 1]; g++) L += cwin_len[g];
+    new_len[r] = L;
+}
+
+// One thread per output word: gathers 16 bases from the corrected windows of its read (optionally reverse-complemented).
+__global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwin_off, const uint16_t *__restrict__ cwin_len,
+                                                const uint8_t *__restrict__ cwin, const uint32_t *__restrict__ new_word_off,
+                                                const int32_t *__restrict__ new_len, uint32_t n_reads, uint32_t total_words, int rc,
+                                                uint32_t *__restrict__ out)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= total_words) return;
+    uint32_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (new_word_off[mid] <= w) lo = mid; else hi = mid; }
+    const uint32_t r = lo;
+    const int len = new_len[r];
+    const int b0 = (int)(w - new_word_off[r]) * 16;
+    uint32_t v = 0;
+    if (b0 < len) {
+        // locate the window holding the first source base, then step window by window
+        const uint32_t g0 = gwin_off[r], g1 = gwin_off[r + 1];
+        int src = rc ? len - 1 - b0 : b0;
+        uint32_t g = g0; int acc = 0;
+        while (g + 1 < g1 && acc + (int)cwin_len[g] <= src) { acc += cwin_len[g]; g++; }
+        for (int j = 0; j < 16 && b0 + j < len; j++) {
+            uint32_t code = cwin[(size_t)g * FSV_CW_STRIDE + (src - acc)];
+            if (rc) {
+                code = 3u - code;
+                src--;
+                while (src < acc && g > g0) { g--; acc -= cwin_len[g]; }
+            } else {
+                src++;
+                while (g + 1 < g1 && src - acc >= (int)cwin_len[g]) { acc += cwin_len[g]; g++; }
+            }
+            v |= code << (2 * j);
+        }
+    }
+    out[w] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ k_exact
+// if_exact_match (Assembly.cpp:894-974): the two overlap intervals must be the same string.  One wavefront per overlap slot.
+__global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                              const int32_t *__restrict__ read_len, const uint32_t *__restrict__ set_start,
+                                              const uint32_t *__restrict__ pair_base, uint32_t n_sets, fsv_ovl *__restrict__ ovl)
+{
+    const uint32_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    fsv_ovl o = ovl[p];
+    if (!o.valid) return;
+    uint32_t lo = 0, hi = n_sets;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (pair_base[mid] <= p) lo = mid; else hi = mid; }
+    const uint32_t r0 = set_start[lo];
+    const uint32_t rq = r0 + o.q, rt = r0 + o.t;
+    const int L = o.x_e - o.x_s + 1;
+    bool same = (L == o.y_e - o.y_s + 1);
+    if (same) {
+        const uint32_t xw = word_off[rq], yw = word_off[rt];
+        const int ylen = read_len[rt];
+        bool diff = false;
+        for (int i = lane; i < L && !diff; i += 64)
+            diff = fsv_base_fwd(store, xw, o.x_s + i) != fsv_base_at(store, yw, ylen, o.rev, o.y_s + i);
+        same = !__any(diff);
+    }
+    if (lane == 0) { o.exact = same ? 1 : 0; ovl[p] = o; }
+}
+
+// ------------------------------------------------------------------------------------------------ k_stitch
+struct fsv_piece { uint32_t read; uint32_t rev; uint32_t len; uint32_t pad; uint64_t dst; };
+__global__ __launch_bounds__(256) void k_stitch(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                                const int32_t *__restrict__ read_len, const fsv_piece *__restrict__ pieces, char *__restrict__ out)
+{
+    const fsv_piece pc = pieces[blockIdx.x];
+    const uint32_t w = word_off[pc.read];
+    const int len = read_len[pc.read];
+    for (uint32_t i = threadIdx.x; i < pc.len; i += blockDim.x) out[pc.dst + i] = "ACGT"[fsv_base_at(store, w, len, (int)pc.rev, (int)i)];
+}
+
+__global__ void k_unpack_reads(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off, const int32_t *__restrict__ read_len,
+                               const uint64_t *__restrict__ dst_off, char *__restrict__ out)
+{
+    const uint32_t r = blockIdx.x;
+    const uint32_t w = word_off[r];
+    const int len = read_len[r];
+    for (int i = threadIdx.x; i < len; i += blockDim.x) out[dst_off[r] + i] = "ACGT"[fsv_base_fwd(store, w, i)];
+}

@@ -1,0 +1,104 @@
+// bpm_device.h -- device-side banded bit-parallel edit distance shared by K5 (verify), the rescue pass and K6 (path).
+// Recurrence and end-site rule follow hifiasm-0.14 Levenshtein_distance.h:274-461 (64-bit words, as the scalar reference).
+#pragma once
+#include "fsv_internal.h"
+
+struct BpmState {
+    uint64_t eq0, eq1, eq2, eq3; // match masks of the y rows inside the band
+    uint64_t vp, vn;
+};
+
+__device__ __forceinline__ uint64_t bpm_pick_eq(const BpmState &s, uint32_t c)
+{
+    uint64_t lo = (c & 1u) ? s.eq1 : s.eq0;
+    uint64_t hi = (c & 1u) ? s.eq3 : s.eq2;
+    return (c & 2u) ? hi : lo;
+}
+
+__device__ __forceinline__ void bpm_eq_set(BpmState &s, uint32_t c, uint64_t bit)
+{
+    s.eq0 |= (c == 0u) ? bit : 0ull;
+    s.eq1 |= (c == 1u) ? bit : 0ull;
+    s.eq2 |= (c == 2u) ? bit : 0ull;
+    s.eq3 |= (c == 3u) ? bit : 0ull;
+}
+
+// y base at padded-window column j (column 0 sits k bases before the predicted start);
+// 4 = outside the read ('N' in the reference's fill_subregion).
+__device__ __forceinline__ uint32_t bpm_ywin_base(const uint32_t *__restrict__ store, const fsv_wtask &t, int win0, int j)
+{
+    int p = win0 + j;
+    if (p < 0 || p >= t.y_len) return 4u;
+    return fsv_base_at(store, t.y_word, t.y_len, t.y_rev, p);
+}
+
+// determine_overlap_region (Correct.cpp:203-250): false = window geometrically impossible
+__device__ __forceinline__ bool bpm_window_geometry(const fsv_wtask &t, fsv_wres &r)
+{
+    const int n = t.x_len, k = t.k, wlen = n + 2 * k;
+    r.end_site = -1; r.err = -1; r.y_beg = -1; r.extra_begin = -1; r.extra_end = -1;
+    if (t.y_start < 0 || t.y_len <= t.y_start || t.y_len - t.y_start + 2 * k + FSV_K_MAX < wlen) return false;
+    int ys = t.y_start - k, olen = min(wlen, t.y_len - ys);
+    r.extra_end = (int16_t)(wlen - olen);
+    r.extra_begin = 0;
+    if (ys < 0) { r.extra_begin = (int16_t)(-ys); ys = 0; }
+    r.y_beg = ys;
+    return true;
+}
+
+// last-column scan, Levenshtein_distance.h:418-457
+__device__ __forceinline__ int bpm_pick_end(const BpmState &s, int err, int n, int k, int &best_out)
+{
+    int best = -1, site = -1, e = err, ungapped = -1;
+    if (e <= k) { best = e; site = n - 1; }
+    for (int i = 0; i < 2 * k;) {
+        e += (int)((s.vp >> i) & 1ull);
+        e -= (int)((s.vn >> i) & 1ull);
+        ++i;
+        if (e <= k && (best < 0 || e <= best)) { best = e; site = n - 1 + i; }
+        if (i == k) ungapped = e;
+    }
+    if (best >= 0 && k > 0 && ungapped == best) site = n - 1 + k;
+    best_out = best;
+    return best < 0 ? -1 : site;
+}
+
+// Column sink for K6: called once per DP column with that column's D0 and the post-update VP/VN.
+struct BpmNoSink {
+    __device__ __forceinline__ void operator()(int, uint64_t, uint64_t, uint64_t) const {}
+};
+
+template <class Sink>
+__device__ __forceinline__ void bpm_run(const uint32_t *__restrict__ store, const fsv_wtask &t, fsv_wres &r, Sink sink)
+{
+    if (!bpm_window_geometry(t, r)) return;
+    const int n = t.x_len, k = t.k;
+    const int win0 = t.y_start - k;
+    BpmState s;
+    s.eq0 = s.eq1 = s.eq2 = s.eq3 = 0; s.vp = 0; s.vn = 0;
+    for (int b = 0; b <= 2 * k; b++) bpm_eq_set(s, bpm_ywin_base(store, t, win0, b), 1ull << b);
+    const uint64_t top = 1ull << (2 * k);
+    int err = 0;
+    for (int i = 0; i < n; i++) {
+        uint32_t c = fsv_base_fwd(store, t.x_word, t.x_start + i);
+        uint64_t x = bpm_pick_eq(s, c) | s.vn;
+        uint64_t d0 = ((s.vp + (x & s.vp)) ^ s.vp) | x;
+        uint64_t hn = s.vp & d0;
+        uint64_t hp = s.vn | ~(s.vp | d0);
+        uint64_t sh = d0 >> 1;
+        s.vn = sh & hp;
+        s.vp = hn | ~(sh | hp);
+        if (!(d0 & 1ull)) {
+            ++err;
+            if (err - 2 * k > k) return; // Levenshtein_distance.h:367-375
+        }
+        sink(i, d0, s.vp, s.vn);
+        if (i + 1 < n) {
+            s.eq0 >>= 1; s.eq1 >>= 1; s.eq2 >>= 1; s.eq3 >>= 1;
+            bpm_eq_set(s, bpm_ywin_base(store, t, win0, i + 1 + 2 * k), top);
+        }
+    }
+    int best;
+    r.end_site = bpm_pick_end(s, err, n, k, best);
+    r.err = best;
+}

@@ -50,6 +50,10 @@ int fsv_ctx_create(int device, fsv_ctx **out)
 void fsv_ctx_destroy(fsv_ctx *ctx)
 {
     if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->asm_ws_free) ctx->asm_ws_free(ctx);
+    if (ctx->aln_ws_free) ctx->aln_ws_free(ctx);
     if (ctx->own_stream && ctx->stream) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);

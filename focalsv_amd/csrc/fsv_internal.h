@@ -14,6 +14,10 @@ struct fsv_ctx {
     uint64_t hbm_bytes = 0;
     std::string name;
     std::string last_error;
+    void *asm_ws = nullptr;                 // assembly workspace (asm.hip)
+    void (*asm_ws_free)(fsv_ctx *) = nullptr;
+    void *aln_ws = nullptr;                 // alignment workspace (aln.hip)
+    void (*aln_ws_free)(fsv_ctx *) = nullptr;
 };
 
 #define FSV_HIP(ctx, call)                                                              \

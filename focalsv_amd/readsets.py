@@ -1,0 +1,33 @@
+"""Host-side container for a batch of read sets (one set = one FASTA the reference hands to hifiasm)."""
+from dataclasses import dataclass
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class PackedBatch:
+    words: np.ndarray      # uint32 2-bit store
+    word_off: np.ndarray   # uint64 [n_reads + 1]
+    read_len: np.ndarray   # int32 [n_reads]
+    set_start: np.ndarray  # uint32 [n_sets + 1]
+
+    @property
+    def n_reads(self):
+        return len(self.read_len)
+
+    @property
+    def n_sets(self):
+        return len(self.set_start) - 1
+
+
+def pack_sets(sets: Sequence[Sequence[bytes]]) -> PackedBatch:
+    reads: List[bytes] = []
+    start = [0]
+    for s in sets:
+        reads.extend(s)
+        start.append(len(reads))
+    words, off, lens = _lib.pack_reads(reads)
+    return PackedBatch(words, off, lens, np.asarray(start, dtype=np.uint32))

@@ -113,6 +113,90 @@ int fsv_bpm_windows_dev(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wtask
 int fsv_bpm_windows(fsv_ctx *ctx, const uint32_t *store, size_t store_words, const fsv_wtask *tasks,
                     uint32_t n_tasks, fsv_wres *res);
 
+/* ---- assembler boundary -----------------------------------------------------
+ * Replaces the process boundary `hifiasm -o <prefix> -t <T> <reads.fa>` and the GFA
+ * read-back (focalsv/3_assembly/run_assembly.py:15-44, post_assembly.py:79-95).
+ * One "read set" = one FASTA the reference would hand to one hifiasm process
+ * (PS<ps>_hp1.fa, PS<ps>_hp2.fa of a region).  Many sets are assembled per call: a
+ * single 50 kb region cannot fill 256 CUs.
+ *
+ * Stages (hifiasm-0.14 file:line in DESIGN.md): minimizer sketch -> per-read index ->
+ * anchors + chaining -> 375-bp window verification (K5) -> rescue/accept -> window
+ * paths (K6) -> per-column consensus (K8) -> re-pack + reverse-complement, n_rounds
+ * times; then exact overlaps, layout, contig stitching.
+ */
+typedef struct fsv_asm_params {
+    int32_t k, w, hpc;        /* minimizer scheme; hifiasm defaults 51, 51, 1 (CommandLines.cpp:109-166) */
+    int32_t n_rounds;         /* correction rounds, 3 */
+    int32_t min_ovlp;         /* shortest overlap kept, 500 */
+    int32_t min_anchors;      /* shortest chain kept, 3 */
+    int32_t lookback;         /* chain DP predecessors examined, 64 (= one wavefront) */
+    int32_t bw_ec;            /* chain indel budget per mille in correction rounds, 20 (hifiasm 0.02) */
+    int32_t bw_final;         /* ... in the final overlap pass, 0 = co-linear anchors only */
+    int32_t min_contig_reads; /* contigs built from fewer reads are dropped unless none is left, 2 */
+} fsv_asm_params;
+void fsv_asm_default_params(fsv_asm_params *p);
+
+typedef struct fsv_mz {       /* ha_mz1_t, htab.h:8-13 */
+    uint64_t hash;
+    uint32_t pos;             /* index of the k-mer's last base */
+    uint8_t  rev, span;
+    uint16_t pad;
+} fsv_mz;                     /* 16 bytes */
+
+typedef struct fsv_ovl {      /* overlap_region / ma_hit_t, Hash_Table.h:67-101, Overlaps.h:56-64 */
+    uint32_t q, t;            /* read indices inside the set */
+    int32_t x_s, x_e;         /* inclusive range on q (forward strand) */
+    int32_t y_s, y_e;         /* inclusive range on t, strand coordinates */
+    int32_t score, n_chain;
+    int32_t chain_off;        /* unused on the device */
+    int32_t first_win, n_win; /* window tasks of this overlap */
+    int32_t align_len, err_sum;
+    uint8_t rev, is_match, exact, valid;
+} fsv_ovl;                    /* 56 bytes */
+
+typedef struct fsv_readsets {
+    const uint32_t *store_dev;  /* device: 2-bit read store */
+    const uint64_t *word_off;   /* host: n_reads+1 word offsets into the store */
+    const int32_t  *read_len;   /* host: n_reads lengths in bases */
+    const uint32_t *set_start;  /* host: n_sets+1 read indices; set s owns reads [set_start[s], set_start[s+1]) */
+    uint32_t n_reads, n_sets;
+} fsv_readsets;
+
+typedef struct fsv_contigs {
+    char     *seq;         /* host, capacity seq_cap: ASCII contig bases back to back */
+    uint64_t  seq_cap;
+    uint64_t *off;         /* host, capacity contig_cap+1 */
+    uint32_t *set;         /* host, capacity contig_cap: owning set of each contig */
+    uint32_t *n_reads;     /* host, capacity contig_cap: reads laid out in each contig */
+    uint32_t  contig_cap;
+    uint32_t  n_contigs;   /* out */
+    int32_t  *set_status;  /* host, n_sets: 0 ok, >0 warning bits (FSV_W_*), <0 FSV_E* for that set only */
+} fsv_contigs;
+
+#define FSV_W_MZ_TRUNC     1  /* a read had more minimizers than the per-read cap; the rest were ignored */
+#define FSV_W_ANCHOR_TRUNC 2  /* a read pair had more anchors than the chaining tile holds */
+#define FSV_W_NO_LAYOUT    4  /* no overlap graph: the longest read was emitted as the contig */
+
+/* capacity needed for fsv_contigs.seq / contig count for these read sets */
+int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap);
+int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params *params, fsv_contigs *out);
+
+/* Optional per-stage counters of the last fsv_assemble_batch on this context (for the roofline accounting):
+ * window tasks verified (K5), paths computed (K6), DP column steps, algorithmic bytes (SURVEY.md 8d model). */
+typedef struct fsv_asm_stats {
+    uint64_t n_pairs, n_overlaps, n_windows, n_windows_matched, n_paths, n_path_dp;
+    uint64_t dp_columns;       /* K5 + rescue + K6 column steps */
+    uint64_t algo_bytes;       /* packed operand + result bytes of all DP tasks + reads in + contigs out */
+    uint64_t n_exact_overlaps;
+    double   ms_sketch, ms_chain, ms_verify, ms_path, ms_consensus, ms_final, ms_total;
+} fsv_asm_stats;
+int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out);
+
+/* Test hook: after fsv_assemble_batch(...) with n_rounds = r, the corrected reads of the last round
+ * can be fetched as ASCII (same order as the input reads). */
+int fsv_asm_fetch_reads(fsv_ctx *ctx, char *seq, uint64_t seq_cap, uint64_t *off, uint32_t n_reads);
+
 #ifdef __cplusplus
 }
 #endif

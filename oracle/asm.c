@@ -246,20 +246,30 @@ static void window_path(const char *x, const char *y, int ylen, int rev, orc_win
 }
 
 /* ---------------------------------------------------------------- S7: consensus of one grid window of read x */
-typedef struct { uint32_t key; int32_t cnt; } ins_slot;
-#define INS_SLOTS 4
+/* insertion votes are kept as an event list (column, key); key = len << 24 | 2-bit bases, len <= INS_MAXLEN */
+typedef struct { int32_t col; uint32_t key; } ins_event;
 #define INS_MAXLEN 12
 
 static inline int base2(char c) { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 0; } }
 
-static void ins_vote(ins_slot *s, uint32_t key)
+typedef struct { ins_event *e; int n, cap; } ins_list;
+static void ins_vote(ins_list *l, int col, uint32_t key)
 {
-    int i;
-    for (i = 0; i < INS_SLOTS; i++) {
-        if (s[i].cnt && s[i].key == key) { s[i].cnt++; return; }
-        if (!s[i].cnt) { s[i].key = key; s[i].cnt = 1; return; }
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 256; l->e = (ins_event *)realloc(l->e, sizeof(ins_event) * (size_t)l->cap); }
+    l->e[l->n].col = col; l->e[l->n].key = key; l->n++;
+}
+/* most frequent key at a column; ties go to the smaller key; returns its count (0 = none) */
+static int ins_winner(const ins_list *l, int col, uint32_t *key_out)
+{
+    int i, j, best = 0; uint32_t bk = 0;
+    for (i = 0; i < l->n; i++) {
+        int c = 0;
+        if (l->e[i].col != col) continue;
+        for (j = 0; j < l->n; j++) c += (l->e[j].col == col && l->e[j].key == l->e[i].key);
+        if (c > best || (c == best && l->e[i].key < bk)) { best = c; bk = l->e[i].key; }
     }
-    /* table full: the vote still counts in the column total (caller), but cannot win */
+    *key_out = bk;
+    return best;
 }
 
 static int is_homopolymer_site(const char *x, int xlen, int p)
@@ -410,7 +420,7 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
     const char *x = R->seq[q];
     int xlen = R->len[q], nwin = (xlen + ORC_WINDOW - 1) / ORC_WINDOW, g, i, outn = 0;
     int32_t (*cnt)[6] = (int32_t (*)[6])malloc(sizeof(int32_t[6]) * (ORC_WINDOW + 1));
-    ins_slot (*ins)[INS_SLOTS] = (ins_slot (*)[INS_SLOTS])malloc(sizeof(ins_slot[INS_SLOTS]) * (ORC_WINDOW + 1));
+    ins_list ins = {0, 0, 0};
     int32_t *instot = (int32_t *)malloc(sizeof(int32_t) * (ORC_WINDOW + 1));
     /* overlaps of q are contiguous in ov[] (generated q-major) */
     int o0 = 0, o1;
@@ -421,7 +431,7 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
     for (g = 0; g < nwin; g++) {
         int gs = g * ORC_WINDOW, glen = (gs + ORC_WINDOW <= xlen ? ORC_WINDOW : xlen - gs), cover = 0, c;
         memset(cnt, 0, sizeof(int32_t[6]) * (ORC_WINDOW + 1));
-        memset(ins, 0, sizeof(ins_slot[INS_SLOTS]) * (ORC_WINDOW + 1));
+        ins.n = 0;
         memset(instot, 0, sizeof(int32_t) * (ORC_WINDOW + 1));
         for (i = o0; i < o1; i++) {
             const orc_ovl *o = &ov[i];
@@ -443,7 +453,7 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
                     if (gap <= INS_MAXLEN) {
                         uint32_t key = (uint32_t)gap << 24; int b;
                         for (b = 0; b < gap; b++) key |= (uint32_t)base2(ybase(y, ylen, o->rev, w->ry_start - gap + b)) << (2 * b);
-                        ins_vote(ins[0], key);
+                        ins_vote(&ins, 0, key);
                     }
                 }
             }
@@ -457,7 +467,7 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
                         if (L <= INS_MAXLEN) {
                             uint32_t key = (uint32_t)L << 24; int b;
                             for (b = 0; b < L; b++) key |= (uint32_t)base2(ybase(y, ylen, o->rev, yp + b)) << (2 * b);
-                            ins_vote(ins[xp], key);
+                            ins_vote(&ins, xp, key);
                         }
                     }
                     yp += L; p += L;
@@ -479,12 +489,12 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
             /* (1) what sits between column c-1 and c: nothing, or an inserted string */
             {
                 int none = cnt[c][5] - instot[c] + 1; /* + the read itself */
-                int bi = -1, s;
+                uint32_t key = 0;
+                int bc = instot[c] ? ins_winner(&ins, c, &key) : 0;
                 total = cnt[c][5] + 1;
-                for (s = 0; s < INS_SLOTS; s++) if (ins[c][s].cnt && (bi < 0 || ins[c][s].cnt > ins[c][bi].cnt)) bi = s;
-                if (bi >= 0 && ins[c][bi].cnt > none && wins(ins[c][bi].cnt, total, homo)) {
-                    int L = (int)(ins[c][bi].key >> 24);
-                    for (b = 0; b < L; b++) out[outn++] = "ACGT"[(ins[c][bi].key >> (2 * b)) & 3];
+                if (bc > none && wins(bc, total, homo)) {
+                    int L = (int)(key >> 24);
+                    for (b = 0; b < L; b++) out[outn++] = "ACGT"[(key >> (2 * b)) & 3];
                 }
             }
             /* (2) the column itself: A/C/G/T or deleted */
@@ -501,7 +511,7 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
             }
         }
     }
-    free(cnt); free(ins); free(instot);
+    free(cnt); free(ins.e); free(instot);
     (void)i;
     return outn;
 }

@@ -1,0 +1,92 @@
+"""The batched HIP assembly (fsv_assemble_batch through the C ABI) against the CPU oracle, bit for bit:
+corrected reads after 1, 2 and 3 rounds and the final contigs; plus the hifiasm contig digests."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from focalsv_amd import _lib, synth
+from focalsv_amd.readsets import pack_sets
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with _lib.Context(0) as c:
+        yield c
+
+
+def canon(s):
+    return min(s, synth.revcomp(s))
+
+
+def gpu_assemble(ctx, sets, params=None):
+    b = pack_sets(sets)
+    d = ctx.upload(b.words)
+    try:
+        contigs, cset, cnr, status = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start, params)
+        reads = ctx.fetch_reads(b.n_reads, int(b.read_len.sum()) * 2 + 1024)
+    finally:
+        ctx.dev_free(d)
+    return contigs, cset, status, reads, b
+
+
+@pytest.mark.parametrize("rounds", [0, 1, 2, 3])
+def test_rounds_match_oracle(ctx, rounds):
+    r = synth.make_region(3)
+    sets = [r.reads[0], r.reads[1]]
+    p = ctx.default_asm_params()
+    p.n_rounds = rounds
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets, p)
+    po = O.default_params()
+    po.n_rounds = rounds
+    k = 0
+    for si, s in enumerate(sets):
+        oc, ocorr = O.assemble(s, po)
+        for j in range(len(s)):
+            assert reads[k + j] == ocorr[j], (rounds, si, j, len(reads[k + j]), len(ocorr[j]))
+        k += len(s)
+        mine = [c for c, cs in zip(contigs, cset) if cs == si]
+        assert mine == oc, (rounds, si, [len(c) for c in mine], [len(c) for c in oc])
+
+
+def test_batch_of_regions_matches_oracle_and_haplotypes(ctx):
+    regions = [synth.make_region(i) for i in (0, 7, 22, 38)]
+    sets = [rd for r in regions for rd in r.reads]
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets)
+    for si, s in enumerate(sets):
+        oc, _ = O.assemble(s)
+        mine = [c for c, cs in zip(contigs, cset) if cs == si]
+        assert mine == oc
+    exact = 0
+    for ri, r in enumerate(regions):
+        for h in (0, 1):
+            mine = [c for c, cs in zip(contigs, cset) if cs == 2 * ri + h]
+            exact += (len(mine) == 1 and canon(mine[0]) == canon(r.haps[h]))
+    assert exact >= 7  # region 38 / hp2 keeps hifiasm's own 1-base end artifact
+
+
+def test_contigs_equal_hifiasm_digests(ctx, golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, "hifiasm_contigs.json")))["sets"]
+    want = [g for g in gold if g["region"] in (1, 2, 39)]
+    regions = {i: synth.make_region(i) for i in (1, 2, 39)}
+    sets = [regions[g["region"]].reads[g["hap"] - 1] for g in want]
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets)
+    for si, g in enumerate(want):
+        got = sorted((len(c), hashlib.md5(canon(c)).hexdigest()) for c, cs in zip(contigs, cset) if cs == si)
+        assert got == sorted((c["len"], c["md5"]) for c in g["contigs"])
+
+
+def test_degenerate_sets(ctx):
+    r = synth.make_region(5)
+    sets = [[], r.reads[0][:1], r.reads[0][:2], [b"ACGT" * 30, b"ACGT" * 30]]
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets)
+    assert len(status) == 4
+    for si, s in enumerate(sets):
+        oc, _ = O.assemble(s) if s else ([], [])
+        mine = [c for c, cs in zip(contigs, cset) if cs == si]
+        assert mine == oc
