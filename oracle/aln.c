@@ -1,0 +1,285 @@
+/* oracle/aln.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the contig-vs-reference alignment FocalSV obtains from
+ *   minimap2 -a -x asm5 --cs -r2k ref_chr.fa assemblies.fa | samtools sort
+ * (focalsv/4_sv_calling/Dippav/DipPAV_variant_call.py:103-108), as consumed by
+ * extract_contig_signature_CCS.py:14-47, 342-432 (reference_name, pos, reference_end, cigar, is_reverse, mapq).
+ *
+ * minimap2 2.24 itself is NOT under /root/reference (conda pin requirement.yaml:12), so this part of the
+ * oracle is "parity unpinned" against minimap2.  What is pinned:
+ *   - the DP recurrence, tie-breaking and backtrack state machine follow the in-tree ksw2
+ *     (software/hifiasm-0.14/ksw2_extz2_sse.c:23-305 left-aligned branch :171-196; ksw2.h:115-150 ksw_backtrack),
+ *     checked in single-affine mode against tests/golden/ksw_extz2.json minted from that code;
+ *   - minimizer seeds are ha_sketch without HPC (sketch.cpp:39-137), k = 19 as in minimap2's asm5 preset;
+ *   - scoring is the published asm5 preset: A=1 B=19 O=39,81 E=3,1.
+ * Pipeline: seeds unique in both sequences -> majority strand -> co-linear chain (look-back 64) ->
+ * gap-free runs between anchors stay 'M'; everything else is merged into events, padded by up to
+ * ALN_PAD identical bases per side (so that a gap can be left-aligned past the seed boundary) and
+ * aligned globally with dual-affine gaps; contig ends are extended gap-free with an X-drop and the
+ * rest is soft-clipped.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+static char comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+
+void orc_aln_default_params(orc_aln_params *P)
+{
+    P->k = 19; P->w = 19; P->min_anchors = 3; P->lookback = 64; P->max_gap = 20000;
+    P->a = 1; P->b = 19; P->q = 39; P->e = 3; P->q2 = 81; P->e2 = 1;
+    P->pad = 24; P->max_mm_run = 4; P->xdrop = 100; P->max_cells = 1 << 26;
+}
+
+/* ------------------------------------------------------------------ global dual-affine DP (ksw2 conventions)
+ * i indexes the target (reference), j the query.  Per cell one byte:
+ *   bits 0-2  which state gives H: 0 diagonal, 1 E (deletion), 2 F (insertion), 3 E2, 4 F2 (strictly greater wins, in that order)
+ *   0x08 E continues, 0x10 F continues, 0x20 E2 continues, 0x40 F2 continues (strictly better than opening)
+ * q2 < 0 disables the second gap model (single affine, as ksw_extz2_sse). */
+#define NEG (-(1 << 29))
+int orc_nw(const char *t, int tl, const char *q, int ql, const orc_aln_params *P, uint32_t *cigar, int cigar_cap, int *n_cigar, uint8_t *bt)
+{
+    const int two = P->q2 >= 0;
+    int32_t *H = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ql + 1) * 2), *Hn = H + (ql + 1), *tmp;
+    int32_t *base = H;
+    int i, j, n = 0, state = 0, score;
+    /* row -1 */
+    H[0] = 0;
+    for (j = 1; j <= ql; j++) {
+        int g1 = -(P->q + P->e * j), g2 = two ? -(P->q2 + P->e2 * j) : NEG;
+        H[j] = g1 > g2 ? g1 : g2;
+    }
+    {
+        int32_t *E = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ql + 1) * 2), *E2 = E + (ql + 1);
+        for (j = 0; j <= ql; j++) { E[j] = NEG; E2[j] = NEG; }
+        /* E[j] = value of the E state entering cell (i, j) from (i-1, j): initialised from the boundary row */
+        for (j = 1; j <= ql; j++) {
+            /* coming down from H(-1, j-1 .. ) : E(0,j) = H(-1,j) - q - e */
+            E[j] = H[j] - P->q - P->e;
+            E2[j] = two ? H[j] - P->q2 - P->e2 : NEG;
+        }
+        for (i = 0; i < tl; i++) {
+            int32_t hleft, f, f2, hdiag;
+            {
+                int g1 = -(P->q + P->e * (i + 1)), g2 = two ? -(P->q2 + P->e2 * (i + 1)) : NEG;
+                Hn[0] = g1 > g2 ? g1 : g2; /* H(i, -1) */
+            }
+            hleft = Hn[0];
+            f = hleft - P->q - P->e; f2 = two ? hleft - P->q2 - P->e2 : NEG;
+            hdiag = H[0]; /* H(i-1, -1) */
+            for (j = 1; j <= ql; j++) {
+                int32_t z = hdiag + (t[i] == q[j - 1] && t[i] != 'N' ? P->a : -P->b);
+                int32_t a = E[j], b = f, a2 = E2[j], b2 = f2, h, o;
+                uint8_t d = 0;
+                h = z;
+                if (a > h) { h = a; d = 1; }
+                if (b > h) { h = b; d = 2; }
+                if (two && a2 > h) { h = a2; d = 3; }
+                if (two && b2 > h) { h = b2; d = 4; }
+                /* next-cell gap states and their continuation flags */
+                o = h - P->q;
+                if (a > o) { d |= 0x08; E[j] = a - P->e; } else E[j] = o - P->e;
+                if (b > o) { d |= 0x10; f = b - P->e; } else f = o - P->e;
+                if (two) {
+                    o = h - P->q2;
+                    if (a2 > o) { d |= 0x20; E2[j] = a2 - P->e2; } else E2[j] = o - P->e2;
+                    if (b2 > o) { d |= 0x40; f2 = b2 - P->e2; } else f2 = o - P->e2;
+                }
+                bt[(size_t)i * ql + (j - 1)] = d;
+                hdiag = H[j];
+                Hn[j] = h;
+            }
+            tmp = H; H = Hn; Hn = tmp;
+        }
+        free(E);
+    }
+    score = H[ql];
+    /* backtrack: ksw_backtrack (ksw2.h:119-150), emitted end-to-start then reversed */
+    i = tl - 1; j = ql - 1;
+    while (i >= 0 && j >= 0) {
+        uint8_t d = bt[(size_t)i * ql + j];
+        int op;
+        if (state == 0) state = d & 7;
+        else if (!((d >> (state + 2)) & 1)) state = 0;
+        if (state == 0) state = d & 7;
+        if (state == 0) { op = 0; i--; j--; }
+        else if (state == 1 || state == 3) { op = 2; i--; }
+        else { op = 1; j--; }
+        if (n && (cigar[n - 1] & 0xf) == (uint32_t)op) cigar[n - 1] += 1u << 4;
+        else { if (n == cigar_cap) { free(base); return NEG; } cigar[n++] = 1u << 4 | (uint32_t)op; }
+    }
+    if (i >= 0) { if (n && (cigar[n - 1] & 0xf) == 2) cigar[n - 1] += (uint32_t)(i + 1) << 4; else { if (n == cigar_cap) { free(base); return NEG; } cigar[n++] = (uint32_t)(i + 1) << 4 | 2; } }
+    if (j >= 0) { if (n && (cigar[n - 1] & 0xf) == 1) cigar[n - 1] += (uint32_t)(j + 1) << 4; else { if (n == cigar_cap) { free(base); return NEG; } cigar[n++] = (uint32_t)(j + 1) << 4 | 1; } }
+    for (i = 0; i < n / 2; i++) { uint32_t x = cigar[i]; cigar[i] = cigar[n - 1 - i]; cigar[n - 1 - i] = x; }
+    *n_cigar = n;
+    free(base);
+    return score;
+}
+
+/* ------------------------------------------------------------------ seeds + chain */
+typedef struct { int32_t qe, te; } anc_t;
+static int anc_cmp(const void *a, const void *b)
+{
+    const anc_t *x = (const anc_t *)a, *y = (const anc_t *)b;
+    if (x->qe != y->qe) return x->qe < y->qe ? -1 : 1;
+    if (x->te != y->te) return x->te < y->te ? -1 : 1;
+    return 0;
+}
+
+static inline int ilog2_32(uint32_t v) { int l = 0; while (v >>= 1) l++; return l; }
+
+/* chain of (contig, reference); on the reverse strand the contig coordinates are those of its reverse complement.
+ * returns the number of chain anchors (0 = none) */
+int orc_aln_chain(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, const orc_aln_params *P, int *rev_out,
+                  int32_t *cq, int32_t *ct, int cap)
+{
+    int i = 0, j = 0, n = 0, nf = 0, nr = 0, rev, best = -1, cnt = 0, c;
+    int lim = nq < nt ? nq : nt;
+    anc_t *a; uint8_t *sr; int32_t *f, *pre;
+    if (lim <= 0) return 0;
+    a = (anc_t *)malloc(sizeof(anc_t) * (size_t)lim);
+    sr = (uint8_t *)malloc((size_t)lim);
+    while (i < nq && j < nt) {
+        if (mq[i].hash < mt[j].hash) i++;
+        else if (mq[i].hash > mt[j].hash) j++;
+        else {
+            sr[n] = mq[i].rev ^ mt[j].rev;
+            a[n].qe = sr[n] ? (lenq - 1) - ((int32_t)mq[i].pos - mq[i].span + 1) : (int32_t)mq[i].pos;
+            a[n].te = (int32_t)mt[j].pos;
+            if (sr[n]) nr++; else nf++;
+            n++; i++; j++;
+        }
+    }
+    rev = nr > nf;
+    for (i = 0, j = 0; i < n; i++) if (sr[i] == rev) a[j++] = a[i];
+    n = j;
+    free(sr);
+    *rev_out = rev;
+    if (n < P->min_anchors) { free(a); return 0; }
+    qsort(a, (size_t)n, sizeof(anc_t), anc_cmp);
+    f = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 2); pre = f + n;
+    for (i = 0; i < n; i++) {
+        int32_t bs = P->k, bp = -1;
+        int lo = i - P->lookback < 0 ? 0 : i - P->lookback;
+        for (j = i - 1; j >= lo; j--) {
+            int32_t dq = a[i].qe - a[j].qe, dt = a[i].te - a[j].te, gap, sc;
+            if (dq <= 0 || dt <= 0) continue;
+            gap = dq > dt ? dq - dt : dt - dq;
+            if (gap > P->max_gap) continue;
+            sc = dq < dt ? dq : dt;
+            if (sc > P->k) sc = P->k;
+            if (gap) sc -= (gap >> 7) + (ilog2_32((uint32_t)gap) >> 1) + 1;
+            sc += f[j];
+            if (sc > bs) { bs = sc; bp = j; }
+        }
+        f[i] = bs; pre[i] = bp;
+    }
+    for (i = 0; i < n; i++) if (best < 0 || f[i] > f[best]) best = i;
+    for (c = best; c >= 0; c = pre[c]) cnt++;
+    if (cnt >= P->min_anchors && cnt <= cap) { int k2 = cnt; for (c = best; c >= 0; c = pre[c]) { k2--; cq[k2] = a[c].qe; ct[k2] = a[c].te; } }
+    else cnt = 0;
+    free(f); free(a);
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ one contig against one reference window */
+static void push(uint32_t *cg, int *n, int cap, uint32_t op, uint32_t len)
+{
+    if (!len) return;
+    if (*n && (cg[*n - 1] & 0xf) == op) { cg[*n - 1] += len << 4; return; }
+    if (*n < cap) cg[(*n)++] = len << 4 | op;
+}
+
+int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
+                     uint32_t *cigar, int cigar_cap)
+{
+    orc_mz *mq = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)(lenq + 8)), *mt = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)(lent + 8));
+    int nq, nt, rev = 0, nch, i, n = 0, w = P->w;
+    int32_t *cq, *ct;
+    char *q = NULL;
+    const char *Q;
+    memset(out, 0, sizeof(*out));
+    { int L = lenq > lent ? lenq : lent; if (L / 3000 + 1 > w) w = L / 3000 + 1; }
+    nq = orc_unique_sorted(mq, orc_sketch(contig, lenq, w, P->k, 0, mq, lenq + 8));
+    nt = orc_unique_sorted(mt, orc_sketch(ref, lent, w, P->k, 0, mt, lent + 8));
+    cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nq + 1) * 2); ct = cq + nq + 1;
+    nch = orc_aln_chain(mq, nq, lenq, mt, nt, P, &rev, cq, ct, nq);
+    free(mq); free(mt);
+    if (nch == 0) { free(cq); return 0; }
+    if (rev) { q = (char *)malloc((size_t)lenq); for (i = 0; i < lenq; i++) q[i] = comp(contig[lenq - 1 - i]); Q = q; } else Q = contig;
+    {
+        /* segment classes between consecutive anchors: 0 identical, 1 few mismatches ('M'), 2 needs DP */
+        int nseg = nch - 1, s;
+        uint8_t *cls = (uint8_t *)malloc((size_t)nseg + 1);
+        int qs0 = cq[0] - P->k + 1, ts0 = ct[0] - P->k + 1; /* first anchor k-mer is part of the alignment */
+        int qbeg, tbeg, qend, tend, x, best, bi;
+        for (s = 0; s < nseg; s++) {
+            int dq = cq[s + 1] - cq[s], dt = ct[s + 1] - ct[s], mm = 0, p;
+            if (dq != dt) { cls[s] = 2; continue; }
+            for (p = 1; p <= dq; p++) mm += Q[cq[s] + p] != ref[ct[s] + p];
+            cls[s] = mm == 0 ? 0 : (mm <= P->max_mm_run ? 1 : 2);
+        }
+        /* gap-free X-drop extension to the left of the first anchor and to the right of the last one */
+        x = 0; best = 0; bi = 0;
+        for (i = 1; qs0 - i >= 0 && ts0 - i >= 0; i++) {
+            x += Q[qs0 - i] == ref[ts0 - i] ? P->a : -P->b;
+            if (x > best) { best = x; bi = i; }
+            if (best - x > P->xdrop) break;
+        }
+        qbeg = qs0 - bi; tbeg = ts0 - bi;
+        x = 0; best = 0; bi = 0;
+        for (i = 1; cq[nch - 1] + i < lenq && ct[nch - 1] + i < lent; i++) {
+            x += Q[cq[nch - 1] + i] == ref[ct[nch - 1] + i] ? P->a : -P->b;
+            if (x > best) { best = x; bi = i; }
+            if (best - x > P->xdrop) break;
+        }
+        qend = cq[nch - 1] + bi; tend = ct[nch - 1] + bi; /* inclusive */
+        push(cigar, &n, cigar_cap, 4, (uint32_t)qbeg);
+        /* walk the segments: runs of class < 2 are M; runs of class 2 become one padded DP event */
+        {
+            int mstart_q = qbeg; /* start of the pending M run (query coordinate); the matching ref coordinate follows the diagonal */
+            s = 0;
+            while (s < nseg) {
+                int e;
+                if (cls[s] < 2) { s++; continue; }
+                e = s;
+                while (e + 1 < nseg && cls[e + 1] == 2) e++;
+                {
+                    /* event covers query (cq[s], cq[e+1]] and ref (ct[s], ct[e+1]] ; pad into the identical neighbours */
+                    int eqs = cq[s] + 1, eqe = cq[e + 1], ets = ct[s] + 1, ete = ct[e + 1];
+                    int lp = 0, rp = 0, lim_l, lim_r, tl, ql, nc = 0, sc;
+                    uint32_t *cg2; uint8_t *bt;
+                    lim_l = eqs - mstart_q; if (lim_l > P->pad) lim_l = P->pad;
+                    while (lp < lim_l && Q[eqs - 1 - lp] == ref[ets - 1 - lp]) lp++;
+                    lim_r = P->pad;
+                    if (eqe + lim_r > qend) lim_r = qend - eqe;
+                    if (ete + lim_r > tend) lim_r = tend - ete;
+                    /* do not pad into the next event: stop at the next class-2 segment's start */
+                    { int nx = e + 1; while (nx < nseg && cls[nx] < 2) nx++; if (nx < nseg && eqe + lim_r > cq[nx]) lim_r = cq[nx] - eqe; }
+                    while (rp < lim_r && Q[eqe + 1 + rp] == ref[ete + 1 + rp]) rp++;
+                    eqs -= lp; ets -= lp; eqe += rp; ete += rp;
+                    ql = eqe - eqs + 1; tl = ete - ets + 1;
+                    push(cigar, &n, cigar_cap, 0, (uint32_t)(eqs - mstart_q));
+                    if ((int64_t)ql * tl > P->max_cells) { free(cls); free(cq); free(q); return -1; }
+                    cg2 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(ql + tl + 2));
+                    bt = (uint8_t *)malloc((size_t)(ql > 0 ? ql : 1) * (size_t)(tl > 0 ? tl : 1));
+                    if (ql == 0) { nc = 1; cg2[0] = (uint32_t)tl << 4 | 2; }
+                    else if (tl == 0) { nc = 1; cg2[0] = (uint32_t)ql << 4 | 1; }
+                    else { sc = orc_nw(ref + ets, tl, Q + eqs, ql, P, cg2, ql + tl + 2, &nc, bt); (void)sc; }
+                    for (i = 0; i < nc; i++) push(cigar, &n, cigar_cap, cg2[i] & 0xf, cg2[i] >> 4);
+                    free(cg2); free(bt);
+                    mstart_q = eqe + 1;
+                }
+                s = e + 1;
+            }
+            push(cigar, &n, cigar_cap, 0, (uint32_t)(qend + 1 - mstart_q));
+        }
+        push(cigar, &n, cigar_cap, 4, (uint32_t)(lenq - 1 - qend));
+        out->ref_start = tbeg; out->ref_end = tend + 1; out->rev = (uint8_t)rev; out->mapq = 60; out->n_cigar = n;
+        out->n_chain = nch; out->q_start = qbeg; out->q_end = qend + 1;
+        free(cls);
+    }
+    free(cq); free(q);
+    return 1;
+}

@@ -61,6 +61,29 @@ void orc_asm_default_params(orc_asm_params *P);
 int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const orc_asm_params *P,
                  char *contigs, uint64_t contigs_cap, uint64_t *contig_off, int contig_cap, int *n_contigs,
                  char *corrected, uint64_t corrected_cap, uint64_t *corrected_off);
+typedef struct {
+    int32_t k, w;             /* seeds: 19, 19 (minimap2 asm5); w grows with the sequence length */
+    int32_t min_anchors, lookback, max_gap;
+    int32_t a, b, q, e, q2, e2; /* asm5: 1, 19, 39, 3, 81, 1; q2 < 0 = single affine */
+    int32_t pad;              /* identical bases added on each side of a DP event: 24 */
+    int32_t max_mm_run;       /* an equal-length inter-seed run with at most this many mismatches stays 'M': 4 */
+    int32_t xdrop;            /* gap-free end extension: 100 */
+    int32_t max_cells;        /* largest DP event: 2^26 cells */
+} orc_aln_params;
+
+typedef struct {
+    int32_t ref_start, ref_end; /* 0-based, end exclusive (pysam pos / reference_end) */
+    int32_t q_start, q_end;     /* aligned part of the (strand-oriented) contig */
+    int32_t n_cigar, n_chain;
+    uint8_t rev, mapq, pad[2];
+} orc_aln;
+
+void orc_aln_default_params(orc_aln_params *P);
+int orc_nw(const char *t, int tl, const char *q, int ql, const orc_aln_params *P, uint32_t *cigar, int cigar_cap, int *n_cigar, uint8_t *bt);
+int orc_aln_chain(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, const orc_aln_params *P, int *rev_out,
+                  int32_t *cq, int32_t *ct, int cap);
+int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
+                     uint32_t *cigar, int cigar_cap);
 int orc_sketch(const char *s, int len, int w, int k, int hpc, orc_mz *out, int cap);
 int orc_bpm(const char *y, int m, const char *x, int n, int k, int *err);
 int orc_bpm_path(const char *y, int m, const char *x, int n, int k, int *err, int *start_site, int *path_len,

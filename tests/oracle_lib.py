@@ -92,3 +92,46 @@ def assemble(reads, params=None):
     craw = corrected.raw
     return ([raw[int(coff[i]):int(coff[i + 1])] for i in range(nc.value)],
             [craw[int(roff[i]):int(roff[i + 1])] for i in range(n)])
+
+
+class AlnParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "min_anchors", "lookback", "max_gap", "a", "b", "q", "e", "q2", "e2", "pad",
+                                         "max_mm_run", "xdrop", "max_cells")]
+
+
+class Aln(C.Structure):
+    _fields_ = [("ref_start", C.c_int32), ("ref_end", C.c_int32), ("q_start", C.c_int32), ("q_end", C.c_int32),
+                ("n_cigar", C.c_int32), ("n_chain", C.c_int32), ("rev", C.c_uint8), ("mapq", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
+def aln_default_params():
+    p = AlnParams()
+    lib().orc_aln_default_params(C.byref(p))
+    return p
+
+
+def cigar_str(cg):
+    return "".join(f"{int(c) >> 4}{'MIDNS'[int(c) & 0xf]}" for c in cg)
+
+
+def nw(target: bytes, query: bytes, params=None):
+    p = params or aln_default_params()
+    cap = len(target) + len(query) + 4
+    cg = np.zeros(cap, dtype=np.uint32)
+    bt = np.zeros(max(1, len(target) * len(query)), dtype=np.uint8)
+    n = C.c_int(0)
+    sc = lib().orc_nw(target, len(target), query, len(query), C.byref(p), cg.ctypes.data_as(C.c_void_p), cap, C.byref(n), bt.ctypes.data_as(C.c_void_p))
+    return sc, cg[: n.value].copy()
+
+
+def align_contig(contig: bytes, ref: bytes, params=None):
+    """-> None or dict(ref_start, ref_end, rev, mapq, cigar=[(op,len)] in BAM op codes 0 M 1 I 2 D 4 S)"""
+    p = params or aln_default_params()
+    cap = 1 << 16
+    cg = np.zeros(cap, dtype=np.uint32)
+    a = Aln()
+    rc = lib().orc_align_contig(contig, len(contig), ref, len(ref), C.byref(p), C.byref(a), cg.ctypes.data_as(C.c_void_p), cap)
+    if rc <= 0:
+        return None
+    return {"ref_start": a.ref_start, "ref_end": a.ref_end, "rev": int(a.rev), "mapq": int(a.mapq), "q_start": a.q_start, "q_end": a.q_end,
+            "cigar": [(int(c) & 0xf, int(c) >> 4) for c in cg[: a.n_cigar]], "raw": cg[: a.n_cigar].copy()}
