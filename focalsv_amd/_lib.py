@@ -42,6 +42,26 @@ class AsmStats(C.Structure):
                [(n, C.c_double) for n in ("ms_sketch", "ms_chain", "ms_verify", "ms_path", "ms_consensus", "ms_final", "ms_total")]
 
 
+class AlnParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "min_anchors", "lookback", "max_gap", "a", "b", "q", "e", "q2", "e2", "pad",
+                                         "max_mm_run", "xdrop", "max_cells")]
+
+
+class Alns(C.Structure):
+    _fields_ = [("rec", C.c_void_p), ("rec_cap", C.c_uint32), ("n_rec", C.c_uint32), ("cigar", C.c_void_p), ("cigar_cap", C.c_uint64),
+                ("n_cigar", C.c_uint64), ("contig_status", C.c_void_p)]
+
+
+class AlnStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_pairs", "n_events", "dp_cells", "algo_bytes")] + \
+               [(n, C.c_double) for n in ("ms_seed", "ms_chain", "ms_events", "ms_dp", "ms_total")]
+
+
+ALN_REC_DTYPE = np.dtype([("ref_start", "<i4"), ("ref_end", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"), ("n_cigar", "<u4"),
+                          ("n_chain", "<u4"), ("cigar_off", "<u8"), ("contig", "<u4"), ("rev", "u1"), ("mapq", "u1"), ("pad", "u1", (2,))])
+assert ALN_REC_DTYPE.itemsize == 40
+
+
 class FsvError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -84,6 +104,11 @@ def load():
         "fsv_assemble_batch": (C.c_int, [vp, C.POINTER(ReadSets), C.POINTER(AsmParams), C.POINTER(Contigs)]),
         "fsv_asm_last_stats": (C.c_int, [vp, C.POINTER(AsmStats)]),
         "fsv_asm_fetch_reads": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint32]),
+        "fsv_aln_default_params": (None, [C.POINTER(AlnParams)]),
+        "fsv_align_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.POINTER(AlnParams), C.POINTER(Alns)]),
+        "fsv_aln_last_stats": (C.c_int, [vp, C.POINTER(AlnStats)]),
+        "fsv_nw": (C.c_int, [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnParams), C.POINTER(C.c_int32), vp, C.c_uint32,
+                             C.POINTER(C.c_uint32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -218,3 +243,43 @@ class Context:
         off = np.zeros(n_reads + 1, dtype=np.uint64)
         self.check(self._lib.fsv_asm_fetch_reads(self._h, _ptr(seq), total_cap, _ptr(off), n_reads), "fsv_asm_fetch_reads")
         return [seq[int(off[i]):int(off[i + 1])].tobytes() for i in range(n_reads)]
+
+    # aligner boundary ---------------------------------------------------------------
+    def default_aln_params(self):
+        p = AlnParams()
+        self._lib.fsv_aln_default_params(C.byref(p))
+        return p
+
+    def align_batch(self, contigs, contig_ref, refs, params=None):
+        """fsv_align_batch.  contigs / refs: lists of bytes; contig_ref[i] = index of the window contig i belongs to.
+        -> (records ndarray[ALN_REC_DTYPE], cigar ndarray[uint32], contig_status ndarray[int32])"""
+        n = len(contigs)
+        coff = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(c) for c in contigs], out=coff[1:])
+        roff = np.zeros(len(refs) + 1, dtype=np.uint64)
+        np.cumsum([len(r) for r in refs], out=roff[1:])
+        cseq = np.frombuffer(b"".join(contigs) + b"\0", dtype=np.uint8)
+        rseq = np.frombuffer(b"".join(refs) + b"\0", dtype=np.uint8)
+        cref = np.ascontiguousarray(contig_ref, dtype=np.uint32)
+        rec = np.zeros(max(1, n), dtype=ALN_REC_DTYPE)
+        cap = int(coff[-1]) // 8 + 4096 * max(1, n)
+        cigar = np.zeros(cap, dtype=np.uint32)
+        status = np.zeros(max(1, n), dtype=np.int32)
+        out = Alns(_ptr(rec).value, len(rec), 0, _ptr(cigar).value, cap, 0, _ptr(status).value)
+        p = params if params is not None else self.default_aln_params()
+        self.check(self._lib.fsv_align_batch(self._h, _ptr(cseq), _ptr(coff), n, _ptr(cref), _ptr(rseq), _ptr(roff), len(refs), C.byref(p),
+                                             C.byref(out)), "fsv_align_batch")
+        return rec[: out.n_rec].copy(), cigar[: out.n_cigar].copy(), status[:n].copy()
+
+    def aln_stats(self):
+        st = AlnStats()
+        self.check(self._lib.fsv_aln_last_stats(self._h, C.byref(st)), "fsv_aln_last_stats")
+        return {n: getattr(st, n) for n, _ in AlnStats._fields_}
+
+    def nw(self, target: bytes, query: bytes, params=None):
+        p = params if params is not None else self.default_aln_params()
+        cap = len(target) + len(query) + 4
+        cg = np.zeros(cap, dtype=np.uint32)
+        sc, n = C.c_int32(0), C.c_uint32(0)
+        self.check(self._lib.fsv_nw(self._h, target, len(target), query, len(query), C.byref(p), C.byref(sc), _ptr(cg), cap, C.byref(n)), "fsv_nw")
+        return sc.value, cg[: n.value].copy()

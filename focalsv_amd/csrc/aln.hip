@@ -1,0 +1,593 @@
+// aln.hip -- contig-vs-reference-window alignment (fsv_align_batch) for gfx950.
+//
+// Replaces `minimap2 -a -x asm5 --cs -r2k` + pysam read-back (focalsv/4_sv_calling/Dippav/DipPAV_variant_call.py:103-112;
+// extract_contig_signature_CCS.py:14-47, 342-432).  Restated in oracle/aln.c, which this file must match bit for bit.
+//   k_sketch / k_uniq   seeds (ha_sketch without HPC, k = 19)           sketch.cpp:39-137
+//   k_chain_aln         co-linear chain, one wavefront per pair, all state in LDS
+//   k_aln_events        gap-free runs vs DP events, padding, X-drop end extension
+//   k_nw                dual-affine global DP of one event on anti-diagonals (one workgroup per event), the
+//                       recurrence / tie rules / backtrack of the in-tree ksw2 (ksw2_extz2_sse.c:171-196, ksw2.h:115-150)
+#include "asm_kernels.h"
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+#define ALN_AMAX 8192
+#define ALN_EV_CAP 2048      // events per pair
+#define ALN_CG_CAP 1024      // CIGAR runs per event
+#define NW_LDS_Q 2048        // query length up to which the rolling DP rows live in LDS
+#define NW_NEG (-(1 << 29))
+
+struct AlnHeader { int32_t qbeg, tbeg, qend, tend, n_events, n_chain, rev, status; };
+struct AlnEvent { int32_t qs, qe, ts, te; };   // inclusive
+struct NwTask { uint32_t pair; int32_t qs, ql, ts, tl; uint32_t cg_off; uint64_t bt_off; uint64_t row_off; };
+
+__device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
+
+// ------------------------------------------------------------------------------------------------ chain
+__global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ word_off, const int32_t *__restrict__ read_len,
+                                                  const fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off,
+                                                  const uint32_t *__restrict__ mz_cnt, uint64_t *__restrict__ chain_out,
+                                                  AlnHeader *__restrict__ hdr, fsv_aln_params P)
+{
+    __shared__ uint64_t s_key[ALN_AMAX];
+    __shared__ int32_t s_f[ALN_AMAX];
+    __shared__ uint16_t s_aux[ALN_AMAX];
+    const int lane = threadIdx.x;
+    const uint32_t p = blockIdx.x, rq = 2 * p, rt = 2 * p + 1;
+    const int lenq = read_len[rq];
+    const fsv_mz *mq = mz + mz_off[rq], *mt = mz + mz_off[rt];
+    const int nq = (int)mz_cnt[rq], nt = (int)mz_cnt[rt];
+    AlnHeader h; h.qbeg = h.tbeg = h.qend = h.tend = 0; h.n_events = 0; h.n_chain = 0; h.rev = 0; h.status = 1;
+    int n = 0, nrev = 0, nfwd = 0;
+    for (int base = 0; base < nq; base += 64) {
+        int i = base + lane;
+        bool hit = false; uint64_t key = 0; uint16_t aux = 0;
+        if (i < nq) {
+            fsv_mz a = mq[i];
+            int l2 = 0, h2 = nt;
+            while (l2 < h2) { int mid = (l2 + h2) >> 1; if (mt[mid].hash < a.hash) l2 = mid + 1; else h2 = mid; }
+            if (l2 < nt) { fsv_mz b = mt[l2]; if (b.hash == a.hash) { hit = true; key = (uint64_t)a.pos << 32 | b.pos; aux = (uint16_t)(a.span | ((a.rev ^ b.rev) << 8)); } }
+        }
+        uint64_t m = __ballot(hit);
+        int at = n + __popcll(m & ((1ull << lane) - 1));
+        if (hit && at < ALN_AMAX) { s_key[at] = key; s_aux[at] = aux; }
+        nrev += __popcll(__ballot(hit && (aux >> 8)));
+        nfwd += __popcll(__ballot(hit && !(aux >> 8)));
+        n += __popcll(m);
+    }
+    if (n > ALN_AMAX) n = ALN_AMAX;
+    __syncthreads();
+    const int rev = nrev > nfwd;
+    h.rev = rev;
+    int m2 = 0;
+    for (int base = 0; base < n; base += 64) {
+        int i = base + lane;
+        bool keep = false; uint64_t key = 0;
+        if (i < n) {
+            uint16_t aux = s_aux[i];
+            key = s_key[i];
+            if ((aux >> 8) == rev) {
+                keep = true;
+                if (rev) { int qp = (int)(key >> 32), span = aux & 0xff; qp = (lenq - 1) - (qp - span + 1); key = (uint64_t)(uint32_t)qp << 32 | (uint32_t)key; }
+            }
+        }
+        uint64_t m = __ballot(keep);
+        int at = m2 + __popcll(m & ((1ull << lane) - 1));
+        __syncthreads();
+        if (keep) s_key[at] = key;
+        m2 += __popcll(m);
+        __syncthreads();
+    }
+    n = m2;
+    if (n < P.min_anchors) { if (lane == 0) hdr[p] = h; return; }
+    int np = 1;
+    while (np < n) np <<= 1;
+    for (int i = n + lane; i < np; i += 64) s_key[i] = ~0ull;
+    __syncthreads();
+    for (int sz = 2; sz <= np; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = lane; i < np; i += 64) {
+                int j = i ^ st;
+                if (j > i) { bool up = (i & sz) == 0; uint64_t a = s_key[i], b = s_key[j]; if ((a > b) == up) { s_key[i] = b; s_key[j] = a; } }
+            }
+            __syncthreads();
+        }
+    for (int i = 0; i < n; i++) {
+        const uint64_t ki = s_key[i];
+        const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
+        const int j = i - 1 - lane;
+        int cand = -1; // -1 = no legal predecessor (a legal candidate is >= k - 200 + k > -1 ... kept distinct by `ok`)
+        bool ok = false;
+        if (j >= 0) {
+            const uint64_t kj = s_key[j];
+            const int dq = qe - (int)(kj >> 32), dt = te - (int)(uint32_t)kj;
+            if (dq > 0 && dt > 0) {
+                const int gap = dq > dt ? dq - dt : dt - dq;
+                if (gap <= P.max_gap) {
+                    int sc = min(min(dq, dt), P.k);
+                    if (gap) sc -= (gap >> 7) + (ilog2_u32((uint32_t)gap) >> 1) + 1;
+                    cand = sc + s_f[j];
+                    ok = true;
+                }
+            }
+        }
+        // scores can drop below zero here (gap penalty), so bias before packing; lanes without a legal predecessor sit out
+        const bool legal = ok;
+        const long long mine = legal ? ((long long)(cand + (1 << 20)) * 64 + (63 - lane)) : -1;
+        const long long bestp = wave_max_i64(mine);
+        const int bests = bestp < 0 ? -(1 << 30) : (int)(bestp >> 6) - (1 << 20);
+        if (bests > P.k) { if (mine == bestp) { s_f[i] = bests; s_aux[i] = (uint16_t)j; } }
+        else if (lane == 0) { s_f[i] = P.k; s_aux[i] = 0xffff; }
+        __syncthreads();
+    }
+    long long bk = -1;
+    for (int i = lane; i < n; i += 64) { long long v = (long long)s_f[i] * 16384 + (16383 - i); bk = v > bk ? v : bk; }
+    bk = wave_max_i64(bk);
+    const int best = 16383 - (int)(bk & 16383);
+    int cnt = 0;
+    if (lane == 0) { int c = best; while (c != 0xffff) { cnt++; c = s_aux[c]; } }
+    cnt = __shfl(cnt, 0, 64);
+    if (cnt < P.min_anchors) { if (lane == 0) hdr[p] = h; return; }
+    if (lane == 0) {
+        uint64_t *out = chain_out + (size_t)p * ALN_AMAX;
+        int c = best, k2 = cnt;
+        while (c != 0xffff) { out[--k2] = s_key[c]; c = s_aux[c]; }
+        h.n_chain = cnt; h.status = 0;
+        hdr[p] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ events
+// query base of the strand-oriented contig
+__device__ __forceinline__ uint32_t qbase(const uint32_t *__restrict__ store, uint32_t qw, int lenq, int rev, int p) { return fsv_base_at(store, qw, lenq, rev, p); }
+
+__global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                                    const int32_t *__restrict__ read_len, const uint64_t *__restrict__ chain,
+                                                    AlnHeader *__restrict__ hdr, AlnEvent *__restrict__ events, fsv_aln_params P)
+{
+    __shared__ uint8_t s_cls[ALN_AMAX];
+    const uint32_t p = blockIdx.x;
+    AlnHeader h = hdr[p];
+    if (h.status != 0) return;
+    const uint32_t qw = word_off[2 * p], tw = word_off[2 * p + 1];
+    const int lenq = read_len[2 * p], lent = read_len[2 * p + 1], rev = h.rev, nch = h.n_chain, nseg = nch - 1;
+    const uint64_t *c = chain + (size_t)p * ALN_AMAX;
+    // segment classes between consecutive anchors: 0 identical, 1 few mismatches ('M'), 2 needs DP
+    for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
+        const int q0 = (int)(c[s] >> 32), t0 = (int)(uint32_t)c[s], dq = (int)(c[s + 1] >> 32) - q0, dt = (int)(uint32_t)c[s + 1] - t0;
+        uint8_t cls = 2;
+        if (dq == dt) {
+            int mm = 0;
+            for (int k2 = 1; k2 <= dq && mm <= P.max_mm_run; k2++) mm += qbase(store, qw, lenq, rev, q0 + k2) != fsv_base_fwd(store, tw, t0 + k2);
+            cls = mm == 0 ? 0 : (mm <= P.max_mm_run ? 1 : 2);
+        }
+        s_cls[s] = cls;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+#define CQ(i) ((int)(c[i] >> 32))
+#define CT(i) ((int)(uint32_t)c[i])
+    const int qs0 = CQ(0) - P.k + 1, ts0 = CT(0) - P.k + 1;
+    int x = 0, best = 0, bi = 0;
+    for (int i = 1; qs0 - i >= 0 && ts0 - i >= 0; i++) {
+        x += qbase(store, qw, lenq, rev, qs0 - i) == fsv_base_fwd(store, tw, ts0 - i) ? P.a : -P.b;
+        if (x > best) { best = x; bi = i; }
+        if (best - x > P.xdrop) break;
+    }
+    const int qbeg = qs0 - bi, tbeg = ts0 - bi;
+    x = 0; best = 0; bi = 0;
+    for (int i = 1; CQ(nch - 1) + i < lenq && CT(nch - 1) + i < lent; i++) {
+        x += qbase(store, qw, lenq, rev, CQ(nch - 1) + i) == fsv_base_fwd(store, tw, CT(nch - 1) + i) ? P.a : -P.b;
+        if (x > best) { best = x; bi = i; }
+        if (best - x > P.xdrop) break;
+    }
+    const int qend = CQ(nch - 1) + bi, tend = CT(nch - 1) + bi;
+    AlnEvent *ev = events + (size_t)p * ALN_EV_CAP;
+    int ne = 0, mstart_q = qbeg, s = 0, status = 0;
+    while (s < nseg) {
+        if (s_cls[s] < 2) { s++; continue; }
+        int e = s;
+        while (e + 1 < nseg && s_cls[e + 1] == 2) e++;
+        int eqs = CQ(s) + 1, eqe = CQ(e + 1), ets = CT(s) + 1, ete = CT(e + 1);
+        int lp = 0, rp = 0;
+        int lim_l = min(eqs - mstart_q, P.pad);
+        while (lp < lim_l && qbase(store, qw, lenq, rev, eqs - 1 - lp) == fsv_base_fwd(store, tw, ets - 1 - lp)) lp++;
+        int lim_r = P.pad;
+        if (eqe + lim_r > qend) lim_r = qend - eqe;
+        if (ete + lim_r > tend) lim_r = tend - ete;
+        { int nx = e + 1; while (nx < nseg && s_cls[nx] < 2) nx++; if (nx < nseg && eqe + lim_r > CQ(nx)) lim_r = CQ(nx) - eqe; }
+        while (rp < lim_r && qbase(store, qw, lenq, rev, eqe + 1 + rp) == fsv_base_fwd(store, tw, ete + 1 + rp)) rp++;
+        eqs -= lp; ets -= lp; eqe += rp; ete += rp;
+        if (ne >= ALN_EV_CAP) { status = FSV_ECAP; break; }
+        if ((long long)(eqe - eqs + 1) * (ete - ets + 1) > P.max_cells) { status = FSV_EUNSUP; break; }
+        ev[ne].qs = eqs; ev[ne].qe = eqe; ev[ne].ts = ets; ev[ne].te = ete; ne++;
+        mstart_q = eqe + 1;
+        s = e + 1;
+    }
+#undef CQ
+#undef CT
+    h.qbeg = qbeg; h.tbeg = tbeg; h.qend = qend; h.tend = tend; h.n_events = ne; h.status = status;
+    hdr[p] = h;
+}
+
+// ------------------------------------------------------------------------------------------------ NW
+// One workgroup per event, cells of one anti-diagonal in parallel.  Rolling rows indexed by the query position:
+//   H on diagonals d-1 and d-2, and the E/F/E2/F2 values *leaving* each cell of diagonal d-1.
+// Per cell one traceback byte with ksw2's layout (ksw2.h:115-118).
+__global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                            const int32_t *__restrict__ read_len, const AlnHeader *__restrict__ hdr,
+                                            const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all, int32_t *__restrict__ rows_all,
+                                            uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
+{
+    __shared__ int32_t s_rows[11 * NW_LDS_Q];
+    const NwTask T = tasks[blockIdx.x];
+    const uint32_t qw = word_off[2 * T.pair], tw = word_off[2 * T.pair + 1];
+    const int lenq = read_len[2 * T.pair], rev = hdr[T.pair].rev;
+    const int ql = T.ql, tl = T.tl;
+    const bool two = P.q2 >= 0;
+    int32_t *rows = ql <= NW_LDS_Q ? s_rows : rows_all + T.row_off;
+    const int stride = ql <= NW_LDS_Q ? NW_LDS_Q : ql;
+    uint8_t *bt = bt_all + T.bt_off;
+    // rows: H[3], Eo[2], Fo[2], E2o[2], F2o[2]
+#define HROW(d) (rows + (size_t)(((d) % 3 + 3) % 3) * stride)
+#define EROW(d) (rows + (size_t)(3 + ((d) & 1)) * stride)
+#define FROW(d) (rows + (size_t)(5 + ((d) & 1)) * stride)
+#define E2ROW(d) (rows + (size_t)(7 + ((d) & 1)) * stride)
+#define F2ROW(d) (rows + (size_t)(9 + ((d) & 1)) * stride)
+    for (int d = 0; d <= ql + tl - 2; d++) {
+        const int jlo = max(0, d - (tl - 1)), jhi = min(ql - 1, d);
+        int32_t *Hc = HROW(d), *H1 = HROW(d - 1), *H2 = HROW(d - 2);
+        for (int j = jlo + (int)threadIdx.x; j <= jhi; j += blockDim.x) {
+            const int i = d - j;
+            // boundary values (ksw2: a gap of length l before the first cell costs min(q + e*l, q2 + e2*l))
+            int32_t hdiag, a, b, a2 = NW_NEG, b2 = NW_NEG;
+            if (i == 0 && j == 0) hdiag = 0;
+            else if (i == 0) { int g1 = -(P.q + P.e * j), g2 = two ? -(P.q2 + P.e2 * j) : NW_NEG; hdiag = max(g1, g2); }
+            else if (j == 0) { int g1 = -(P.q + P.e * i), g2 = two ? -(P.q2 + P.e2 * i) : NW_NEG; hdiag = max(g1, g2); }
+            else hdiag = H2[j - 1];
+            if (i == 0) {
+                int g1 = -(P.q + P.e * (j + 1)), g2 = two ? -(P.q2 + P.e2 * (j + 1)) : NW_NEG;
+                const int hup = max(g1, g2); // H(-1, j)
+                a = hup - P.q - P.e; if (two) a2 = hup - P.q2 - P.e2;
+            } else { a = EROW(d - 1)[j]; if (two) a2 = E2ROW(d - 1)[j]; }
+            if (j == 0) {
+                int g1 = -(P.q + P.e * (i + 1)), g2 = two ? -(P.q2 + P.e2 * (i + 1)) : NW_NEG;
+                const int hleft = max(g1, g2); // H(i, -1)
+                b = hleft - P.q - P.e; if (two) b2 = hleft - P.q2 - P.e2;
+            } else { b = FROW(d - 1)[j - 1]; if (two) b2 = F2ROW(d - 1)[j - 1]; }
+            const uint32_t tb = fsv_base_fwd(store, tw, T.ts + i), qb = qbase(store, qw, lenq, rev, T.qs + j);
+            int32_t h = hdiag + (tb == qb ? P.a : -P.b);
+            uint8_t dd = 0;
+            if (a > h) { h = a; dd = 1; }
+            if (b > h) { h = b; dd = 2; }
+            if (two && a2 > h) { h = a2; dd = 3; }
+            if (two && b2 > h) { h = b2; dd = 4; }
+            int32_t o = h - P.q;
+            if (a > o) { dd |= 0x08; EROW(d)[j] = a - P.e; } else EROW(d)[j] = o - P.e;
+            if (b > o) { dd |= 0x10; FROW(d)[j] = b - P.e; } else FROW(d)[j] = o - P.e;
+            if (two) {
+                o = h - P.q2;
+                if (a2 > o) { dd |= 0x20; E2ROW(d)[j] = a2 - P.e2; } else E2ROW(d)[j] = o - P.e2;
+                if (b2 > o) { dd |= 0x40; F2ROW(d)[j] = b2 - P.e2; } else F2ROW(d)[j] = o - P.e2;
+            }
+            Hc[j] = h;
+            bt[(size_t)i * ql + j] = dd;
+        }
+        __syncthreads();
+        (void)H1;
+    }
+    if (threadIdx.x != 0) return;
+    scores[blockIdx.x] = HROW(ql + tl - 2)[ql - 1];
+    // ksw_backtrack, emitted end-to-start then reversed in place
+    uint32_t *cg = cg_all + T.cg_off;
+    int n = 0, i = tl - 1, j = ql - 1, state = 0;
+    bool over = false;
+    auto put = [&](uint32_t op, uint32_t len) {
+        if (n && (cg[n - 1] & 0xf) == op) cg[n - 1] += len << 4;
+        else if (n < ALN_CG_CAP) cg[n++] = len << 4 | op;
+        else over = true;
+    };
+    while (i >= 0 && j >= 0) {
+        const uint8_t dd = bt[(size_t)i * ql + j];
+        if (state == 0) state = dd & 7;
+        else if (!((dd >> (state + 2)) & 1)) state = 0;
+        if (state == 0) state = dd & 7;
+        if (state == 0) { put(0, 1); i--; j--; }
+        else if (state == 1 || state == 3) { put(2, 1); i--; }
+        else { put(1, 1); j--; }
+    }
+    if (i >= 0) put(2, (uint32_t)(i + 1));
+    if (j >= 0) put(1, (uint32_t)(j + 1));
+    for (int k2 = 0; k2 < n / 2; k2++) { uint32_t t = cg[k2]; cg[k2] = cg[n - 1 - k2]; cg[n - 1 - k2] = t; }
+    cg_n[blockIdx.x] = over ? 0xffffffffu : (uint32_t)n;
+#undef HROW
+#undef EROW
+#undef FROW
+#undef E2ROW
+#undef F2ROW
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct DevBuf { void *p = nullptr; size_t cap = 0; };
+
+struct AlnWs {
+    DevBuf store, word_off, len, wper, mz, mz_off, mz_cnt, warn, chain, hdr, events, tasks, bt, rows, cg, cg_n, scores;
+    fsv_aln_stats stats;
+    std::vector<DevBuf *> all() { return {&store, &word_off, &len, &wper, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
+};
+
+void aln_ws_free(fsv_ctx *ctx)
+{
+    AlnWs *w = (AlnWs *)ctx->aln_ws;
+    if (!w) return;
+    for (DevBuf *b : w->all()) if (b->p) (void)hipFree(b->p);
+    delete w;
+    ctx->aln_ws = nullptr;
+}
+
+AlnWs *aln_ws_get(fsv_ctx *ctx)
+{
+    if (!ctx->aln_ws) { ctx->aln_ws = new AlnWs(); ctx->aln_ws_free = aln_ws_free; memset(&((AlnWs *)ctx->aln_ws)->stats, 0, sizeof(fsv_aln_stats)); }
+    return (AlnWs *)ctx->aln_ws;
+}
+
+int ensure(fsv_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return FSV_OK;
+    if (b.p) { FSV_HIP(ctx, hipStreamSynchronize(ctx->stream)); FSV_HIP(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    FSV_HIP(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return FSV_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_ != FSV_OK) return rc_; } while (0)
+template <class T> int upload(fsv_ctx *ctx, DevBuf &b, const std::vector<T> &v)
+{
+    TRY(ensure(ctx, b, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) FSV_HIP(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return FSV_OK;
+}
+struct Timer {
+    std::chrono::steady_clock::time_point t0; fsv_ctx *ctx;
+    explicit Timer(fsv_ctx *c) : ctx(c) { (void)hipStreamSynchronize(c->stream); t0 = std::chrono::steady_clock::now(); }
+    double stop() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// packs pairs (query, target) into a store; returns lens / offsets
+int pack_pairs(fsv_ctx *ctx, AlnWs &W, const std::vector<const char *> &seq, const std::vector<uint64_t> &slen, std::vector<uint32_t> &word_off,
+               std::vector<int32_t> &len)
+{
+    const uint32_t n = (uint32_t)seq.size();
+    std::vector<uint64_t> off(n + 1, 0);
+    for (uint32_t r = 0; r < n; r++) off[r + 1] = off[r] + slen[r];
+    std::vector<char> cat(off[n] + 1);
+    for (uint32_t r = 0; r < n; r++) memcpy(cat.data() + off[r], seq[r], slen[r]);
+    const size_t cap = fsv_pack_bound(off.data(), n);
+    if (cap >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "alignment batch too large; split it");
+    std::vector<uint32_t> words(cap);
+    std::vector<uint64_t> woff(n + 1);
+    TRY(fsv_pack_reads(cat.data(), off.data(), n, words.data(), cap, woff.data()));
+    word_off.resize(n + 1); len.resize(n);
+    for (uint32_t r = 0; r <= n; r++) word_off[r] = (uint32_t)woff[r];
+    for (uint32_t r = 0; r < n; r++) len[r] = (int32_t)slen[r];
+    TRY(upload(ctx, W.store, words));
+    TRY(upload(ctx, W.word_off, word_off));
+    TRY(upload(ctx, W.len, len));
+    return FSV_OK;
+}
+
+int run_nw(fsv_ctx *ctx, AlnWs &W, const std::vector<NwTask> &tasks, uint64_t bt_bytes, uint64_t row_words, const fsv_aln_params &P)
+{
+    TRY(upload(ctx, W.tasks, tasks));
+    TRY(ensure(ctx, W.bt, bt_bytes + 16));
+    TRY(ensure(ctx, W.rows, row_words * 4 + 16));
+    TRY(ensure(ctx, W.cg, tasks.size() * (size_t)ALN_CG_CAP * 4));
+    TRY(ensure(ctx, W.cg_n, tasks.size() * 4));
+    TRY(ensure(ctx, W.scores, tasks.size() * 4));
+    hipLaunchKernelGGL(k_nw, dim3((uint32_t)tasks.size()), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+                       (const int32_t *)W.len.p, (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (int32_t *)W.rows.p,
+                       (uint32_t *)W.cg.p, (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
+    FSV_HIP(ctx, hipGetLastError());
+    return FSV_OK;
+}
+
+void push_cg(std::vector<uint32_t> &cg, uint32_t op, uint32_t len)
+{
+    if (!len) return;
+    if (!cg.empty() && (cg.back() & 0xf) == op) cg.back() += len << 4;
+    else cg.push_back(len << 4 | op);
+}
+
+} // namespace
+
+extern "C" void fsv_aln_default_params(fsv_aln_params *P)
+{
+    if (!P) return;
+    P->k = 19; P->w = 19; P->min_anchors = 3; P->lookback = 64; P->max_gap = 20000;
+    P->a = 1; P->b = 19; P->q = 39; P->e = 3; P->q2 = 81; P->e2 = 1;
+    P->pad = 24; P->max_mm_run = 4; P->xdrop = 100; P->max_cells = 1 << 26;
+}
+
+extern "C" int fsv_aln_last_stats(const fsv_ctx *ctx, fsv_aln_stats *out)
+{
+    if (!ctx || !out || !ctx->aln_ws) return FSV_EINVAL;
+    *out = ((const AlnWs *)ctx->aln_ws)->stats;
+    return FSV_OK;
+}
+
+static int check_aln_params(fsv_ctx *ctx, const fsv_aln_params &P)
+{
+    if (P.k < 1 || P.k > 31 || P.w < 1 || P.w > 64 || P.lookback != 64 || P.min_anchors < 2 || P.pad < 0 || P.a < 0 || P.b < 0 || P.q < 0 || P.e < 0 || P.max_cells < 1)
+        return fsv_fail(ctx, FSV_EINVAL, "fsv_aln_params out of range");
+    return FSV_OK;
+}
+
+extern "C" int fsv_nw(fsv_ctx *ctx, const char *target, int32_t tl, const char *query, int32_t ql, const fsv_aln_params *params, int32_t *score,
+                      uint32_t *cigar, uint32_t cigar_cap, uint32_t *n_cigar)
+{
+    if (!ctx || !target || !query || tl < 1 || ql < 1 || !score || !cigar || !n_cigar) return FSV_EINVAL;
+    fsv_aln_params P;
+    if (params) P = *params; else fsv_aln_default_params(&P);
+    TRY(check_aln_params(ctx, P));
+    if ((int64_t)tl * ql > P.max_cells) return fsv_fail(ctx, FSV_EUNSUP, "event larger than max_cells");
+    FSV_HIP(ctx, hipSetDevice(ctx->device));
+    AlnWs &W = *aln_ws_get(ctx);
+    std::vector<uint32_t> word_off; std::vector<int32_t> len;
+    TRY(pack_pairs(ctx, W, {query, target}, {(uint64_t)ql, (uint64_t)tl}, word_off, len));
+    std::vector<AlnHeader> hdr(1); memset(&hdr[0], 0, sizeof(AlnHeader));
+    TRY(upload(ctx, W.hdr, hdr));
+    std::vector<NwTask> tasks(1);
+    tasks[0] = NwTask{0u, 0, ql, 0, tl, 0u, 0ull, 0ull};
+    TRY(run_nw(ctx, W, tasks, (uint64_t)tl * ql, ql > NW_LDS_Q ? 11ull * ql : 0, P));
+    uint32_t n = 0; int32_t sc = 0;
+    FSV_HIP(ctx, hipMemcpyAsync(&n, W.cg_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipMemcpyAsync(&sc, W.scores.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n == 0xffffffffu || n > cigar_cap) return FSV_ECAP;
+    FSV_HIP(ctx, hipMemcpyAsync(cigar, W.cg.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_cigar = n; *score = sc;
+    return FSV_OK;
+}
+
+extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint64_t *contig_off, uint32_t n_contigs, const uint32_t *contig_ref,
+                               const char *ref_seq, const uint64_t *ref_off, uint32_t n_refs, const fsv_aln_params *params, fsv_alns *out)
+{
+    if (!ctx || !out || !out->rec || !out->cigar || !out->contig_status) return FSV_EINVAL;
+    out->n_rec = 0; out->n_cigar = 0;
+    if (n_contigs == 0) return FSV_OK;
+    if (!contig_seq || !contig_off || !contig_ref || !ref_seq || !ref_off) return FSV_EINVAL;
+    if (out->rec_cap < n_contigs) return fsv_fail(ctx, FSV_ECAP, "rec_cap must be >= n_contigs");
+    fsv_aln_params P;
+    if (params) P = *params; else fsv_aln_default_params(&P);
+    TRY(check_aln_params(ctx, P));
+    FSV_HIP(ctx, hipSetDevice(ctx->device));
+    AlnWs &W = *aln_ws_get(ctx);
+    memset(&W.stats, 0, sizeof(W.stats));
+    Timer ttot(ctx);
+    const uint32_t np = n_contigs, nr = 2 * np;
+    std::vector<const char *> seq(nr); std::vector<uint64_t> slen(nr);
+    std::vector<uint8_t> wper(nr);
+    std::vector<int32_t> pre_status(np, 0);
+    for (uint32_t p = 0; p < np; p++) {
+        if (contig_ref[p] >= n_refs) return fsv_fail(ctx, FSV_EINVAL, "contig_ref out of range");
+        seq[2 * p] = contig_seq + contig_off[p]; slen[2 * p] = contig_off[p + 1] - contig_off[p];
+        seq[2 * p + 1] = ref_seq + ref_off[contig_ref[p]]; slen[2 * p + 1] = ref_off[contig_ref[p] + 1] - ref_off[contig_ref[p]];
+        const uint64_t L = std::max(slen[2 * p], slen[2 * p + 1]);
+        uint64_t w = std::max<uint64_t>((uint64_t)P.w, L / 3000 + 1);
+        if (w > 64 || slen[2 * p] < (uint64_t)P.k || slen[2 * p + 1] < (uint64_t)P.k || L >= (1u << 24)) { pre_status[p] = w > 64 || L >= (1u << 24) ? FSV_EUNSUP : 1; w = 64; }
+        wper[2 * p] = wper[2 * p + 1] = (uint8_t)w;
+        if (slen[2 * p] == 0 || slen[2 * p + 1] == 0) return fsv_fail(ctx, FSV_EINVAL, "empty contig or reference window");
+    }
+    Timer tseed(ctx);
+    std::vector<uint32_t> word_off; std::vector<int32_t> len;
+    TRY(pack_pairs(ctx, W, seq, slen, word_off, len));
+    TRY(upload(ctx, W.wper, wper));
+    std::vector<uint32_t> mz_off(nr + 1, 0);
+    uint64_t m = 0;
+    for (uint32_t r = 0; r < nr; r++) { mz_off[r] = (uint32_t)m; m += (uint64_t)len[r] / 8 + 64; }
+    if (m >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "alignment batch too large; split it");
+    mz_off[nr] = (uint32_t)m;
+    TRY(upload(ctx, W.mz_off, mz_off));
+    TRY(ensure(ctx, W.mz, m * sizeof(fsv_mz)));
+    TRY(ensure(ctx, W.mz_cnt, (size_t)nr * 4));
+    TRY(ensure(ctx, W.warn, (size_t)nr * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)nr * 4, ctx->stream));
+    hipLaunchKernelGGL(k_sketch, dim3(fsv_grid_for(nr, 64)), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+                       (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, nr, P.w, P.k, 0,
+                       (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p);
+    FSV_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_uniq<ALN_AMAX>, dim3(nr), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (uint32_t *)W.mz_cnt.p,
+                       (uint32_t *)W.warn.p);
+    FSV_HIP(ctx, hipGetLastError());
+    W.stats.ms_seed = tseed.stop();
+    Timer tchain(ctx);
+    TRY(ensure(ctx, W.chain, (size_t)np * ALN_AMAX * 8));
+    TRY(ensure(ctx, W.hdr, (size_t)np * sizeof(AlnHeader)));
+    TRY(ensure(ctx, W.events, (size_t)np * ALN_EV_CAP * sizeof(AlnEvent)));
+    hipLaunchKernelGGL(k_chain_aln, dim3(np), dim3(64), 0, ctx->stream, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
+                       (const fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (const uint32_t *)W.mz_cnt.p, (uint64_t *)W.chain.p, (AlnHeader *)W.hdr.p, P);
+    FSV_HIP(ctx, hipGetLastError());
+    W.stats.ms_chain = tchain.stop();
+    Timer tev(ctx);
+    hipLaunchKernelGGL(k_aln_events, dim3(np), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+                       (const int32_t *)W.len.p, (const uint64_t *)W.chain.p, (AlnHeader *)W.hdr.p, (AlnEvent *)W.events.p, P);
+    FSV_HIP(ctx, hipGetLastError());
+    std::vector<AlnHeader> hdr(np);
+    std::vector<AlnEvent> events((size_t)np * ALN_EV_CAP);
+    FSV_HIP(ctx, hipMemcpyAsync(hdr.data(), W.hdr.p, (size_t)np * sizeof(AlnHeader), hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t p = 0; p < np; p++)
+        if (hdr[p].status == 0 && hdr[p].n_events > 0)
+            FSV_HIP(ctx, hipMemcpyAsync(events.data() + (size_t)p * ALN_EV_CAP, (const AlnEvent *)W.events.p + (size_t)p * ALN_EV_CAP,
+                                        (size_t)hdr[p].n_events * sizeof(AlnEvent), hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    W.stats.ms_events = tev.stop();
+    // DP tasks
+    Timer tdp(ctx);
+    std::vector<NwTask> tasks;
+    std::vector<uint32_t> first_task(np + 1, 0);
+    uint64_t bt = 0, rows = 0;
+    for (uint32_t p = 0; p < np; p++) {
+        first_task[p] = (uint32_t)tasks.size();
+        if (pre_status[p] != 0 || hdr[p].status != 0) continue;
+        for (int e = 0; e < hdr[p].n_events; e++) {
+            const AlnEvent &ev = events[(size_t)p * ALN_EV_CAP + e];
+            NwTask t;
+            t.pair = p; t.qs = ev.qs; t.ql = ev.qe - ev.qs + 1; t.ts = ev.ts; t.tl = ev.te - ev.ts + 1;
+            t.cg_off = (uint32_t)(tasks.size() * ALN_CG_CAP); t.bt_off = bt; t.row_off = rows;
+            bt += (uint64_t)t.ql * t.tl;
+            if (t.ql > NW_LDS_Q) rows += 11ull * t.ql;
+            W.stats.dp_cells += (uint64_t)t.ql * t.tl;
+            W.stats.algo_bytes += (uint64_t)(t.ql + t.tl + 3) / 4;
+            tasks.push_back(t);
+        }
+    }
+    first_task[np] = (uint32_t)tasks.size();
+    std::vector<uint32_t> cg_n(tasks.size()), cg(tasks.size() * (size_t)ALN_CG_CAP);
+    if (!tasks.empty()) {
+        if (tasks.size() * (uint64_t)ALN_CG_CAP >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "too many DP events in one batch");
+        TRY(run_nw(ctx, W, tasks, bt, rows, P));
+        FSV_HIP(ctx, hipMemcpyAsync(cg_n.data(), W.cg_n.p, tasks.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipMemcpyAsync(cg.data(), W.cg.p, cg.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    W.stats.ms_dp = tdp.stop();
+    W.stats.n_pairs = np; W.stats.n_events = tasks.size();
+    // stitch: S, M runs, events, S
+    for (uint32_t p = 0; p < np; p++) {
+        W.stats.algo_bytes += (uint64_t)(len[2 * p] + len[2 * p + 1] + 3) / 4;
+        int32_t st = pre_status[p] != 0 ? pre_status[p] : hdr[p].status;
+        if (st == 0) {
+            std::vector<uint32_t> c;
+            const AlnHeader &h = hdr[p];
+            push_cg(c, 4, (uint32_t)h.qbeg);
+            int mstart = h.qbeg;
+            for (uint32_t t = first_task[p]; t < first_task[p + 1] && st == 0; t++) {
+                const NwTask &T = tasks[t];
+                push_cg(c, 0, (uint32_t)(T.qs - mstart));
+                if (cg_n[t] == 0xffffffffu) { st = FSV_ECAP; break; }
+                for (uint32_t i = 0; i < cg_n[t]; i++) { uint32_t v = cg[(size_t)t * ALN_CG_CAP + i]; push_cg(c, v & 0xf, v >> 4); }
+                mstart = T.qs + T.ql;
+            }
+            if (st == 0) {
+                push_cg(c, 0, (uint32_t)(h.qend + 1 - mstart));
+                push_cg(c, 4, (uint32_t)(len[2 * p] - 1 - h.qend));
+                if (out->n_cigar + c.size() > out->cigar_cap) return fsv_fail(ctx, FSV_ECAP, "cigar buffer too small");
+                fsv_aln_rec &r = out->rec[out->n_rec++];
+                r.ref_start = h.tbeg; r.ref_end = h.tend + 1; r.q_start = h.qbeg; r.q_end = h.qend + 1; r.n_cigar = (uint32_t)c.size();
+                r.n_chain = (uint32_t)h.n_chain; r.cigar_off = out->n_cigar; r.contig = p; r.rev = (uint8_t)h.rev; r.mapq = 60; r.pad[0] = r.pad[1] = 0;
+                memcpy(out->cigar + out->n_cigar, c.data(), c.size() * 4);
+                out->n_cigar += c.size();
+                W.stats.algo_bytes += c.size() * 4;
+            }
+        }
+        out->contig_status[p] = st;
+    }
+    W.stats.ms_total = ttot.stop();
+    return FSV_OK;
+}

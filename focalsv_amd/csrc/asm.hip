@@ -128,9 +128,9 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, 64, ctx->stream));
     hipLaunchKernelGGL(k_sketch, dim3(fsv_grid_for(B.n_reads, 64)), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
                        (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
-                       P.hpc, (uint32_t *)W.warn.p);
+                       P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr);
     FSV_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_uniq, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
+    hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
                        (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p);
     FSV_HIP(ctx, hipGetLastError());
     W.stats.ms_sketch += ts.stop();

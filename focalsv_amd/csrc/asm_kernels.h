@@ -31,9 +31,7 @@ struct fsv_wpath {           // 128 bytes per window task
 };
 static_assert(sizeof(fsv_wpath) == 128, "fsv_wpath layout");
 
-struct AsmDims {
-    uint32_t n_reads, n_sets, n_pairs;
-};
+namespace { // every translation unit that includes this header gets its own copy of the kernels
 
 // ------------------------------------------------------------------------------------------------ k_sketch
 __device__ __forceinline__ uint64_t mix64(uint64_t key)
@@ -53,7 +51,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t key)
 __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                                const int32_t *__restrict__ read_len, const uint32_t *__restrict__ mz_off,
                                                fsv_mz *__restrict__ mz, uint32_t *__restrict__ mz_cnt, uint32_t n_reads, int w, int k,
-                                               int hpc, uint32_t *__restrict__ warn)
+                                               int hpc, uint32_t *__restrict__ warn, const uint8_t *__restrict__ w_per_read)
 {
     __shared__ uint64_t r_hash[64][64];
     __shared__ uint32_t r_meta[64][64]; // pos << 1 | rev
@@ -66,6 +64,7 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
     const int len = read_len[r];
     const uint32_t cap = mz_off[r + 1] - mz_off[r];
     fsv_mz *out = mz + mz_off[r];
+    if (w_per_read) w = w_per_read[r];
     const uint64_t NONE = ~0ull;
     const uint64_t mask = (1ull << k) - 1;
     uint64_t km0 = 0, km1 = 0, km2 = 0, km3 = 0;
@@ -135,17 +134,18 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
 
 // ------------------------------------------------------------------------------------------------ k_uniq
 // One workgroup per read: bitonic sort of (hash, pos) in LDS, keep hashes that occur exactly once.
+template <int UQ_MAX>
 __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
                                               uint32_t *__restrict__ warn)
 {
-    __shared__ uint64_t s_hash[FSV_UQ_MAX];
-    __shared__ uint64_t s_pay[FSV_UQ_MAX]; // pos | rev << 32 | span << 40
+    __shared__ uint64_t s_hash[UQ_MAX];
+    __shared__ uint64_t s_pay[UQ_MAX]; // pos | rev << 32 | span << 40
     __shared__ uint32_t s_scan[256];
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
     fsv_mz *a = mz + mz_off[r];
     uint32_t n = mz_cnt[r];
-    if (n > FSV_UQ_MAX) { if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = FSV_UQ_MAX; }
+    if (n > UQ_MAX) { if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = UQ_MAX; }
     uint32_t np = 1;
     while (np < n) np <<= 1;
     for (uint32_t i = tid; i < np; i += 256) {
@@ -830,3 +830,5 @@ __global__ void k_unpack_reads(const uint32_t *__restrict__ store, const uint32_
     const int len = read_len[r];
     for (int i = threadIdx.x; i < len; i += blockDim.x) out[dst_off[r] + i] = "ACGT"[fsv_base_fwd(store, w, i)];
 }
+
+} // namespace

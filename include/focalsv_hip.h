@@ -197,6 +197,59 @@ int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out);
  * can be fetched as ASCII (same order as the input reads). */
 int fsv_asm_fetch_reads(fsv_ctx *ctx, char *seq, uint64_t seq_cap, uint64_t *off, uint32_t n_reads);
 
+/* ---- aligner boundary ---------------------------------------------------------
+ * Replaces `minimap2 -a -x asm5 --cs -r2k ref_chr.fa assemblies.fa | samtools sort` and the pysam read-back
+ * (focalsv/4_sv_calling/Dippav/DipPAV_variant_call.py:103-112; fields consumed by
+ * extract_contig_signature_CCS.py:14-47, 279-282, 347-356: reference_name, pos, reference_end, cigar with
+ * ops {0 M, 1 I, 2 D, 4 S, 5 H}, qname, is_reverse, mapq).  Every contig is aligned against the reference
+ * window of its own region (the caller adds the window's chromosome offset to ref_start/ref_end).
+ * minimap2 itself is not part of the reference tree; scoring is its published asm5 preset and the DP
+ * follows the in-tree ksw2 (software/hifiasm-0.14/ksw2_extz2_sse.c, ksw2.h:115-150).
+ */
+typedef struct fsv_aln_params {
+    int32_t k, w;               /* seeds: 19, 19; w grows with the sequence length (len/3000 + 1) */
+    int32_t min_anchors, lookback, max_gap;  /* 3, 64, 20000 */
+    int32_t a, b, q, e, q2, e2; /* asm5: 1, 19, 39, 3, 81, 1 */
+    int32_t pad;                /* identical bases added on each side of a DP event, 24 */
+    int32_t max_mm_run;         /* equal-length inter-seed run with <= this many mismatches stays M, 4 */
+    int32_t xdrop;              /* gap-free end extension, 100 */
+    int32_t max_cells;          /* largest DP event, 2^26 cells */
+} fsv_aln_params;
+void fsv_aln_default_params(fsv_aln_params *p);
+
+typedef struct fsv_aln_rec {
+    int32_t  ref_start, ref_end;  /* 0-based in the window, end exclusive (pysam pos / reference_end) */
+    int32_t  q_start, q_end;      /* aligned part of the strand-oriented contig */
+    uint32_t n_cigar;
+    uint32_t n_chain;
+    uint64_t cigar_off;           /* into fsv_alns.cigar */
+    uint32_t contig;              /* index of the contig */
+    uint8_t  rev, mapq, pad[2];
+} fsv_aln_rec;                    /* 40 bytes */
+
+typedef struct fsv_alns {
+    fsv_aln_rec *rec;       /* host, capacity rec_cap (>= n_contigs) */
+    uint32_t  rec_cap, n_rec;
+    uint32_t *cigar;        /* host, BAM encoding len << 4 | op */
+    uint64_t  cigar_cap, n_cigar;
+    int32_t  *contig_status; /* host, n_contigs: 0 aligned, 1 no chain (unaligned), <0 FSV_E* for that contig */
+} fsv_alns;
+
+/* contig i is aligned to reference window contig_ref[i] */
+int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint64_t *contig_off, uint32_t n_contigs,
+                    const uint32_t *contig_ref, const char *ref_seq, const uint64_t *ref_off, uint32_t n_refs,
+                    const fsv_aln_params *params, fsv_alns *out);
+
+typedef struct fsv_aln_stats {
+    uint64_t n_pairs, n_events, dp_cells, algo_bytes;
+    double ms_seed, ms_chain, ms_events, ms_dp, ms_total;
+} fsv_aln_stats;
+int fsv_aln_last_stats(const fsv_ctx *ctx, fsv_aln_stats *out);
+
+/* single global alignment (the DP of one event), exposed for known-answer tests against ksw2 */
+int fsv_nw(fsv_ctx *ctx, const char *target, int32_t tl, const char *query, int32_t ql, const fsv_aln_params *params,
+           int32_t *score, uint32_t *cigar, uint32_t cigar_cap, uint32_t *n_cigar);
+
 #ifdef __cplusplus
 }
 #endif
