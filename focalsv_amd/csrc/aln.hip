@@ -30,14 +30,15 @@ __device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v)
 // ------------------------------------------------------------------------------------------------ chain
 __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ word_off, const int32_t *__restrict__ read_len,
                                                   const fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off,
-                                                  const uint32_t *__restrict__ mz_cnt, uint64_t *__restrict__ chain_out,
+                                                  const uint32_t *__restrict__ mz_cnt, const uint32_t *__restrict__ pair_q,
+                                                  const uint32_t *__restrict__ pair_t, uint64_t *__restrict__ chain_out,
                                                   AlnHeader *__restrict__ hdr, fsv_aln_params P)
 {
     __shared__ uint64_t s_key[ALN_AMAX];
     __shared__ int32_t s_f[ALN_AMAX];
     __shared__ uint16_t s_aux[ALN_AMAX];
     const int lane = threadIdx.x;
-    const uint32_t p = blockIdx.x, rq = 2 * p, rt = 2 * p + 1;
+    const uint32_t p = blockIdx.x, rq = pair_q[p], rt = pair_t[p];
     const int lenq = read_len[rq];
     const fsv_mz *mq = mz + mz_off[rq], *mt = mz + mz_off[rt];
     const int nq = (int)mz_cnt[rq], nt = (int)mz_cnt[rt];
@@ -146,15 +147,16 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
 __device__ __forceinline__ uint32_t qbase(const uint32_t *__restrict__ store, uint32_t qw, int lenq, int rev, int p) { return fsv_base_at(store, qw, lenq, rev, p); }
 
 __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
-                                                    const int32_t *__restrict__ read_len, const uint64_t *__restrict__ chain,
+                                                    const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
+                                                    const uint32_t *__restrict__ pair_t, const uint64_t *__restrict__ chain,
                                                     AlnHeader *__restrict__ hdr, AlnEvent *__restrict__ events, fsv_aln_params P)
 {
     __shared__ uint8_t s_cls[ALN_AMAX];
     const uint32_t p = blockIdx.x;
     AlnHeader h = hdr[p];
     if (h.status != 0) return;
-    const uint32_t qw = word_off[2 * p], tw = word_off[2 * p + 1];
-    const int lenq = read_len[2 * p], lent = read_len[2 * p + 1], rev = h.rev, nch = h.n_chain, nseg = nch - 1;
+    const uint32_t qw = word_off[pair_q[p]], tw = word_off[pair_t[p]];
+    const int lenq = read_len[pair_q[p]], lent = read_len[pair_t[p]], rev = h.rev, nch = h.n_chain, nseg = nch - 1;
     const uint64_t *c = chain + (size_t)p * ALN_AMAX;
     // segment classes between consecutive anchors: 0 identical, 1 few mismatches ('M'), 2 needs DP
     for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
@@ -219,14 +221,15 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
 //   H on diagonals d-1 and d-2, and the E/F/E2/F2 values *leaving* each cell of diagonal d-1.
 // Per cell one traceback byte with ksw2's layout (ksw2.h:115-118).
 __global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
-                                            const int32_t *__restrict__ read_len, const AlnHeader *__restrict__ hdr,
+                                            const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
+                                            const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                             const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all, int32_t *__restrict__ rows_all,
                                             uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
 {
     __shared__ int32_t s_rows[11 * NW_LDS_Q];
     const NwTask T = tasks[blockIdx.x];
-    const uint32_t qw = word_off[2 * T.pair], tw = word_off[2 * T.pair + 1];
-    const int lenq = read_len[2 * T.pair], rev = hdr[T.pair].rev;
+    const uint32_t qw = word_off[pair_q[T.pair]], tw = word_off[pair_t[T.pair]];
+    const int lenq = read_len[pair_q[T.pair]], rev = hdr[T.pair].rev;
     const int ql = T.ql, tl = T.tl;
     const bool two = P.q2 >= 0;
     int32_t *rows = ql <= NW_LDS_Q ? s_rows : rows_all + T.row_off;
@@ -315,9 +318,9 @@ __global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, 
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 struct AlnWs {
-    DevBuf store, word_off, len, wper, mz, mz_off, mz_cnt, warn, chain, hdr, events, tasks, bt, rows, cg, cg_n, scores;
+    DevBuf store, word_off, len, wper, pair_q, pair_t, mz, mz_off, mz_cnt, warn, chain, hdr, events, tasks, bt, rows, cg, cg_n, scores;
     fsv_aln_stats stats;
-    std::vector<DevBuf *> all() { return {&store, &word_off, &len, &wper, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
+    std::vector<DevBuf *> all() { return {&store, &word_off, &len, &wper, &pair_q, &pair_t, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
 };
 
 void aln_ws_free(fsv_ctx *ctx)
@@ -389,7 +392,8 @@ int run_nw(fsv_ctx *ctx, AlnWs &W, const std::vector<NwTask> &tasks, uint64_t bt
     TRY(ensure(ctx, W.cg_n, tasks.size() * 4));
     TRY(ensure(ctx, W.scores, tasks.size() * 4));
     hipLaunchKernelGGL(k_nw, dim3((uint32_t)tasks.size()), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
-                       (const int32_t *)W.len.p, (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (int32_t *)W.rows.p,
+                       (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
+                       (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (int32_t *)W.rows.p,
                        (uint32_t *)W.cg.p, (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
     return FSV_OK;
@@ -440,6 +444,8 @@ extern "C" int fsv_nw(fsv_ctx *ctx, const char *target, int32_t tl, const char *
     TRY(pack_pairs(ctx, W, {query, target}, {(uint64_t)ql, (uint64_t)tl}, word_off, len));
     std::vector<AlnHeader> hdr(1); memset(&hdr[0], 0, sizeof(AlnHeader));
     TRY(upload(ctx, W.hdr, hdr));
+    TRY(upload(ctx, W.pair_q, std::vector<uint32_t>{0u}));
+    TRY(upload(ctx, W.pair_t, std::vector<uint32_t>{1u}));
     std::vector<NwTask> tasks(1);
     tasks[0] = NwTask{0u, 0, ql, 0, tl, 0u, 0ull, 0ull};
     TRY(run_nw(ctx, W, tasks, (uint64_t)tl * ql, ql > NW_LDS_Q ? 11ull * ql : 0, P));
@@ -469,24 +475,43 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     AlnWs &W = *aln_ws_get(ctx);
     memset(&W.stats, 0, sizeof(W.stats));
     Timer ttot(ctx);
-    const uint32_t np = n_contigs, nr = 2 * np;
+    const uint32_t np = n_contigs, nr = n_refs + n_contigs;
+    // sequences in the store: the reference windows first, then the contigs; every window is sketched once with
+    // w = max(P.w, L/3000 + 1), L = the longest sequence of its group, and its contigs use the same w
     std::vector<const char *> seq(nr); std::vector<uint64_t> slen(nr);
     std::vector<uint8_t> wper(nr);
+    std::vector<uint32_t> pair_q(np), pair_t(np);
     std::vector<int32_t> pre_status(np, 0);
+    std::vector<uint64_t> group_len(n_refs, 0);
+    for (uint32_t r = 0; r < n_refs; r++) {
+        seq[r] = ref_seq + ref_off[r]; slen[r] = ref_off[r + 1] - ref_off[r];
+        if (slen[r] == 0) return fsv_fail(ctx, FSV_EINVAL, "empty reference window");
+        group_len[r] = slen[r];
+    }
     for (uint32_t p = 0; p < np; p++) {
         if (contig_ref[p] >= n_refs) return fsv_fail(ctx, FSV_EINVAL, "contig_ref out of range");
-        seq[2 * p] = contig_seq + contig_off[p]; slen[2 * p] = contig_off[p + 1] - contig_off[p];
-        seq[2 * p + 1] = ref_seq + ref_off[contig_ref[p]]; slen[2 * p + 1] = ref_off[contig_ref[p] + 1] - ref_off[contig_ref[p]];
-        const uint64_t L = std::max(slen[2 * p], slen[2 * p + 1]);
-        uint64_t w = std::max<uint64_t>((uint64_t)P.w, L / 3000 + 1);
-        if (w > 64 || slen[2 * p] < (uint64_t)P.k || slen[2 * p + 1] < (uint64_t)P.k || L >= (1u << 24)) { pre_status[p] = w > 64 || L >= (1u << 24) ? FSV_EUNSUP : 1; w = 64; }
-        wper[2 * p] = wper[2 * p + 1] = (uint8_t)w;
-        if (slen[2 * p] == 0 || slen[2 * p + 1] == 0) return fsv_fail(ctx, FSV_EINVAL, "empty contig or reference window");
+        seq[n_refs + p] = contig_seq + contig_off[p]; slen[n_refs + p] = contig_off[p + 1] - contig_off[p];
+        if (slen[n_refs + p] == 0) return fsv_fail(ctx, FSV_EINVAL, "empty contig");
+        group_len[contig_ref[p]] = std::max(group_len[contig_ref[p]], slen[n_refs + p]);
+        pair_q[p] = n_refs + p; pair_t[p] = contig_ref[p];
+    }
+    for (uint32_t r = 0; r < n_refs; r++) {
+        uint64_t w = std::max<uint64_t>((uint64_t)P.w, group_len[r] / 3000 + 1);
+        wper[r] = (uint8_t)std::min<uint64_t>(w, 64);
+    }
+    for (uint32_t p = 0; p < np; p++) {
+        const uint32_t r = contig_ref[p];
+        const uint64_t L = group_len[r];
+        wper[n_refs + p] = wper[r];
+        if (L / 3000 + 1 > 64 || L >= (1u << 24)) pre_status[p] = FSV_EUNSUP;
+        else if (slen[n_refs + p] < (uint64_t)P.k || slen[r] < (uint64_t)P.k) pre_status[p] = 1;
     }
     Timer tseed(ctx);
     std::vector<uint32_t> word_off; std::vector<int32_t> len;
     TRY(pack_pairs(ctx, W, seq, slen, word_off, len));
     TRY(upload(ctx, W.wper, wper));
+    TRY(upload(ctx, W.pair_q, pair_q));
+    TRY(upload(ctx, W.pair_t, pair_t));
     std::vector<uint32_t> mz_off(nr + 1, 0);
     uint64_t m = 0;
     for (uint32_t r = 0; r < nr; r++) { mz_off[r] = (uint32_t)m; m += (uint64_t)len[r] / 8 + 64; }
@@ -510,12 +535,14 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     TRY(ensure(ctx, W.hdr, (size_t)np * sizeof(AlnHeader)));
     TRY(ensure(ctx, W.events, (size_t)np * ALN_EV_CAP * sizeof(AlnEvent)));
     hipLaunchKernelGGL(k_chain_aln, dim3(np), dim3(64), 0, ctx->stream, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
-                       (const fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (const uint32_t *)W.mz_cnt.p, (uint64_t *)W.chain.p, (AlnHeader *)W.hdr.p, P);
+                       (const fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (const uint32_t *)W.mz_cnt.p, (const uint32_t *)W.pair_q.p,
+                       (const uint32_t *)W.pair_t.p, (uint64_t *)W.chain.p, (AlnHeader *)W.hdr.p, P);
     FSV_HIP(ctx, hipGetLastError());
     W.stats.ms_chain = tchain.stop();
     Timer tev(ctx);
     hipLaunchKernelGGL(k_aln_events, dim3(np), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
-                       (const int32_t *)W.len.p, (const uint64_t *)W.chain.p, (AlnHeader *)W.hdr.p, (AlnEvent *)W.events.p, P);
+                       (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const uint64_t *)W.chain.p,
+                       (AlnHeader *)W.hdr.p, (AlnEvent *)W.events.p, P);
     FSV_HIP(ctx, hipGetLastError());
     std::vector<AlnHeader> hdr(np);
     std::vector<AlnEvent> events((size_t)np * ALN_EV_CAP);
@@ -560,7 +587,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     W.stats.n_pairs = np; W.stats.n_events = tasks.size();
     // stitch: S, M runs, events, S
     for (uint32_t p = 0; p < np; p++) {
-        W.stats.algo_bytes += (uint64_t)(len[2 * p] + len[2 * p + 1] + 3) / 4;
+        W.stats.algo_bytes += (uint64_t)(len[pair_q[p]] + len[pair_t[p]] + 3) / 4;
         int32_t st = pre_status[p] != 0 ? pre_status[p] : hdr[p].status;
         if (st == 0) {
             std::vector<uint32_t> c;
@@ -576,7 +603,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
             }
             if (st == 0) {
                 push_cg(c, 0, (uint32_t)(h.qend + 1 - mstart));
-                push_cg(c, 4, (uint32_t)(len[2 * p] - 1 - h.qend));
+                push_cg(c, 4, (uint32_t)(len[pair_q[p]] - 1 - h.qend));
                 if (out->n_cigar + c.size() > out->cigar_cap) return fsv_fail(ctx, FSV_ECAP, "cigar buffer too small");
                 fsv_aln_rec &r = out->rec[out->n_rec++];
                 r.ref_start = h.tbeg; r.ref_end = h.tend + 1; r.q_start = h.qbeg; r.q_end = h.qend + 1; r.n_cigar = (uint32_t)c.size();

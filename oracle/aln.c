@@ -200,7 +200,6 @@ int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, co
     char *q = NULL;
     const char *Q;
     memset(out, 0, sizeof(*out));
-    { int L = lenq > lent ? lenq : lent; if (L / 3000 + 1 > w) w = L / 3000 + 1; }
     nq = orc_unique_sorted(mq, orc_sketch(contig, lenq, w, P->k, 0, mq, lenq + 8));
     nt = orc_unique_sorted(mt, orc_sketch(ref, lent, w, P->k, 0, mt, lent + 8));
     cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nq + 1) * 2); ct = cq + nq + 1;

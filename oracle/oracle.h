@@ -62,7 +62,7 @@ int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const o
                  char *contigs, uint64_t contigs_cap, uint64_t *contig_off, int contig_cap, int *n_contigs,
                  char *corrected, uint64_t corrected_cap, uint64_t *corrected_off);
 typedef struct {
-    int32_t k, w;             /* seeds: 19, 19 (minimap2 asm5); w grows with the sequence length */
+    int32_t k, w;             /* seeds: 19, 19 (minimap2 asm5); callers raise w to len/3000+1 for long windows */
     int32_t min_anchors, lookback, max_gap;
     int32_t a, b, q, e, q2, e2; /* asm5: 1, 19, 39, 3, 81, 1; q2 < 0 = single affine */
     int32_t pad;              /* identical bases added on each side of a DP event: 24 */
