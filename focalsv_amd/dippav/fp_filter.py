@@ -66,7 +66,8 @@ def FP_filter(input_path, signature_dir, output_path, max_comp_svlen=250, max_di
         for line in f:
             (header if line[0] == '#' else body).append(line)
     reads = {}
-    for name in {l.split()[0] for l in body}:
+    autosomes = {'chr%d' % i for i in range(1, 23)}
+    for name in {l.split()[0] for l in body} & autosomes:
         reads[name] = load_read_sigs("%s/%s_reads_sig.txt" % (signature_dir, name))
     with open(output_path, 'w') as f:
         f.writelines(header)

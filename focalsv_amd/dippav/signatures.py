@@ -176,15 +176,21 @@ def extract_sig_from_split(read1, read2, min_mapq=50, max_svlen=50000, profile: 
 
 
 # ---------------------------------------------------------------------------------------------- clustering
-def _seed_cluster(sigs, same):
+def _seed_cluster(sigs, same, max_shift=None):
     """the first unassigned signature seeds a cluster and absorbs every later unassigned one that matches it;
-    the longest member represents the cluster (first on ties).  CCS:157-249."""
+    the longest member represents the cluster (first on ties).  CCS:157-249.
+    The reference scans all pairs; a match needs |dpos| <= max_shift, so on position-sorted input (which is what
+    the reference always passes) the scan can stop once positions run past the seed -- same result, O(n) not O(n^2)."""
     label = [-1] * len(sigs)
+    is_sorted = max_shift is not None and all(sigs[k][2] <= sigs[k + 1][2] for k in range(len(sigs) - 1))
     for i, a in enumerate(sigs):
         if label[i] != -1:
             continue
         label[i] = i
-        for j, b in enumerate(sigs):
+        for j in range(i + 1 if is_sorted else 0, len(sigs)):
+            b = sigs[j]
+            if is_sorted and b[2] - a[2] > max_shift:
+                break
             if label[j] == -1 and same(a, b):
                 label[j] = i
     out = []
@@ -210,11 +216,11 @@ def _ins_match(a, b, max_shift, min_size_sim):
 
 
 def cluster_del(sigs, max_shift=100, min_overlap_ratio=0.5, min_size_similarity=0.5):
-    return _seed_cluster(sigs, lambda a, b: _del_match(a, b, max_shift, min_overlap_ratio, min_size_similarity))
+    return _seed_cluster(sigs, lambda a, b: _del_match(a, b, max_shift, min_overlap_ratio, min_size_similarity), max_shift)
 
 
 def cluster_ins(sigs, max_shift=100, min_size_similarity=0.5):
-    return _seed_cluster(sigs, lambda a, b: _ins_match(a, b, max_shift, min_size_similarity))
+    return _seed_cluster(sigs, lambda a, b: _ins_match(a, b, max_shift, min_size_similarity), max_shift)
 
 
 def merge_all(del_cigar, ins_cigar, del_split, ins_split):

@@ -1,0 +1,192 @@
+"""The hot path end to end, in memory: read sets of many regions -> haplotype contigs -> contig alignments ->
+DEL/INS calls.  This is what focalsv/3_assembly.py followed by focalsv/4_sv_calling.sh computes through files
+and external binaries; the file-based drop-ins (assembly.assembly, dippav.variant_call.
+dippav_variant_call) wrap the same calls.
+
+Region-level data parallelism: `shard_regions` deals regions to ranks largest-first (independent units, no
+collective while computing); `gather_vcf` is the one exchange step -- the analogue of `cat chr*/...vcf | vcf-sort`
+(focalsv/focalsv.py:66-70) -- an all-gather of per-rank VCF bytes (RCCL on GPUs, gloo in the CPU tests).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .dippav import fp_filter, reads_signature, redundancy, signatures as S, vcf
+from .dippav.variant_call import WindowedRef, call_chromosome, records_from_alignment
+from .readsets import PackedBatch, pack_sets
+
+
+@dataclass
+class RegionInput:
+    chrom: str
+    start: int                      # chromosome coordinate of ref[0]
+    ref: bytes                      # reference window (region +- flank)
+    reads_hp1: List[bytes]
+    reads_hp2: List[bytes]
+    read_records: List[S.AlignedSegment] = field(default_factory=list)  # what the region BAM says about the reads (FP filter)
+    name: str = ""
+
+    @property
+    def work(self) -> int:
+        return sum(map(len, self.reads_hp1)) + sum(map(len, self.reads_hp2))
+
+
+@dataclass
+class DeviceBatch:
+    regions: List[RegionInput]
+    packed: PackedBatch
+    store_dev: int
+
+    def free(self, ctx):
+        if self.store_dev:
+            ctx.dev_free(self.store_dev)
+            self.store_dev = 0
+
+
+@dataclass
+class CallResult:
+    header: List[str]
+    lines: List[str]                 # final VCF body (after FP filter and redundancy removal)
+    raw_lines: List[str]
+    contigs: List[Tuple[int, int, bytes]]   # (region, hp, sequence)
+    set_status: np.ndarray
+    contig_status: np.ndarray
+    asm_stats: Dict
+    aln_stats: Dict
+
+
+def region_from_synth(r, flank_start: int = 0) -> RegionInput:
+    """synthetic Region (focalsv_amd.synth) -> RegionInput with the read records a cropped BAM would provide"""
+    recs = []
+    for h in (0, 1):
+        for j, (pos, ops, rev) in enumerate(r.read_aln[h]):
+            ref_len = sum(n for op, n in ops if op in (0, 2))
+            recs.append(S.AlignedSegment(r.chrom, r.start + pos, r.start + pos + ref_len, ops, "r%d_h%d_%d" % (r.index, h + 1, j), rev, 60, None))
+    return RegionInput(r.chrom, r.start, r.ref, list(r.reads[0]), list(r.reads[1]), recs, "Region_%s_S%d_E%d" % (r.chrom, r.start, r.start + len(r.ref)))
+
+
+def upload_regions(ctx: _lib.Context, regions: Sequence[RegionInput]) -> DeviceBatch:
+    """K0: pack every read set (2 per region) into the 2-bit store and put it in HBM (done before the timed region)"""
+    sets = []
+    for r in regions:
+        sets.append(r.reads_hp1)
+        sets.append(r.reads_hp2)
+    packed = pack_sets(sets)
+    return DeviceBatch(list(regions), packed, ctx.upload(packed.words))
+
+
+def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> CallResult:
+    regions, pk = batch.regions, batch.packed
+    contigs, cset, cnr, set_status = ctx.assemble_batch(batch.store_dev, pk.word_off, pk.read_len, pk.set_start, asm_params)
+    asm_stats = ctx.asm_stats()
+    # reformat_fasta (DipPAV_variant_call.py:14-23): contigs are numbered per haplotype across the whole call
+    names, cref, keep_contigs, counters = [], [], [], {1: 0, 2: 0}
+    for c, s in zip(contigs, cset):
+        ri, hp = int(s) // 2, int(s) % 2 + 1
+        names.append("contig_hp%d_%d" % (hp, counters[hp]))
+        counters[hp] += 1
+        cref.append(ri)
+        keep_contigs.append((ri, hp, c))
+    rec, cigar, contig_status = ctx.align_batch(contigs, cref, [r.ref for r in regions], aln_params) if contigs else (np.zeros(0, _lib.ALN_REC_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.int32))
+    aln_stats = ctx.aln_stats() if contigs else {}
+    records = records_from_alignment(rec, cigar, names, [regions[i].chrom for i in cref], [regions[i].start for i in cref])
+    contig_seq = {n: c.decode() for n, c in zip(names, contigs)}
+    raw, final = [], []
+    chroms = sorted({r.chrom for r in regions}, key=lambda c: (len(c), c))
+    read_sigs = {}
+    for chrom in chroms:
+        ref = WindowedRef()
+        rr = []
+        for r in regions:
+            if r.chrom == chrom:
+                ref.add(r.start, r.ref.decode())
+                rr += r.read_records
+        paired, body = call_chromosome(records, chrom, ref, contig_seq, data_type)
+        raw += body
+        read_sigs[chrom] = reads_signature.reads_signatures(rr, 50)
+    kept = fp_filter.filter_lines(vcf.HEADER_LINES, raw, read_sigs)
+    header, final, dropped = redundancy.collapse(vcf.HEADER_LINES, kept)
+    return CallResult(header, final, raw, keep_contigs, set_status, contig_status, asm_stats, aln_stats)
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU
+def shard_regions(work: Sequence[int], world_size: int) -> List[List[int]]:
+    """static region -> rank assignment: largest first onto the least loaded rank.  Deterministic."""
+    order = sorted(range(len(work)), key=lambda i: (-work[i], i))
+    load = [0] * world_size
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        k = min(range(world_size), key=lambda j: (load[j], j))
+        out[k].append(i)
+        load[k] += work[i]
+    for o in out:
+        o.sort()
+    return out
+
+
+def _vcf_key(line: str):
+    d = line.split('\t', 2)
+    c = d[0]
+    num = c[3:] if c.startswith('chr') else c
+    return (0, int(num)) if num.isdigit() else (1, num), int(d[1])
+
+
+def gather_vcf(lines: Sequence[str], group=None, device=None) -> Optional[List[str]]:
+    """all ranks contribute their VCF body lines; every rank gets the (chrom, pos)-sorted union.
+    Two-phase all-gather (int64 sizes, then padded bytes) through torch.distributed: backend 'nccl' is RCCL over xGMI."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return sorted(lines, key=_vcf_key)
+    ws = dist.get_world_size(group)
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    payload = "".join(lines).encode()
+    size = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    dist.all_gather(sizes, size, group=group)
+    mx = max(1, int(max(int(s.item()) for s in sizes)))
+    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    if payload:
+        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(ws)]
+    dist.all_gather(bufs, buf, group=group)
+    out: List[str] = []
+    for s, b in zip(sizes, bufs):
+        n = int(s.item())
+        if n:
+            out += bytes(b[:n].cpu().numpy()).decode().splitlines(True)
+    return sorted(out, key=_vcf_key)
+
+
+# ------------------------------------------------------------------------------------------------ evaluation
+def parse_calls(lines: Sequence[str]):
+    out = []
+    for l in lines:
+        d = l.rstrip('\n').split('\t')
+        info = dict(kv.split('=', 1) for kv in d[7].split(';') if '=' in kv)
+        out.append({"chrom": d[0], "pos": int(d[1]), "type": info["SVTYPE"], "svlen": abs(int(info["SVLEN"])), "gt": d[9]})
+    return out
+
+
+def match_truth(calls, truth, bp_tol: int = 1, len_tol: float = 0.02, left_shift_ok: int = 0):
+    """truth: [(chrom, type, pos0, len, gt)] -> (tp, fp, fn, gt_ok).  A call matches when type agrees, |SVLEN diff| <= len_tol
+    and the position is within bp_tol of the truth position, or up to `left_shift_ok` bases to its left (a left-aligned
+    gap inside a repeat is the same allele)."""
+    used = [False] * len(calls)
+    tp = gt_ok = 0
+    for (chrom, typ, pos, ln, gt) in truth:
+        hit = None
+        for i, c in enumerate(calls):
+            if used[i] or c["chrom"] != chrom or c["type"] != typ:
+                continue
+            d = c["pos"] - pos
+            if abs(c["svlen"] - ln) <= max(0, int(len_tol * ln)) and (abs(d) <= bp_tol or -left_shift_ok <= d <= 0):
+                hit = i
+                break
+        if hit is not None:
+            used[hit] = True
+            tp += 1
+            gt_ok += calls[hit]["gt"] == gt
+    return tp, len(calls) - tp, len(truth) - tp, gt_ok

@@ -35,6 +35,8 @@ class Region:
     haps: Tuple[bytes, bytes]
     reads: Tuple[List[bytes], List[bytes]]
     truth: List[TruthSV] = field(default_factory=list)
+    # what the region-cropped read BAM would say about every read: (0-based window position, BAM cigar, is_reverse)
+    read_aln: Tuple[List[tuple], List[tuple]] = field(default_factory=lambda: ([], []))
 
 
 def _rand_seq(rng, n):
@@ -77,7 +79,44 @@ def _add_errors(rng, seq: np.ndarray, rate: float) -> np.ndarray:
     return res
 
 
-def _sample_reads(rng, hap: np.ndarray, depth: float, len_lo: int, len_hi: int, err: float, min_keep: int = 3000):
+def _segments(events, ref_len):
+    """events [(ref_pos, 'DEL'|'INS', length)] -> [(op, ref_start, hap_start, length)] with BAM ops 0 M, 1 I, 2 D"""
+    segs, r, h = [], 0, 0
+    for pos, kind, n in sorted(events):
+        if pos > r:
+            segs.append((0, r, h, pos - r)); h += pos - r; r = pos
+        if kind == "DEL":
+            segs.append((2, r, h, n)); r += n
+        else:
+            segs.append((1, r, h, n)); h += n
+    if ref_len > r:
+        segs.append((0, r, h, ref_len - r))
+    return segs
+
+
+def _truth_cigar(segs, a, b):
+    """alignment of hap[a:b) to the reference: (ref_pos, [(op, len)]); an insertion cut by the read end is soft-clipped"""
+    ops, pos = [], None
+    for op, rs, hs, n in segs:
+        if op == 2:
+            if pos is not None and hs < b and hs > a:
+                ops.append((2, n))
+            continue
+        lo, hi = max(a, hs), min(b, hs + n)
+        if hi <= lo:
+            continue
+        if op == 0:
+            if pos is None:
+                pos = rs + (lo - hs)
+            ops.append((0, hi - lo))
+        else:
+            ops.append((1 if (pos is not None and hi < b) else 4, hi - lo))
+    while ops and ops[-1][0] == 2:
+        ops.pop()
+    return pos, ops
+
+
+def _sample_reads(rng, hap: np.ndarray, depth: float, len_lo: int, len_hi: int, err: float, min_keep: int = 3000, segs=None, aln_out=None):
     reads = []
     total, target = 0, depth * hap.size
     H = hap.size
@@ -88,9 +127,13 @@ def _sample_reads(rng, hap: np.ndarray, depth: float, len_lo: int, len_hi: int, 
         if b - a < min_keep:
             continue
         seg = _add_errors(rng, hap[a:b], err)
-        if rng.random() < 0.5:
+        rev = rng.random() < 0.5
+        if rev:
             seg = _COMP[seg][::-1]
         reads.append(seg.tobytes())
+        if aln_out is not None:
+            pos, ops = _truth_cigar(segs, a, b)
+            aln_out.append((pos, ops, bool(rev)))
         total += b - a
     return reads
 
@@ -166,10 +209,12 @@ def make_region(i: int, width: int = 50_000, profile: str = "hifi", depth_per_ha
         raise ValueError(profile)
     lo, hi = min(lo, max(1000, width // 2)), min(hi, width)
     keep = min(3000, max(500, width // 8))
-    r1 = _sample_reads(rng, hap1, depth_per_hap, lo, hi, err, keep)
-    r2 = _sample_reads(rng, hap2, depth_per_hap, lo, hi, err, keep)
+    a1, a2 = [], []
+    r1 = _sample_reads(rng, hap1, depth_per_hap, lo, hi, err, keep, _segments([(dpos, "DEL", dlen), (ipos, "INS", ilen)], width), a1)
+    r2 = _sample_reads(rng, hap2, depth_per_hap, lo, hi, err, keep,
+                       _segments([(p, k, (n if k == "DEL" else len(n))) for p, k, n in ev2], width), a2)
     truth.sort(key=lambda t: t.pos)
-    return Region(i, chrom, start, ref.tobytes(), (hap1.tobytes(), hap2.tobytes()), (r1, r2), truth)
+    return Region(i, chrom, start, ref.tobytes(), (hap1.tobytes(), hap2.tobytes()), (r1, r2), truth, (a1, a2))
 
 
 def write_region_dir(region: Region, out_dir: str) -> str:
