@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- target regions/sec of the per-region local-assembly + SV-calling hot path on MI355X.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 launched through torch.distributed.run,
+one rank per GPU.  A "step" is one pass of the whole hot path (assembly -> contig alignment -> SV calling -> VCF gather)
+over one batch of synthetic regions whose packed reads already sit in HBM.  Workload = BASELINE.json configs[1]:
+256 synthetic 50 kb regions, 30x HiFi-like 15 kb reads, per GPU (weak scaling: every rank gets its own 256 regions).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(n_regions, first_index):
+    """The oracle (CPU restatement, one core) on a bounded sample of the same workload: assembly of both haplotypes,
+    contig alignment and the host SV logic.  kind = "port".  When the prebuilt reference hifiasm is present
+    (oracle/_ref, built from /root/reference in the build container) its wall time on the same read sets is added."""
+    import subprocess
+    import tempfile
+    from focalsv_amd import synth
+    from focalsv_amd.dippav import signatures as S
+    from focalsv_amd.dippav.variant_call import WindowedRef, call_chromosome
+    from tests import oracle_lib as O
+    regions = [synth.make_region(first_index + i, start=(first_index + i) * 60000) for i in range(n_regions)]
+    t0 = time.perf_counter()
+    recs, contig_seq, cnt = [], {}, {1: 0, 2: 0}
+    for r in regions:
+        for h in (0, 1):
+            for c in O.assemble(r.reads[h])[0]:
+                name = "contig_hp%d_%d" % (h + 1, cnt[h + 1]); cnt[h + 1] += 1
+                a = O.align_contig(c, r.ref)
+                contig_seq[name] = c.decode()
+                if a:
+                    recs.append(S.AlignedSegment(r.chrom, r.start + a["ref_start"], r.start + a["ref_end"], a["cigar"], name, bool(a["rev"]), a["mapq"], None))
+    recs.sort(key=lambda x: x.pos)
+    ref = WindowedRef()
+    for r in regions:
+        ref.add(r.start, r.ref.decode())
+    call_chromosome(recs, "chr21", ref, contig_seq, 'CCS')
+    dt = time.perf_counter() - t0
+    out = {"value": round(n_regions / dt, 4), "unit": "regions/s", "cores": 1, "kind": "port",
+           "sample": f"{n_regions} of the bench's regions (indices {first_index}..{first_index + n_regions - 1}), oracle/ C restatement, {dt:.1f} s"}
+    hifiasm = os.path.join(ROOT, "oracle", "_ref", "hifiasm-0.14")
+    if os.path.exists(hifiasm):
+        cores = os.cpu_count() or 1
+        with tempfile.TemporaryDirectory() as tmp:
+            t0 = time.perf_counter()
+            for r in regions:
+                d = synth.write_region_dir(r, os.path.join(tmp, "r%d" % r.index))
+                for h in (1, 2):
+                    subprocess.run([hifiasm, "-f0", "-o", f"PS1_hp{h}.asm", "-t", str(min(cores, 16)), f"PS1_hp{h}.fa"], cwd=d, check=False,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt2 = time.perf_counter() - t0
+        out["reference_hifiasm"] = {"value": round(n_regions / dt2, 4), "unit": "regions/s (assembly half only, -f0: Bloom filter off)",
+                                    "cores": min(cores, 16), "seconds": round(dt2, 2)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--regions", type=int, default=256, help="regions per GPU (BASELINE.json configs[1]: 256)")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="regions the CPU baseline runs (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from focalsv_amd import _lib, pipeline, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.gpus > 1:
+        sys.exit("launch with torch.distributed.run for --gpus > 1")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    # synthetic inputs (untimed), sharded by work over the ranks' own region ranges: weak scaling
+    n = args.regions
+    idx0 = rank * n
+    regions = [synth.make_region(idx0 + i, start=(idx0 + i) * 60000) for i in range(n)]
+    inputs = [pipeline.region_from_synth(r) for r in regions]
+    truth = [(r.chrom, t.svtype, r.start + t.pos, t.length, t.gt) for r in regions for t in r.truth]
+
+    ctx = _lib.Context(local)
+    batch = pipeline.upload_regions(ctx, inputs)  # reads resident in HBM before timing starts
+
+    def step():
+        res = pipeline.run_hot_path(ctx, batch)
+        lines = pipeline.gather_vcf(res.lines) if world > 1 else res.lines
+        return res, lines
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats_acc = []
+    for _ in range(args.steps):
+        res, lines = step()
+        stats_acc.append((res.asm_stats, res.aln_stats))
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # correctness on this rank's regions (the gathered VCF holds every rank's calls; filter to ours)
+    mine = [l for l in lines if idx0 * 60000 <= int(l.split('\t')[1]) < (idx0 + n) * 60000]
+    calls = pipeline.parse_calls(mine)
+    tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.02, left_shift_ok=2000)
+    tp1, _, _, _ = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.02, left_shift_ok=0)
+
+    if rank == 0:
+        a = stats_acc[-1][0]
+        l = stats_acc[-1][1]
+        kern = a.get("kernels", {})
+        dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else (None, None)
+        peak = 8000.0
+        roof = None
+        if dom[0]:
+            k = dom[1]
+            ach = (k["algo_bytes"] / max(1, k["launches"])) / (k["ms"] / max(1, k["launches"]) * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 6),
+                    "traffic": None, "launches_per_step": k["launches"], "avg_launch_ms": round(k["ms"] / max(1, k["launches"]), 4),
+                    "algo_bytes_per_launch": int(k["algo_bytes"] / max(1, k["launches"])),
+                    "note": "integer DP with operands in registers/LDS: the binding roof is VALU issue, not HBM (DESIGN.md)"}
+        out = {
+            "metric": "target regions/sec (50 kb, 30x HiFi)", "value": round(world * n * args.steps / dt, 3), "unit": "regions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{n} synthetic 50 kb regions per GPU, 30x HiFi-like reads U(10k,20k), 0.2% error, seed 1000+i "
+                                   "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather"},
+            "sv_vs_truth": {"truth": len(truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok, "tp_within_1bp_unshifted": tp1},
+            "stage_ms": {k: round(v, 2) for k, v in a.items() if k.startswith("ms_")},
+            "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},
+            "algo_bytes_per_region": int((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) / n),
+            "hbm_roofline_whole_path": {"GBps": round((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) * args.steps / dt / 1e9 * 1.0, 3), "frac": round((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) * args.steps / dt / 8e12, 6)},
+            "roofline": roof,
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 0)
+        print(json.dumps(out))
+    fence()
+    batch.free(ctx)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,10 +36,15 @@ class Contigs(C.Structure):
                 ("contig_cap", C.c_uint32), ("n_contigs", C.c_uint32), ("set_status", C.c_void_p)]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 24), ("ms", C.c_double), ("launches", C.c_uint64), ("algo_bytes", C.c_uint64)]
+
+
 class AsmStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_pairs", "n_overlaps", "n_windows", "n_windows_matched", "n_paths", "n_path_dp",
                                           "dp_columns", "algo_bytes", "n_exact_overlaps")] + \
-               [(n, C.c_double) for n in ("ms_sketch", "ms_chain", "ms_verify", "ms_path", "ms_consensus", "ms_final", "ms_total")]
+               [(n, C.c_double) for n in ("ms_sketch", "ms_chain", "ms_verify", "ms_path", "ms_consensus", "ms_final", "ms_total")] + \
+               [("n_kernels", C.c_uint32), ("pad", C.c_uint32), ("kernels", KernelStat * 16)]
 
 
 class AlnParams(C.Structure):
@@ -236,7 +241,10 @@ class Context:
     def asm_stats(self):
         st = AsmStats()
         self.check(self._lib.fsv_asm_last_stats(self._h, C.byref(st)), "fsv_asm_last_stats")
-        return {n: getattr(st, n) for n, _ in AsmStats._fields_}
+        out = {n: getattr(st, n) for n, _ in AsmStats._fields_ if n not in ("kernels", "pad", "n_kernels")}
+        out["kernels"] = {st.kernels[i].name.decode(): {"ms": st.kernels[i].ms, "launches": st.kernels[i].launches,
+                                                        "algo_bytes": st.kernels[i].algo_bytes} for i in range(st.n_kernels)}
+        return out
 
     def fetch_reads(self, n_reads, total_cap):
         seq = np.empty(total_cap, dtype=np.uint8)

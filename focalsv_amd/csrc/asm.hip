@@ -17,6 +17,22 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// HIP-event timing of individual kernels on the context's stream; resolved once at the end of the batch
+struct KTimes {
+    struct Rec { int k; hipEvent_t a, b; uint64_t bytes; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get() { if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); } return pool[used++]; }
+    void begin(fsv_ctx *ctx, int k, uint64_t bytes) { Rec r{k, get(), get(), bytes}; (void)hipEventRecord(r.a, ctx->stream); recs.push_back(r); }
+    void end(fsv_ctx *ctx) { (void)hipEventRecord(recs.back().b, ctx->stream); }
+    void reset() { recs.clear(); used = 0; }
+    ~KTimes() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
+enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_COUNT };
+const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm", "k_rescue_accept", "k_path_fast", "k_path_dp", "k_consensus",
+                                        "k_repack", "k_exact", "k_stitch"};
+
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
         cols, tmp, gwin_off, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
@@ -26,6 +42,7 @@ struct AsmWs {
     const uint32_t *cur_store = nullptr;
     uint32_t n_reads = 0;
     fsv_asm_stats stats;
+    KTimes kt;
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
@@ -126,13 +143,17 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     TRY(ensure(ctx, W.ovl, (size_t)std::max(1u, B.n_pairs) * sizeof(fsv_ovl)));
     TRY(ensure(ctx, W.counters, 64));
     FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, 64, ctx->stream));
+    W.kt.begin(ctx, KN_SKETCH, (uint64_t)G.word_off[B.n_reads] * 4 + (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz));
     hipLaunchKernelGGL(k_sketch, dim3(fsv_grid_for(B.n_reads, 64)), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
                        (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
                        P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr);
     FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
+    W.kt.begin(ctx, KN_UNIQ, (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz) * 2);
     hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
                        (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p);
     FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
     W.stats.ms_sketch += ts.stop();
     if (B.n_pairs == 0) return FSV_OK;
     Timer tc(ctx);
@@ -143,8 +164,10 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     A.ovl = (fsv_ovl *)W.ovl.p; A.tasks = (fsv_wtask *)W.tasks.p; A.task_counter = (uint32_t *)W.counters.p; A.task_cap = task_cap;
     A.overflow = (uint32_t *)W.counters.p + 1; A.warn = (uint32_t *)W.warn.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
     A.n_sets = B.n_sets; A.k_score = P.k; A.min_anchors = P.min_anchors; A.min_ovlp = P.min_ovlp; A.bw = bw; A.emit_tasks = emit_tasks ? 1 : 0;
+    W.kt.begin(ctx, KN_CHAIN, (uint64_t)B.n_pairs * (2ull * 600 * sizeof(fsv_mz) / 4 + sizeof(fsv_ovl)));
     hipLaunchKernelGGL(k_chain, dim3(B.n_pairs), dim3(64), 0, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
     W.stats.ms_chain += tc.stop();
     return FSV_OK;
 }
@@ -243,6 +266,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     FSV_HIP(ctx, hipSetDevice(ctx->device));
     AsmWs &W = *ws_get(ctx);
     memset(&W.stats, 0, sizeof(W.stats));
+    W.kt.reset();
     Timer ttotal(ctx);
 
     Batch B;
@@ -308,18 +332,24 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         W.stats.n_windows += n_tasks;
         if (n_tasks) {
             Timer tv(ctx);
+            W.kt.begin(ctx, KN_BPM, (uint64_t)n_tasks * (32 + 196 + 16));
             TRY(fsv_bpm_windows_dev(ctx, store, (const fsv_wtask *)W.tasks.p, n_tasks, (fsv_wres *)W.res.p));
-            hipLaunchKernelGGL(k_rescue_accept, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
+            W.kt.end(ctx);
+            W.kt.begin(ctx, KN_RESCUE, (uint64_t)n_tasks * 48 + (uint64_t)B.n_pairs * sizeof(fsv_ovl) * 2);
+    hipLaunchKernelGGL(k_rescue_accept, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
                                B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)((uint32_t *)W.counters.p + 4));
             FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
             W.stats.ms_verify += tv.stop();
             Timer tp(ctx);
             TRY(ensure(ctx, W.paths, (size_t)n_tasks * sizeof(fsv_wpath)));
             TRY(ensure(ctx, W.dp_list, (size_t)n_tasks * 4));
-            hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
+            W.kt.begin(ctx, KN_PATH_FAST, (uint64_t)n_tasks * (48 + 128));
+    hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
                                (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, n_tasks, (fsv_wpath *)W.paths.p,
                                (uint32_t *)W.dp_list.p, (uint32_t *)W.counters.p + 2);
             FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
             FSV_HIP(ctx, hipMemcpyAsync(cnt, W.counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             const uint32_t n_dp = cnt[2];
@@ -332,9 +362,11 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
                 TRY(ensure(ctx, W.tmp, (size_t)stride * (FSV_PATH_CAP + 64)));
                 for (uint32_t b = 0; b < n_dp; b += chunk) {
                     const uint32_t e = std::min(n_dp, b + chunk);
-                    hipLaunchKernelGGL(k_path_dp, dim3(fsv_grid_for(e - b, 64)), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                    W.kt.begin(ctx, KN_PATH_DP, (uint64_t)(e - b) * (32 + 196 + 128));
+    hipLaunchKernelGGL(k_path_dp, dim3(fsv_grid_for(e - b, 64)), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
                                        (const uint32_t *)W.dp_list.p, b, e, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p, (uint8_t *)W.tmp.p, stride);
                     FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
                 }
             }
             W.stats.ms_path += tp.stop();
@@ -352,8 +384,10 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         C.gwin_off = (const uint32_t *)W.gwin_off.p; C.ovl = (const fsv_ovl *)W.ovl.p; C.tasks = (const fsv_wtask *)W.tasks.p;
         C.paths = (const fsv_wpath *)W.paths.p; C.cwin = (uint8_t *)W.cwin.p; C.cwin_len = (uint16_t *)W.cwin_len.p; C.warn = (uint32_t *)W.warn.p;
         C.n_reads = B.n_reads;
-        hipLaunchKernelGGL(k_consensus, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
+        W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_tasks * 128 + (uint64_t)n_gwin * (96 + 448));
+    hipLaunchKernelGGL(k_consensus, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
         FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
         hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
                            (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p);
         FSV_HIP(ctx, hipGetLastError());
@@ -367,10 +401,12 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         TRY(ensure(ctx, dst, ((size_t)total_words + 8) * 4));
         // k_repack needs the new offsets/lengths while the old ones are still in use by nothing else: stage them in mz_cnt/new_len
         TRY(upload(ctx, W.unpack_off, G2.word_off));
-        hipLaunchKernelGGL(k_repack, dim3(fsv_grid_for(total_words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
+        W.kt.begin(ctx, KN_REPACK, (uint64_t)n_gwin * 384 + (uint64_t)total_words * 4);
+    hipLaunchKernelGGL(k_repack, dim3(fsv_grid_for(total_words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
                            (const uint16_t *)W.cwin_len.p, (const uint8_t *)W.cwin.p, (const uint32_t *)W.unpack_off.p,
                            (const int32_t *)W.new_len.p, B.n_reads, total_words, round + 1 < P.n_rounds ? 1 : 0, (uint32_t *)dst.p);
         FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
         FSV_HIP(ctx, hipMemsetAsync((uint8_t *)dst.p + (size_t)total_words * 4, 0, 32, ctx->stream));
         W.stats.ms_consensus += tcs.stop();
         store = (const uint32_t *)dst.p;
@@ -387,9 +423,11 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0));
     std::vector<fsv_ovl> hovl(B.n_pairs);
     if (B.n_pairs) {
-        hipLaunchKernelGGL(k_exact, dim3(B.n_pairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
+        W.kt.begin(ctx, KN_EXACT, (uint64_t)B.n_pairs * sizeof(fsv_ovl) + W.stats.n_pairs * 0);
+    hipLaunchKernelGGL(k_exact, dim3(B.n_pairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
                            (const uint32_t *)W.set_start.p, (const uint32_t *)W.pair_base.p, B.n_sets, (fsv_ovl *)W.ovl.p);
         FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
         FSV_HIP(ctx, hipMemcpyAsync(hovl.data(), W.ovl.p, (size_t)B.n_pairs * sizeof(fsv_ovl), hipMemcpyDeviceToHost, ctx->stream));
     }
     std::vector<uint32_t> hwarn(B.n_reads);
@@ -427,9 +465,11 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     if (!pieces.empty()) {
         TRY(upload(ctx, W.pieces, pieces));
         TRY(ensure(ctx, W.contig_out, used + 16));
-        hipLaunchKernelGGL(k_stitch, dim3((uint32_t)pieces.size()), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
+        W.kt.begin(ctx, KN_STITCH, used * 2);
+    hipLaunchKernelGGL(k_stitch, dim3((uint32_t)pieces.size()), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const fsv_piece *)W.pieces.p, (char *)W.contig_out.p);
         FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
         FSV_HIP(ctx, hipMemcpyAsync(out->seq, W.contig_out.p, used, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -438,6 +478,15 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     // algorithmic bytes: 2-bit operands + result of every DP task, reads in once per pass, contigs out
     W.stats.algo_bytes = W.stats.n_windows * 212ull + reads_in_bytes * (uint64_t)(P.n_rounds + 1) + used;
     W.stats.ms_total = ttotal.stop();
+    // resolve the per-kernel event timings
+    W.stats.n_kernels = KN_COUNT;
+    for (int k = 0; k < KN_COUNT; k++) { memset(&W.stats.kernels[k], 0, sizeof(fsv_kernel_stat)); strncpy(W.stats.kernels[k].name, kn_names[k], 23); }
+    for (auto &r : W.kt.recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) W.stats.kernels[r.k].ms += ms;
+        W.stats.kernels[r.k].launches++;
+        W.stats.kernels[r.k].algo_bytes += r.bytes;
+    }
     return FSV_OK;
 }
 

@@ -184,12 +184,22 @@ int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_par
 
 /* Optional per-stage counters of the last fsv_assemble_batch on this context (for the roofline accounting):
  * window tasks verified (K5), paths computed (K6), DP column steps, algorithmic bytes (SURVEY.md 8d model). */
+#define FSV_MAX_KERNEL_STATS 16
+typedef struct fsv_kernel_stat {
+    char     name[24];
+    double   ms;           /* summed HIP-event time of this kernel's launches on the context's stream */
+    uint64_t launches;
+    uint64_t algo_bytes;   /* compulsory bytes in + out of those launches (per-kernel table) */
+} fsv_kernel_stat;
+
 typedef struct fsv_asm_stats {
     uint64_t n_pairs, n_overlaps, n_windows, n_windows_matched, n_paths, n_path_dp;
-    uint64_t dp_columns;       /* K5 + rescue + K6 column steps */
+    uint64_t dp_columns;       /* K5 + K6 column steps (windows x their x_len) */
     uint64_t algo_bytes;       /* packed operand + result bytes of all DP tasks + reads in + contigs out */
     uint64_t n_exact_overlaps;
     double   ms_sketch, ms_chain, ms_verify, ms_path, ms_consensus, ms_final, ms_total;
+    uint32_t n_kernels, pad;
+    fsv_kernel_stat kernels[FSV_MAX_KERNEL_STATS];
 } fsv_asm_stats;
 int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out);
 
