@@ -522,9 +522,14 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     TRY(ensure(ctx, W.mz_cnt, (size_t)nr * 4));
     TRY(ensure(ctx, W.warn, (size_t)nr * 4));
     FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)nr * 4, ctx->stream));
-    hipLaunchKernelGGL(k_sketch, dim3(fsv_grid_for(nr, 64)), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
-                       (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, nr, P.w, P.k, 0,
-                       (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p);
+    FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)nr * 4, ctx->stream));
+    uint32_t max_words = 1; int w_max = 1;
+    for (uint32_t r = 0; r < nr; r++) { max_words = std::max<uint32_t>(max_words, (uint32_t)((len[r] + 15) / 16)); w_max = std::max<int>(w_max, wper[r]); }
+    const uint32_t lds_words = std::min<uint32_t>(max_words, 8192u);
+    FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(w_max, lds_words)));
+    hipLaunchKernelGGL(k_sketch, dim3(nr), dim3(64), sketch_lds_bytes(w_max, lds_words), ctx->stream, (const uint32_t *)W.store.p,
+                       (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p,
+                       (uint32_t *)W.mz_cnt.p, nr, P.w, P.k, 0, (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p, w_max, lds_words);
     FSV_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_uniq<ALN_AMAX>, dim3(nr), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (uint32_t *)W.mz_cnt.p,
                        (uint32_t *)W.warn.p);

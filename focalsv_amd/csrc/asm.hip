@@ -109,15 +109,18 @@ struct Batch {
 struct Geometry {
     std::vector<uint32_t> word_off, mz_off, gwin_off;
     uint64_t task_bound = 0;
+    uint32_t max_words = 1;
 };
 
 int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len, Geometry &G)
 {
     G.word_off.assign(B.n_reads + 1, 0); G.mz_off.assign(B.n_reads + 1, 0); G.gwin_off.assign(B.n_reads + 1, 0);
+    G.max_words = 1;
     uint64_t w = 0, m = 0, g = 0;
     for (uint32_t r = 0; r < B.n_reads; r++) {
         G.word_off[r] = (uint32_t)w; G.mz_off[r] = (uint32_t)m; G.gwin_off[r] = (uint32_t)g;
         w += (uint64_t)(len[r] + 15) / 16;
+        G.max_words = std::max<uint32_t>(G.max_words, (uint32_t)((len[r] + 15) / 16));
         m += (uint64_t)len[r] / 8 + 64;
         g += (uint64_t)(len[r] + FSV_WINDOW - 1) / FSV_WINDOW;
     }
@@ -144,9 +147,12 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     TRY(ensure(ctx, W.counters, 64));
     FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, 64, ctx->stream));
     W.kt.begin(ctx, KN_SKETCH, (uint64_t)G.word_off[B.n_reads] * 4 + (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz));
-    hipLaunchKernelGGL(k_sketch, dim3(fsv_grid_for(B.n_reads, 64)), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
+    FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+    const uint32_t lds_words = std::min<uint32_t>(G.max_words, 8192u);
+    FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(P.w, lds_words)));
+    hipLaunchKernelGGL(k_sketch, dim3(B.n_reads), dim3(64), sketch_lds_bytes(P.w, lds_words), ctx->stream, store, (const uint32_t *)W.word_off.p,
                        (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
-                       P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr);
+                       P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, P.w, lds_words);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
     W.kt.begin(ctx, KN_UNIQ, (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz) * 2);

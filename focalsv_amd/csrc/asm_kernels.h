@@ -46,50 +46,98 @@ __device__ __forceinline__ uint64_t mix64(uint64_t key)
     return key;
 }
 
-// One thread walks one read (the minimizer recurrence is sequential); the w-slot ring and the k-slot
-// run-length queue live in LDS, transposed ([slot][lane]) so that lanes never share a bank.
+// One wavefront per read.  The minimizer recurrence is sequential, but what it emits at a position only depends on
+// the w entries around it (and on the k HPC bases behind them), so every lane replays the reference recurrence over
+// its own 1/64 of the read plus a warm-up of w+k+4 homopolymer runs in front and w+2 runs behind, and keeps only the
+// minimizers whose end position falls inside its own slice.  Lanes whose warm-up reaches the read start replay it
+// exactly from base 0 (the l < w+k start-up rules matter only there).  The w-slot ring and the k-slot run-length
+// queue live in LDS, transposed ([slot][lane]) so that lanes never share a bank.  Output order is arbitrary (k_uniq sorts).
+// Dynamic LDS: [read words][w x 64 hashes][w x 64 metas][w x 64 spans][64 x 64 run lengths].
+__host__ __device__ inline size_t sketch_lds_bytes(int w, uint32_t read_words) { return (size_t)read_words * 4 + (size_t)w * 64 * 13 + 64 * 64 + 16; }
+
+struct WordCache { // sequential base access through one cached 16-base word
+    const uint32_t *p; uint32_t w; int idx;
+    __device__ __forceinline__ uint32_t get(int i) { const int wi = i >> 4; if (wi != idx) { w = p[wi]; idx = wi; } return (w >> ((i & 15) << 1)) & 3u; }
+};
+
 __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                                const int32_t *__restrict__ read_len, const uint32_t *__restrict__ mz_off,
                                                fsv_mz *__restrict__ mz, uint32_t *__restrict__ mz_cnt, uint32_t n_reads, int w, int k,
-                                               int hpc, uint32_t *__restrict__ warn, const uint8_t *__restrict__ w_per_read)
+                                               int hpc, uint32_t *__restrict__ warn, const uint8_t *__restrict__ w_per_read, int w_max,
+                                               uint32_t lds_words)
 {
-    __shared__ uint64_t r_hash[64][64];
-    __shared__ uint32_t r_meta[64][64]; // pos << 1 | rev
-    __shared__ uint16_t r_span[64][64];
-    __shared__ uint16_t q_run[64][64];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     const int lane = threadIdx.x;
-    const uint32_t r = blockIdx.x * 64 + lane;
+    const uint32_t r = blockIdx.x;
     if (r >= n_reads) return;
     const uint32_t woff = word_off[r];
     const int len = read_len[r];
     const uint32_t cap = mz_off[r + 1] - mz_off[r];
     fsv_mz *out = mz + mz_off[r];
     if (w_per_read) w = w_per_read[r];
+    // carve the dynamic LDS (8-byte items first)
+    uint64_t *r_hash = (uint64_t *)s_dyn;                               // [w_max][64]
+    uint32_t *s_words = (uint32_t *)(r_hash + (size_t)w_max * 64);      // [lds_words]
+    uint32_t *r_meta = s_words + lds_words;                             // [w_max][64]   pos << 1 | rev
+    uint8_t *r_span = (uint8_t *)(r_meta + (size_t)w_max * 64);         // [w_max][64]
+    uint8_t *q_run = r_span + (size_t)w_max * 64;                       // [64][64]      saturating run lengths
+#define R_HASH(j) r_hash[(j) * 64 + lane]
+#define R_META(j) r_meta[(j) * 64 + lane]
+#define R_SPAN(j) r_span[(j) * 64 + lane]
+#define Q_RUN(j) q_run[(j) * 64 + lane]
+    // stage the read in LDS when it fits: the replay fetches bases one dependent load after another
+    const uint32_t nwords = ((uint32_t)len + 15u) >> 4;
+    const bool staged = nwords <= lds_words;
+    if (staged) for (uint32_t i = lane; i < nwords; i += 64) s_words[i] = store[woff + i];
+    __syncthreads();
+    WordCache B{staged ? (const uint32_t *)s_words : store + woff, 0u, -1};
+    const int c0 = (int)((long long)len * lane / 64), c1 = (int)((long long)len * (lane + 1) / 64);
+    if (c1 <= c0) return;
+    // start of the replay: w+k+4 runs (bases when not compressing) in front of the slice, on a run boundary
+    int b0 = c0;
+    if (hpc) {
+        while (b0 > 0 && B.get(b0 - 1) == B.get(b0)) b0--;
+        for (int n = 0; n < w + k + 4 && b0 > 0; n++) {
+            b0--;
+            const uint32_t c = B.get(b0);
+            while (b0 > 0 && B.get(b0 - 1) == c) b0--;
+        }
+    } else {
+        b0 = max(0, c0 - (w + k + 4));
+    }
     const uint64_t NONE = ~0ull;
     const uint64_t mask = (1ull << k) - 1;
     uint64_t km0 = 0, km1 = 0, km2 = 0, km3 = 0;
     uint64_t best_h = NONE; uint32_t best_meta = 0; uint16_t best_span = 0;
-    int run_head = 0, run_cnt = 0, l = 0, slot = 0, best_slot = 0, span = 0;
-    uint32_t n = 0;
-    for (int j = 0; j < w; j++) { r_hash[j][lane] = NONE; r_meta[j][lane] = 0; r_span[j][lane] = 0; }
+    int run_head = 0, run_cnt = 0, slot = 0, best_slot = 0, span = 0;
+    int l = b0 > 0 ? w + k + 1 : 0; // past the start-up phase every "l >= ..." test of the reference holds
+    int tail = -1;                  // runs still to replay once the slice is done
+    for (int j = 0; j < w; j++) { R_HASH(j) = NONE; R_META(j) = 0; R_SPAN(j) = 0; }
 
 #define EMIT(H, M, S)                                                                                      \
     do {                                                                                                   \
-        if (n < cap) { fsv_mz m_; m_.hash = (H); m_.pos = (M) >> 1; m_.rev = (uint8_t)((M) & 1u); m_.span = (uint8_t)(S); m_.pad = 0; out[n] = m_; } \
-        n++;                                                                                               \
+        const int p_ = (int)((M) >> 1);                                                                    \
+        if (p_ >= c0 && p_ < c1) {                                                                         \
+            const uint32_t at_ = atomicAdd(&mz_cnt[r], 1u);                                                \
+            if (at_ < cap) { fsv_mz m_; m_.hash = (H); m_.pos = (uint32_t)p_; m_.rev = (uint8_t)((M) & 1u); m_.span = (uint8_t)(S); m_.pad = 0; out[at_] = m_; } \
+            else atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC);                                             \
+        }                                                                                                  \
     } while (0)
 
-    for (int i = 0; i < len; i++) {
-        const uint32_t c = fsv_base_fwd(store, woff, i);
+    int i = b0;
+    for (; i < len; i++) {
+        if (i >= c1) { if (tail < 0) tail = w + 2; if (tail-- == 0) break; }
+        const uint32_t c = B.get(i);
         uint64_t cur_h = NONE; uint32_t cur_meta = 0; uint16_t cur_span = 0;
         {
             if (hpc) {
                 int run = 1;
-                while (i + run < len && fsv_base_fwd(store, woff, i + run) == c) run++;
+                while (i + run < len && B.get(i + run) == c) run++;
                 i += run - 1;
-                q_run[(run_head + run_cnt++) & 63][lane] = (uint16_t)min(run, 65535);
-                span += run;
-                if (run_cnt > k) { span -= q_run[run_head][lane]; run_head = (run_head + 1) & 63; run_cnt--; }
+                const int rs = min(run, 255); // saturating: one run >= 255 puts the span at >= 256 (= no minimizer) either way
+                Q_RUN((run_head + run_cnt++) & 63) = (uint8_t)rs;
+                span += rs;
+                if (run_cnt > k) { span -= Q_RUN(run_head); run_head = (run_head + 1) & 63; run_cnt--; }
             } else {
                 span = l + 1 < k ? l + 1 : k;
             }
@@ -106,10 +154,10 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
                 cur_span = (uint16_t)span;
             }
         }
-        r_hash[slot][lane] = cur_h; r_meta[slot][lane] = cur_meta; r_span[slot][lane] = cur_span;
+        R_HASH(slot) = cur_h; R_META(slot) = cur_meta; R_SPAN(slot) = (uint8_t)cur_span;
         if (l == w + k - 1 && best_h != NONE) {
-            for (int j = slot + 1; j < w; j++) if (best_h == r_hash[j][lane] && r_meta[j][lane] != best_meta) EMIT(r_hash[j][lane], r_meta[j][lane], r_span[j][lane]);
-            for (int j = 0; j < slot; j++)     if (best_h == r_hash[j][lane] && r_meta[j][lane] != best_meta) EMIT(r_hash[j][lane], r_meta[j][lane], r_span[j][lane]);
+            for (int j = slot + 1; j < w; j++) if (best_h == R_HASH(j) && R_META(j) != best_meta) EMIT(R_HASH(j), R_META(j), R_SPAN(j));
+            for (int j = 0; j < slot; j++)     if (best_h == R_HASH(j) && R_META(j) != best_meta) EMIT(R_HASH(j), R_META(j), R_SPAN(j));
         }
         if (cur_h <= best_h) {
             if (l >= w + k && best_h != NONE) EMIT(best_h, best_meta, best_span);
@@ -117,19 +165,21 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
         } else if (slot == best_slot) {
             if (l >= w + k - 1 && best_h != NONE) EMIT(best_h, best_meta, best_span);
             best_h = NONE;
-            for (int j = slot + 1; j < w; j++) if (best_h >= r_hash[j][lane]) { best_h = r_hash[j][lane]; best_meta = r_meta[j][lane]; best_span = r_span[j][lane]; best_slot = j; }
-            for (int j = 0; j <= slot; j++)    if (best_h >= r_hash[j][lane]) { best_h = r_hash[j][lane]; best_meta = r_meta[j][lane]; best_span = r_span[j][lane]; best_slot = j; }
+            for (int j = slot + 1; j < w; j++) if (best_h >= R_HASH(j)) { best_h = R_HASH(j); best_meta = R_META(j); best_span = R_SPAN(j); best_slot = j; }
+            for (int j = 0; j <= slot; j++)    if (best_h >= R_HASH(j)) { best_h = R_HASH(j); best_meta = R_META(j); best_span = R_SPAN(j); best_slot = j; }
             if (l >= w + k - 1 && best_h != NONE) {
-                for (int j = slot + 1; j < w; j++) if (best_h == r_hash[j][lane] && best_meta != r_meta[j][lane]) EMIT(r_hash[j][lane], r_meta[j][lane], r_span[j][lane]);
-                for (int j = 0; j <= slot; j++)    if (best_h == r_hash[j][lane] && best_meta != r_meta[j][lane]) EMIT(r_hash[j][lane], r_meta[j][lane], r_span[j][lane]);
+                for (int j = slot + 1; j < w; j++) if (best_h == R_HASH(j) && best_meta != R_META(j)) EMIT(R_HASH(j), R_META(j), R_SPAN(j));
+                for (int j = 0; j <= slot; j++)    if (best_h == R_HASH(j) && best_meta != R_META(j)) EMIT(R_HASH(j), R_META(j), R_SPAN(j));
             }
         }
         if (++slot == w) slot = 0;
     }
-    if (best_h != NONE) EMIT(best_h, best_meta, best_span);
+    if (i >= len && best_h != NONE) EMIT(best_h, best_meta, best_span); // the read's last window (sketch.cpp:134-135)
 #undef EMIT
-    if (n > cap) { atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = cap; }
-    mz_cnt[r] = n;
+#undef R_HASH
+#undef R_META
+#undef R_SPAN
+#undef Q_RUN
 }
 
 // ------------------------------------------------------------------------------------------------ k_uniq
@@ -144,7 +194,7 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
     fsv_mz *a = mz + mz_off[r];
-    uint32_t n = mz_cnt[r];
+    uint32_t n = min(mz_cnt[r], mz_off[r + 1] - mz_off[r]); // k_sketch counts past the cap when it truncates
     if (n > UQ_MAX) { if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = UQ_MAX; }
     uint32_t np = 1;
     while (np < n) np <<= 1;
