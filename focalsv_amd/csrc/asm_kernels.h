@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
 {
     __shared__ uint64_t s_key[FSV_AMAX];  // qe << 32 | te   (raw te first, strand-corrected later)
     __shared__ uint16_t s_aux[FSV_AMAX];  // t span | strand << 8 ; later: predecessor index
-    __shared__ int32_t s_f[FSV_AMAX], s_ind[FSV_AMAX], s_sl[FSV_AMAX];
+    __shared__ __attribute__((aligned(8))) int32_t s_dp[3 * FSV_AMAX]; // s_f | s_ind | s_sl ; the first two double as the staged t hashes
+    int32_t *const s_f = s_dp, *const s_ind = s_dp + FSV_AMAX, *const s_sl = s_dp + 2 * FSV_AMAX;
     __shared__ uint16_t s_chain[FSV_AMAX];
     const int lane = threadIdx.x;
     const uint32_t p = blockIdx.x;
@@ -294,7 +295,12 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     o.q = q; o.t = t; o.x_s = o.x_e = o.y_s = o.y_e = 0; o.score = 0; o.n_chain = 0; o.chain_off = 0; o.first_win = 0; o.n_win = 0;
     o.align_len = 0; o.err_sum = 0; o.rev = 0; o.is_match = 0; o.exact = 0; o.valid = 0;
 
-    // 1. anchors: binary-search every q minimizer in t's sorted unique list
+    // 1. anchors: every q minimizer is looked up in t's sorted unique list; t's hashes are staged in LDS (s_f/s_ind are
+    //    free until the DP) so that the ~10 probes per lookup are LDS reads instead of dependent global loads
+    uint64_t *s_th = (uint64_t *)s_dp;
+    const bool t_in_lds = nt <= FSV_AMAX;
+    if (t_in_lds) for (int i = lane; i < nt; i += 64) s_th[i] = mt[i].hash;
+    __syncthreads();
     int n = 0, nrev = 0, nfwd = 0;
     for (int base = 0; base < nq; base += 64) {
         int i = base + lane;
@@ -302,10 +308,11 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         if (i < nq) {
             fsv_mz a = mq[i];
             int l2 = 0, h2 = nt;
-            while (l2 < h2) { int mid = (l2 + h2) >> 1; if (mt[mid].hash < a.hash) l2 = mid + 1; else h2 = mid; }
-            if (l2 < nt) {
+            if (t_in_lds) { while (l2 < h2) { int mid = (l2 + h2) >> 1; if (s_th[mid] < a.hash) l2 = mid + 1; else h2 = mid; } }
+            else { while (l2 < h2) { int mid = (l2 + h2) >> 1; if (mt[mid].hash < a.hash) l2 = mid + 1; else h2 = mid; } }
+            if (l2 < nt && (t_in_lds ? s_th[l2] : mt[l2].hash) == a.hash) {
                 fsv_mz b = mt[l2];
-                if (b.hash == a.hash) { hit = true; key = (uint64_t)a.pos << 32 | b.pos; aux = (uint16_t)(b.span | ((a.rev ^ b.rev) << 8)); }
+                hit = true; key = (uint64_t)a.pos << 32 | b.pos; aux = (uint16_t)(b.span | ((a.rev ^ b.rev) << 8));
             }
         }
         uint64_t m = __ballot(hit);
@@ -505,42 +512,54 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     const fsv_wtask t = tasks[tid];
     const fsv_wres r = res[tid];
     fsv_wpath *P = paths + tid;
-    P->state = 0;
-    if (r.err < 0 || !ovl[t.ovl].is_match) return;
+    if (r.err < 0 || !ovl[t.ovl].is_match) { P->state = 0; return; }
     const int n = t.x_len;
     const int start = r.end_site - n + 1;
-    bool ok = false;
-    int err = r.err;
-    if (r.err == 0) ok = true;
-    else if (start >= 0) {
+    // mismatch map of the gap-free placement, 16 columns per word; field value 1 == op "mismatch"
+    uint32_t ops32[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) ops32[i] = 0;
+    bool ok = r.err == 0;
+    if (!ok && start >= 0) {
         int mm = 0;
-        for (int i = 0; i < n && mm <= r.err; i++) mm += (fsv_base_fwd(store, t.x_word, t.x_start + i) != task_ybase(store, t, start + i));
+        const int win0 = t.y_start - t.k;
+#pragma unroll
+        for (int b = 0; b < 24; b++) {
+            if (b * 16 < n) {
+                const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + b * 16);
+                const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + start + b * 16);
+                uint32_t d = xb ^ yb.bits;
+                d = (d | (d >> 1)) & 0x55555555u;
+                // columns outside the read ('N') never match; columns past the window do not count
+                uint32_t inval = ~yb.valid & 0xffffu, spread = 0;
+                for (int j = 0; j < 16; j++) spread |= ((inval >> j) & 1u) << (2 * j);
+                d |= spread;
+                const int lim = min(16, n - b * 16);
+                if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+                ops32[b] = d;
+                mm += __popc(d);
+            }
+        }
         ok = (mm == r.err);
     }
     if (!ok) {
         P->state = 2;
-        uint32_t at = atomicAdd(dp_count, 1u);
-        dp_list[at] = tid;
+        dp_list[atomicAdd(dp_count, 1u)] = tid;
         return;
     }
-    // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops and
-    // moves the y interval inwards; there are no gaps to shift.
+    // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops (3) and
+    // moves the y interval inwards -- the alignment end first, then its start; there are no gaps to shift.
     int s2 = start, e2 = r.end_site;
-    uint8_t ops[112];
-    for (int i = 0; i < 112; i++) ops[i] = 0;
-    if (err > 0) {
-        for (int i = 0; i < n; i++) {
-            uint32_t mmf = fsv_base_fwd(store, t.x_word, t.x_start + i) != task_ybase(store, t, start + i);
-            if (mmf) ops_set(ops, i, 1u);
-        }
-        // same order as the reference: the alignment end first, then its start
-        for (int i = n - 1; i >= 0 && ops_get(ops, i) == 1u; i--) { ops_set(ops, i, 3u); e2--; }
-        for (int i = 0; i < n && ops_get(ops, i) == 1u; i++) { ops_set(ops, i, 3u); s2++; }
+    if (r.err > 0) {
+        for (int i = n - 1; i >= 0 && ((ops32[i >> 4] >> ((i & 15) << 1)) & 3u) == 1u; i--) { ops32[i >> 4] |= 3u << ((i & 15) << 1); e2--; }
+        for (int i = 0; i < n && ((ops32[i >> 4] >> ((i & 15) << 1)) & 3u) == 1u; i++) { ops32[i >> 4] |= 3u << ((i & 15) << 1); s2++; }
     }
     P->ry_start = t.y_start - t.k + s2;
     P->ry_end = t.y_start - t.k + e2;
-    P->path_len = (int16_t)n; P->err = (int16_t)err; P->state = 1;
-    for (int i = 0; i < 112; i++) P->ops[i] = ops[i];
+    P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1;
+    uint4 *dst = reinterpret_cast<uint4 *>(P->ops);
+#pragma unroll
+    for (int i = 0; i < 7; i++) dst[i] = make_uint4(ops32[4 * i], ops32[4 * i + 1], ops32[4 * i + 2], ops32[4 * i + 3]);
 }
 
 // Full K6: forward pass keeping {D0, VP, VN} per column in a per-lane slice of an HBM scratch
@@ -665,6 +684,8 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     __shared__ uint32_t s_evn, s_cover;
     __shared__ uint8_t s_out[FSV_WINDOW][14]; // per column: [0] = n bytes, then bytes
     __shared__ uint32_t s_scan[64];
+    __shared__ uint32_t s_path[64][29];       // per lane: the 28 op words of its window path (stride 29: no bank conflicts)
+    __shared__ uint32_t s_yw[64][29];         // per lane: y bases ry_start-16 .. ry_start+431 as 28 fetched 16-base words
     const int lane = threadIdx.x;
     const uint32_t gw = blockIdx.x;
     if (gw >= n_gwin) return;
@@ -691,6 +712,16 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         if (P->state != 1) continue;
         const fsv_wtask t = A.tasks[ti];
         atomicAdd(&s_cover, 1u);
+        // stage this lane's path ops and y bases in LDS: the walk below is a chain of dependent reads
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(P->ops);
+#pragma unroll
+            for (int i = 0; i < 7; i++) { const uint4 v = src[i]; s_path[lane][4 * i] = v.x; s_path[lane][4 * i + 1] = v.y; s_path[lane][4 * i + 2] = v.z; s_path[lane][4 * i + 3] = v.w; }
+        }
+        const int ybase0 = P->ry_start - 16;
+        for (int b = 0; b < 28; b++) s_yw[lane][b] = fetch16(A.store, t.y_word, t.y_len, t.y_rev, ybase0 + 16 * b).bits;
+#define YB(q) ((s_yw[lane][((q) - ybase0) >> 4] >> ((((q) - ybase0) & 15) << 1)) & 3u)
+#define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
         int xp = t.x_start - gs, yp = P->ry_start;
         bool pend = false;
         if (j > 0 && A.paths[ti - 1].state == 1) {
@@ -699,7 +730,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                 pend = true;
                 if (gap <= FSV_INS_MAXLEN) {
                     uint32_t key = (uint32_t)gap << 24;
-                    for (int b = 0; b < gap; b++) key |= fsv_base_at(A.store, t.y_word, t.y_len, t.y_rev, P->ry_start - gap + b) << (2 * b);
+                    for (int b = 0; b < gap; b++) key |= YB(P->ry_start - gap + b) << (2 * b);
                     uint32_t e = atomicAdd(&s_evn, 1u);
                     if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
                 }
@@ -707,15 +738,15 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         }
         const int plen = P->path_len;
         for (int p = 0; p < plen;) {
-            const uint32_t op = ops_get(P->ops, p);
+            const uint32_t op = OP(p);
             if (op == 2u) {
                 int L = 0;
-                while (p + L < plen && ops_get(P->ops, p + L) == 2u) L++;
+                while (p + L < plen && OP(p + L) == 2u) L++;
                 if (xp < glen) {
                     pend = true;
                     if (L <= FSV_INS_MAXLEN) {
                         uint32_t key = (uint32_t)L << 24;
-                        for (int b = 0; b < L; b++) key |= fsv_base_at(A.store, t.y_word, t.y_len, t.y_rev, yp + b) << (2 * b);
+                        for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
                         uint32_t e = atomicAdd(&s_evn, 1u);
                         if (e < FSV_EV_CAP) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
                     }
@@ -726,9 +757,11 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
             atomicAdd(&s_cnt[xp][5], 1u);
             if (pend) { atomicAdd(&s_cnt[xp][6], 1u); pend = false; }
             if (op == 3u) atomicAdd(&s_cnt[xp][4], 1u);
-            else { atomicAdd(&s_cnt[xp][fsv_base_at(A.store, t.y_word, t.y_len, t.y_rev, yp)], 1u); yp++; }
+            else { atomicAdd(&s_cnt[xp][YB(yp)], 1u); yp++; }
             xp++; p++;
         }
+#undef YB
+#undef OP
     }
     __syncthreads();
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;

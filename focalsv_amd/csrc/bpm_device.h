@@ -63,6 +63,54 @@ __device__ __forceinline__ int bpm_pick_end(const BpmState &s, int err, int n, i
     return best < 0 ? -1 : site;
 }
 
+// ---- 16-base stream fetch -----------------------------------------------------------------------------------
+// 16 consecutive strand positions p..p+15 of a read as one word (base j in bits 2j..2j+1) plus a validity mask
+// (bit j set when p+j lies inside the read).  All lanes of a wavefront fetch at the same loop trip, so the loads
+// are uniform and can be issued one block ahead of their use; per-base global loads stalled every DP column.
+struct Bases16 { uint32_t bits, valid; };
+
+__device__ __forceinline__ uint32_t rev_fields2(uint32_t x)
+{
+    x = __brev(x);                                             // reverses bit order: field order reversed, bits inside a field swapped
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); // swap the two bits of every field back
+}
+
+__device__ __forceinline__ uint32_t load_fwd16(const uint32_t *__restrict__ w, int nwords, int f)
+{
+    // forward bases f..f+15 (f may be negative or run past the end: missing words read as 0)
+    const int a = f >> 4, sh = (f & 15) << 1;
+    const uint32_t w0 = (a >= 0 && a < nwords) ? w[a] : 0u;
+    const uint32_t w1 = (a + 1 >= 0 && a + 1 < nwords) ? w[a + 1] : 0u;
+    return sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
+}
+
+__device__ __forceinline__ uint32_t range_mask16(int p, int len)
+{
+    // bit j set iff 0 <= p + j < len
+    const int lo = max(0, -p), hi = min(16, len - p);
+    return hi > lo ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+}
+
+__device__ __forceinline__ Bases16 fetch16(const uint32_t *__restrict__ store, uint32_t word_off, int len, int rev, int p)
+{
+    Bases16 r;
+    const uint32_t *w = store + word_off;
+    const int nwords = (len + 15) >> 4;
+    r.valid = range_mask16(p, len);
+    if (!rev) r.bits = load_fwd16(w, nwords, p);
+    else r.bits = ~rev_fields2(load_fwd16(w, nwords, len - 16 - p)); // strand base j = complement of forward base len-1-p-j
+    return r;
+}
+
+// x windows always lie inside their read: no validity, no strand
+__device__ __forceinline__ uint32_t fetch16_x(const uint32_t *__restrict__ store, uint32_t word_off, int p)
+{
+    const uint32_t *w = store + word_off;
+    const int a = p >> 4, sh = (p & 15) << 1;
+    const uint32_t w0 = w[a], w1 = w[a + 1]; // the store keeps 4 words of slack behind the last read
+    return sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
+}
+
 // Column sink for K6: called once per DP column with that column's D0 and the post-update VP/VN.
 struct BpmNoSink {
     __device__ __forceinline__ void operator()(int, uint64_t, uint64_t, uint64_t) const {}
@@ -76,27 +124,41 @@ __device__ __forceinline__ void bpm_run(const uint32_t *__restrict__ store, cons
     const int win0 = t.y_start - k;
     BpmState s;
     s.eq0 = s.eq1 = s.eq2 = s.eq3 = 0; s.vp = 0; s.vn = 0;
-    for (int b = 0; b <= 2 * k; b++) bpm_eq_set(s, bpm_ywin_base(store, t, win0, b), 1ull << b);
+    for (int b16 = 0; b16 <= 2 * k; b16 += 16) {
+        const Bases16 y = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + b16);
+        for (int j = 0; j < 16 && b16 + j <= 2 * k; j++)
+            if ((y.valid >> j) & 1u) bpm_eq_set(s, (y.bits >> (2 * j)) & 3u, 1ull << (b16 + j));
+    }
     const uint64_t top = 1ull << (2 * k);
     int err = 0;
-    for (int i = 0; i < n; i++) {
-        uint32_t c = fsv_base_fwd(store, t.x_word, t.x_start + i);
-        uint64_t x = bpm_pick_eq(s, c) | s.vn;
-        uint64_t d0 = ((s.vp + (x & s.vp)) ^ s.vp) | x;
-        uint64_t hn = s.vp & d0;
-        uint64_t hp = s.vn | ~(s.vp | d0);
-        uint64_t sh = d0 >> 1;
-        s.vn = sh & hp;
-        s.vp = hn | ~(sh | hp);
-        if (!(d0 & 1ull)) {
-            ++err;
-            if (err - 2 * k > k) return; // Levenshtein_distance.h:367-375
+    uint32_t xb = fetch16_x(store, t.x_word, t.x_start);
+    Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1);
+    for (int blk = 0; blk < n; blk += 16) {
+        // next block's operands are requested before this block's 16 columns are computed
+        const uint32_t xn = fetch16_x(store, t.x_word, t.x_start + blk + 16);
+        const Bases16 yn = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1 + blk + 16);
+        const int lim = min(16, n - blk);
+        for (int j = 0; j < lim; j++) {
+            const int i = blk + j;
+            const uint32_t c = (xb >> (2 * j)) & 3u;
+            uint64_t x = bpm_pick_eq(s, c) | s.vn;
+            uint64_t d0 = ((s.vp + (x & s.vp)) ^ s.vp) | x;
+            uint64_t hn = s.vp & d0;
+            uint64_t hp = s.vn | ~(s.vp | d0);
+            uint64_t sh = d0 >> 1;
+            s.vn = sh & hp;
+            s.vp = hn | ~(sh | hp);
+            if (!(d0 & 1ull)) {
+                ++err;
+                if (err - 2 * k > k) return; // Levenshtein_distance.h:367-375
+            }
+            sink(i, d0, s.vp, s.vn);
+            if (i + 1 < n) {
+                s.eq0 >>= 1; s.eq1 >>= 1; s.eq2 >>= 1; s.eq3 >>= 1;
+                if ((yb.valid >> j) & 1u) bpm_eq_set(s, (yb.bits >> (2 * j)) & 3u, top);
+            }
         }
-        sink(i, d0, s.vp, s.vn);
-        if (i + 1 < n) {
-            s.eq0 >>= 1; s.eq1 >>= 1; s.eq2 >>= 1; s.eq3 >>= 1;
-            bpm_eq_set(s, bpm_ywin_base(store, t, win0, i + 1 + 2 * k), top);
-        }
+        xb = xn; yb = yn;
     }
     int best;
     r.end_site = bpm_pick_end(s, err, n, k, best);
