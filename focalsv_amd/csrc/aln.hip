@@ -118,8 +118,8 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
         }
         // scores can drop below zero here (gap penalty), so bias before packing; lanes without a legal predecessor sit out
         const bool legal = ok;
-        const long long mine = legal ? ((long long)(cand + (1 << 20)) * 64 + (63 - lane)) : -1;
-        const long long bestp = wave_max_i64(mine);
+        const int mine = legal ? ((cand + (1 << 20)) * 64 + (63 - lane)) : -1; // < 2^27
+        const int bestp = wave_max_i32(mine);
         const int bests = bestp < 0 ? -(1 << 30) : (int)(bestp >> 6) - (1 << 20);
         if (bests > P.k) { if (mine == bestp) { s_f[i] = bests; s_aux[i] = (uint16_t)j; } }
         else if (lane == 0) { s_f[i] = P.k; s_aux[i] = 0xffff; }

@@ -20,7 +20,7 @@
 #define FSV_PATH_CAP    448  // ops per window path (x_len + k + slack)
 #define FSV_CW_STRIDE   448  // bytes reserved per corrected grid window
 #define FSV_INS_MAXLEN   12
-#define FSV_EV_CAP     2048  // insertion events per grid window
+#define FSV_EV_CAP     1024  // insertion events per grid window
 
 struct fsv_wpath {           // 128 bytes per window task
     int32_t ry_start, ry_end;   // absolute strand coordinates of the aligned y interval
@@ -236,10 +236,18 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
 }
 
 // ------------------------------------------------------------------------------------------------ k_chain
+// wave-wide max, uniform result.  __shfl_xor goes through the LDS crossbar (ds_bpermute, ~6 dependent round trips);
+// DPP row operations reduce each 16-lane row in four VALU ops and the four row results are read as scalars.
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-    return v;
+    const int lowest = -2147483647 - 1;
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x141, 0xF, 0xF, false)); // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x140, 0xF, 0xF, false)); // row_mirror
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
 }
 __device__ __forceinline__ long long wave_max_i64(long long v)
 {
@@ -676,9 +684,15 @@ __device__ __forceinline__ bool vote_wins(int cnt, int total, bool homo)
     return homo && cnt * 1000 >= total * 515;
 }
 
+#define FSV_VOTE_STRIDE 380 // bytes per vote row (375 columns + pad; 95 words: odd, so rows start on different banks)
+
 __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
 {
-    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][7];
+    // Votes are NOT accumulated with LDS atomics: the lanes walk their paths in lock-step, so all of them would hit
+    // the same column counters at once and serialise.  Every lane (= one overlap) fills its own row of per-column vote
+    // bytes; afterwards the lanes switch roles, take columns, and tally the rows.
+    //   vote byte: 0xff = this overlap does not cover the column; else bits 0-2 = A C G T / 4 deleted, bit 3 = arrived after an insertion
+    __shared__ uint8_t s_vote[64][FSV_VOTE_STRIDE];
     __shared__ uint16_t s_evcol[FSV_EV_CAP];
     __shared__ uint32_t s_evkey[FSV_EV_CAP];
     __shared__ uint32_t s_evn, s_cover;
@@ -699,84 +713,122 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     const uint32_t xw = A.word_off[r];
     const uint32_t s = A.read_set[r], r0 = A.set_start[s], ns = A.set_start[s + 1] - r0, q = r - r0;
     const uint32_t pbase = A.pair_base[s] + q * (ns - 1);
-    for (int i = lane; i < (FSV_WINDOW + 1) * 7; i += 64) (&s_cnt[0][0])[i] = 0;
     if (lane == 0) { s_evn = 0; s_cover = 0; }
     __syncthreads();
-    for (uint32_t oi = lane; oi < ns - 1; oi += 64) {
-        const fsv_ovl o = A.ovl[pbase + oi];
-        if (!o.valid || !o.is_match) continue;
-        const int j = g - o.x_s / FSV_WINDOW;
-        if (j < 0 || j >= o.n_win) continue;
-        const uint32_t ti = (uint32_t)o.first_win + (uint32_t)j;
-        const fsv_wpath *P = A.paths + ti;
-        if (P->state != 1) continue;
-        const fsv_wtask t = A.tasks[ti];
-        atomicAdd(&s_cover, 1u);
-        // stage this lane's path ops and y bases in LDS: the walk below is a chain of dependent reads
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(P->ops);
+    // sets with more than 65 reads need several passes over the vote rows; counts are carried in registers
+    const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
+    uint32_t cnt[6][7]; // up to 6 columns per lane (375 / 64 rounded up), 7 counters each
 #pragma unroll
-            for (int i = 0; i < 7; i++) { const uint4 v = src[i]; s_path[lane][4 * i] = v.x; s_path[lane][4 * i + 1] = v.y; s_path[lane][4 * i + 2] = v.z; s_path[lane][4 * i + 3] = v.w; }
-        }
-        const int ybase0 = P->ry_start - 16;
-        for (int b = 0; b < 28; b++) s_yw[lane][b] = fetch16(A.store, t.y_word, t.y_len, t.y_rev, ybase0 + 16 * b).bits;
-#define YB(q) ((s_yw[lane][((q) - ybase0) >> 4] >> ((((q) - ybase0) & 15) << 1)) & 3u)
-#define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
-        int xp = t.x_start - gs, yp = P->ry_start;
-        bool pend = false;
-        if (j > 0 && A.paths[ti - 1].state == 1) {
-            const int gap = P->ry_start - A.paths[ti - 1].ry_end - 1;
-            if (gap > 0 && xp == 0) {
-                pend = true;
-                if (gap <= FSV_INS_MAXLEN) {
-                    uint32_t key = (uint32_t)gap << 24;
-                    for (int b = 0; b < gap; b++) key |= YB(P->ry_start - gap + b) << (2 * b);
-                    uint32_t e = atomicAdd(&s_evn, 1u);
-                    if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
-                }
-            }
-        }
-        const int plen = P->path_len;
-        for (int p = 0; p < plen;) {
-            const uint32_t op = OP(p);
-            if (op == 2u) {
-                int L = 0;
-                while (p + L < plen && OP(p + L) == 2u) L++;
-                if (xp < glen) {
-                    pend = true;
-                    if (L <= FSV_INS_MAXLEN) {
-                        uint32_t key = (uint32_t)L << 24;
-                        for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
-                        uint32_t e = atomicAdd(&s_evn, 1u);
-                        if (e < FSV_EV_CAP) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int k2 = 0; k2 < 7; k2++) cnt[i][k2] = 0;
+    for (uint32_t obase = 0; obase < ns - 1; obase += 64) {
+        const uint32_t oi = obase + lane;
+        bool active = false;
+        for (int c = lane; c < 64 * (FSV_VOTE_STRIDE / 4); c += 64) ((uint32_t *)&s_vote[0][0])[c] = 0xffffffffu;
+        __syncthreads();
+        if (oi < ns - 1) {
+            const fsv_ovl o = A.ovl[pbase + oi];
+            const int j = g - o.x_s / FSV_WINDOW;
+            if (o.valid && o.is_match && j >= 0 && j < o.n_win) {
+                const uint32_t ti = (uint32_t)o.first_win + (uint32_t)j;
+                const fsv_wpath *P = A.paths + ti;
+                if (P->state == 1) {
+                    active = true;
+                    const fsv_wtask t = A.tasks[ti];
+                    {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(P->ops);
+#pragma unroll
+                        for (int i = 0; i < 7; i++) { const uint4 v = src[i]; s_path[lane][4 * i] = v.x; s_path[lane][4 * i + 1] = v.y; s_path[lane][4 * i + 2] = v.z; s_path[lane][4 * i + 3] = v.w; }
                     }
-                }
-                yp += L; p += L;
-                continue;
-            }
-            atomicAdd(&s_cnt[xp][5], 1u);
-            if (pend) { atomicAdd(&s_cnt[xp][6], 1u); pend = false; }
-            if (op == 3u) atomicAdd(&s_cnt[xp][4], 1u);
-            else { atomicAdd(&s_cnt[xp][YB(yp)], 1u); yp++; }
-            xp++; p++;
-        }
+                    const int ry_start = P->ry_start, plen = P->path_len;
+                    const int ybase0 = ry_start - 16;
+                    for (int b = 0; b < 28; b++) s_yw[lane][b] = fetch16(A.store, t.y_word, t.y_len, t.y_rev, ybase0 + 16 * b).bits;
+#define YB(qq) ((s_yw[lane][((qq) - ybase0) >> 4] >> ((((qq) - ybase0) & 15) << 1)) & 3u)
+#define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
+                    int xp = t.x_start - gs, yp = ry_start;
+                    bool pend = false;
+                    if (j > 0 && A.paths[ti - 1].state == 1) {
+                        const int gap = ry_start - A.paths[ti - 1].ry_end - 1;
+                        if (gap > 0 && xp == 0) {
+                            pend = true;
+                            if (gap <= FSV_INS_MAXLEN) {
+                                uint32_t key = (uint32_t)gap << 24;
+                                for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
+                                uint32_t e = atomicAdd(&s_evn, 1u);
+                                if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
+                            }
+                        }
+                    }
+                    for (int p = 0; p < plen;) {
+                        const uint32_t op = OP(p);
+                        if (op == 2u) {
+                            int L = 0;
+                            while (p + L < plen && OP(p + L) == 2u) L++;
+                            if (xp < glen) {
+                                pend = true;
+                                if (L <= FSV_INS_MAXLEN) {
+                                    uint32_t key = (uint32_t)L << 24;
+                                    for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
+                                    uint32_t e = atomicAdd(&s_evn, 1u);
+                                    if (e < FSV_EV_CAP) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
+                                }
+                            }
+                            yp += L; p += L;
+                            continue;
+                        }
+                        uint32_t v = pend ? 8u : 0u;
+                        pend = false;
+                        if (op == 3u) v |= 4u;
+                        else { v |= YB(yp); yp++; }
+                        s_vote[lane][xp] = (uint8_t)v;
+                        xp++; p++;
+                    }
 #undef YB
 #undef OP
+                }
+            }
+        }
+        const uint64_t am = __ballot(active);
+        if (lane == 0) s_cover += (uint32_t)__popcll(am);
+        __syncthreads();
+        // tally: this lane's columns over the rows that were filled in this pass
+#pragma unroll
+        for (int ci = 0; ci < 6; ci++) {
+            const int c = c0 + ci;
+            if (c < c1) {
+                uint64_t m = am;
+                while (m) {
+                    const int row = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const uint32_t v = s_vote[row][c];
+                    if (v != 0xffu) {
+                        const uint32_t code = v & 7u;
+#pragma unroll
+                        for (int b = 0; b < 5; b++) cnt[ci][b] += (code == (uint32_t)b);
+                        cnt[ci][5]++; cnt[ci][6] += (v >> 3) & 1u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
     const bool verbatim = s_cover < 3u;
     const uint32_t evn = min(s_evn, (uint32_t)FSV_EV_CAP);
     if (s_evn > FSV_EV_CAP && lane == 0) atomicOr(&A.warn[r], 8u);
     // per-column decision
-    for (int c = lane; c < glen; c += 64) {
+#pragma unroll
+    for (int ci = 0; ci < 6; ci++) {
+        const int c = c0 + ci;
+        if (c >= c1) continue;
         const uint32_t own = fsv_base_fwd(A.store, xw, gs + c);
         uint8_t nb = 0;
         if (verbatim) { s_out[c][1] = (uint8_t)own; nb = 1; }
         else {
             const int p = gs + c;
             bool homo = (p > 0 && fsv_base_fwd(A.store, xw, p - 1) == own) || (p + 1 < xlen && fsv_base_fwd(A.store, xw, p + 1) == own);
-            const int arrived = (int)s_cnt[c][5], instot = (int)s_cnt[c][6];
+            const int arrived = (int)cnt[ci][5], instot = (int)cnt[ci][6];
             if (instot) {
                 int bc = 0; uint32_t bk = 0;
                 for (uint32_t i = 0; i < evn; i++) {
@@ -793,10 +845,13 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                 }
             }
             int v[5];
-            for (int b = 0; b < 5; b++) v[b] = (int)s_cnt[c][b];
-            v[own]++;
+#pragma unroll
+            for (int b = 0; b < 5; b++) v[b] = (int)cnt[ci][b] + (own == (uint32_t)b);
             const int total = v[0] + v[1] + v[2] + v[3] + v[4];
-            int bestb = (int)own, bestc = v[own];
+            int bestb = (int)own, bestc = 0;
+#pragma unroll
+            for (int b = 0; b < 5; b++) if ((int)own == b) bestc = v[b];
+#pragma unroll
             for (int b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
             if (bestb != (int)own && !vote_wins(bestc, total, homo)) bestb = (int)own;
             if (bestb < 4) s_out[c][1 + nb++] = (uint8_t)bestb;
@@ -804,8 +859,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         s_out[c][0] = nb;
     }
     __syncthreads();
-    // output offsets: each lane owns a contiguous chunk of columns
-    const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
+    // output offsets: each lane owns the contiguous chunk of columns [c0, c1)
     uint32_t mine = 0;
     for (int c = c0; c < c1; c++) mine += s_out[c][0];
     s_scan[lane] = mine;
