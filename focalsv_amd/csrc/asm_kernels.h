@@ -17,7 +17,7 @@
 
 #define FSV_AMAX       1024  // anchors per read pair held in LDS
 #define FSV_UQ_MAX     4096  // minimizers per read sorted in LDS
-#define FSV_PATH_CAP    448  // ops per window path (x_len + k + slack)
+#define FSV_PATH_CAP    416  // ops per window path: x_len (<= 375) + y-only ops (<= k <= 31)
 #define FSV_CW_STRIDE   448  // bytes reserved per corrected grid window
 #define FSV_INS_MAXLEN   12
 #define FSV_EV_CAP     1024  // insertion events per grid window
@@ -26,8 +26,11 @@ struct fsv_wpath {           // 128 bytes per window task
     int32_t ry_start, ry_end;   // absolute strand coordinates of the aligned y interval
     int16_t path_len, err;
     uint8_t state;              // 0 none, 1 path present, 2 queued for DP
-    uint8_t pad[3];
-    uint8_t ops[112];           // 2-bit ops start-to-end: 0 match 1 mismatch 2 y-only 3 x-only
+    uint8_t y_rev;
+    uint16_t pad;
+    uint32_t y_word;            // where to find read y (the consensus fetches y bases only at mismatches / insertions)
+    int32_t y_len;
+    uint8_t ops[104];           // 2-bit ops start-to-end: 0 match 1 mismatch 2 y-only 3 x-only
 };
 static_assert(sizeof(fsv_wpath) == 128, "fsv_wpath layout");
 
@@ -524,9 +527,9 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     const int n = t.x_len;
     const int start = r.end_site - n + 1;
     // mismatch map of the gap-free placement, 16 columns per word; field value 1 == op "mismatch"
-    uint32_t ops32[28];
+    uint32_t ops32[26];
 #pragma unroll
-    for (int i = 0; i < 28; i++) ops32[i] = 0;
+    for (int i = 0; i < 26; i++) ops32[i] = 0;
     bool ok = r.err == 0;
     if (!ok && start >= 0) {
         int mm = 0;
@@ -564,10 +567,10 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     }
     P->ry_start = t.y_start - t.k + s2;
     P->ry_end = t.y_start - t.k + e2;
-    P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1;
-    uint4 *dst = reinterpret_cast<uint4 *>(P->ops);
+    P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
+    uint2 *dst = reinterpret_cast<uint2 *>(P->ops); // ops sit at byte 24 of the record: 8-byte aligned
 #pragma unroll
-    for (int i = 0; i < 7; i++) dst[i] = make_uint4(ops32[4 * i], ops32[4 * i + 1], ops32[4 * i + 2], ops32[4 * i + 3]);
+    for (int i = 0; i < 13; i++) dst[i] = make_uint2(ops32[2 * i], ops32[2 * i + 1]);
 }
 
 // Full K6: forward pass keeping {D0, VP, VN} per column in a per-lane slice of an HBM scratch
@@ -645,14 +648,16 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
             if (op == 2) yi++; else xi++;
         }
     }
-    uint8_t ops[112];
-    for (int i = 0; i < 112; i++) ops[i] = 0;
     const int pl = min(plen, FSV_PATH_CAP);
-    for (int i = 0; i < pl; i++) ops_set(ops, i, TMP(plen - 1 - i));
+    uint32_t *dst = reinterpret_cast<uint32_t *>(P->ops);
+    for (int wd = 0; wd < 26; wd++) {
+        uint32_t v = 0;
+        for (int f = 0; f < 16; f++) { const int i = wd * 16 + f; if (i < pl) v |= (uint32_t)TMP(plen - 1 - i) << (2 * f); }
+        dst[wd] = v;
+    }
     P->ry_start = t.y_start - t.k + start;
     P->ry_end = t.y_start - t.k + end;
-    P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1;
-    for (int i = 0; i < 112; i++) P->ops[i] = ops[i];
+    P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
 #undef COL
 #undef TMP
 }
@@ -684,22 +689,22 @@ __device__ __forceinline__ bool vote_wins(int cnt, int total, bool homo)
     return homo && cnt * 1000 >= total * 515;
 }
 
-#define FSV_VOTE_STRIDE 380 // bytes per vote row (375 columns + pad; 95 words: odd, so rows start on different banks)
+#define FSV_VOTE_STRIDE 192 // bytes per vote row: two 4-bit votes per byte for 375 columns (+ pad)
 
 __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
 {
     // Votes are NOT accumulated with LDS atomics: the lanes walk their paths in lock-step, so all of them would hit
-    // the same column counters at once and serialise.  Every lane (= one overlap) fills its own row of per-column vote
-    // bytes; afterwards the lanes switch roles, take columns, and tally the rows.
-    //   vote byte: 0xff = this overlap does not cover the column; else bits 0-2 = A C G T / 4 deleted, bit 3 = arrived after an insertion
-    __shared__ uint8_t s_vote[64][FSV_VOTE_STRIDE];
+    // the same column counters at once and serialise.  Every lane (= one overlap) fills its own row of per-column
+    // 4-bit votes; afterwards the lanes switch roles, take columns, and tally the rows.
+    //   vote nibble: 0xf = this overlap does not cover the column; else bits 0-2 = A C G T / 4 deleted, bit 3 = arrived after an insertion
+    // A match op votes for the backbone's own base, so y bases are fetched only at mismatches and insertions.
+    __shared__ __attribute__((aligned(16))) uint8_t s_vote[64][FSV_VOTE_STRIDE];
+    __shared__ uint32_t s_path[64][27];       // per lane: the 26 op words of its window path (odd stride: no bank conflicts); reused as s_out
     __shared__ uint16_t s_evcol[FSV_EV_CAP];
     __shared__ uint32_t s_evkey[FSV_EV_CAP];
     __shared__ uint32_t s_evn, s_cover;
-    __shared__ uint8_t s_out[FSV_WINDOW][14]; // per column: [0] = n bytes, then bytes
+    __shared__ uint32_t s_xraw[28];           // raw store words covering x[gs-16 .. gs+glen+16)
     __shared__ uint32_t s_scan[64];
-    __shared__ uint32_t s_path[64][29];       // per lane: the 28 op words of its window path (stride 29: no bank conflicts)
-    __shared__ uint32_t s_yw[64][29];         // per lane: y bases ry_start-16 .. ry_start+431 as 28 fetched 16-base words
     const int lane = threadIdx.x;
     const uint32_t gw = blockIdx.x;
     if (gw >= n_gwin) return;
@@ -713,15 +718,18 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     const uint32_t xw = A.word_off[r];
     const uint32_t s = A.read_set[r], r0 = A.set_start[s], ns = A.set_start[s + 1] - r0, q = r - r0;
     const uint32_t pbase = A.pair_base[s] + q * (ns - 1);
+    const int xw0 = (gs >> 4) - 1; // first staged word (may be -1 at the read start: reads as 0, never used)
+    if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((xlen + 15) >> 4)) ? A.store[xw + wi] : 0u; }
     if (lane == 0) { s_evn = 0; s_cover = 0; }
     __syncthreads();
-    // sets with more than 65 reads need several passes over the vote rows; counts are carried in registers
+#define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
     const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
     uint32_t cnt[6][7]; // up to 6 columns per lane (375 / 64 rounded up), 7 counters each
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int k2 = 0; k2 < 7; k2++) cnt[i][k2] = 0;
+    // sets with more than 65 reads need several passes over the vote rows; counts are carried in registers
     for (uint32_t obase = 0; obase < ns - 1; obase += 64) {
         const uint32_t oi = obase + lane;
         bool active = false;
@@ -733,33 +741,37 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
             if (o.valid && o.is_match && j >= 0 && j < o.n_win) {
                 const uint32_t ti = (uint32_t)o.first_win + (uint32_t)j;
                 const fsv_wpath *P = A.paths + ti;
-                if (P->state == 1) {
+                const uint4 h0 = *reinterpret_cast<const uint4 *>(P);                      // ry_start, ry_end, path_len|err, state|rev|pad
+                if (((h0.w) & 0xffu) == 1u) {
                     active = true;
-                    const fsv_wtask t = A.tasks[ti];
+                    const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16); // y_word, y_len
                     {
-                        const uint4 *src = reinterpret_cast<const uint4 *>(P->ops);
+                        const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
 #pragma unroll
-                        for (int i = 0; i < 7; i++) { const uint4 v = src[i]; s_path[lane][4 * i] = v.x; s_path[lane][4 * i + 1] = v.y; s_path[lane][4 * i + 2] = v.z; s_path[lane][4 * i + 3] = v.w; }
+                        for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
                     }
-                    const int ry_start = P->ry_start, plen = P->path_len;
-                    const int ybase0 = ry_start - 16;
-                    for (int b = 0; b < 28; b++) s_yw[lane][b] = fetch16(A.store, t.y_word, t.y_len, t.y_rev, ybase0 + 16 * b).bits;
-#define YB(qq) ((s_yw[lane][((qq) - ybase0) >> 4] >> ((((qq) - ybase0) & 15) << 1)) & 3u)
+                    const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
+                    const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
+#define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))
 #define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
-                    int xp = t.x_start - gs, yp = ry_start;
+                    int xp = max(gs, o.x_s) - gs, yp = ry_start;
                     bool pend = false;
-                    if (j > 0 && A.paths[ti - 1].state == 1) {
-                        const int gap = ry_start - A.paths[ti - 1].ry_end - 1;
-                        if (gap > 0 && xp == 0) {
-                            pend = true;
-                            if (gap <= FSV_INS_MAXLEN) {
-                                uint32_t key = (uint32_t)gap << 24;
-                                for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
-                                uint32_t e = atomicAdd(&s_evn, 1u);
-                                if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
+                    if (j > 0) {
+                        const uint4 hp = *reinterpret_cast<const uint4 *>(A.paths + ti - 1);
+                        if ((hp.w & 0xffu) == 1u) {
+                            const int gap = ry_start - (int)hp.y - 1;
+                            if (gap > 0 && xp == 0) {
+                                pend = true;
+                                if (gap <= FSV_INS_MAXLEN) {
+                                    uint32_t key = (uint32_t)gap << 24;
+                                    for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
+                                    uint32_t e = atomicAdd(&s_evn, 1u);
+                                    if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
+                                }
                             }
                         }
                     }
+                    uint32_t acc = 0xffu; // the vote byte being assembled (two columns)
                     for (int p = 0; p < plen;) {
                         const uint32_t op = OP(p);
                         if (op == 2u) {
@@ -780,10 +792,13 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                         uint32_t v = pend ? 8u : 0u;
                         pend = false;
                         if (op == 3u) v |= 4u;
-                        else { v |= YB(yp); yp++; }
-                        s_vote[lane][xp] = (uint8_t)v;
+                        else { v |= (op == 0u) ? XB(gs + xp) : YB(yp); yp++; }
+                        // two columns per byte: low nibble = even column
+                        if (xp & 1) { acc = (acc & 0x0fu) | (v << 4); s_vote[lane][xp >> 1] = (uint8_t)acc; acc = 0xffu; }
+                        else acc = 0xf0u | v;
                         xp++; p++;
                     }
+                    if (xp & 1) s_vote[lane][xp >> 1] = (uint8_t)acc; // last, odd-count column
 #undef YB
 #undef OP
                 }
@@ -801,8 +816,8 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                 while (m) {
                     const int row = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const uint32_t v = s_vote[row][c];
-                    if (v != 0xffu) {
+                    const uint32_t v = (s_vote[row][c >> 1] >> ((c & 1) << 2)) & 0xfu;
+                    if (v != 0xfu) {
                         const uint32_t code = v & 7u;
 #pragma unroll
                         for (int b = 0; b < 5; b++) cnt[ci][b] += (code == (uint32_t)b);
@@ -813,6 +828,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         }
         __syncthreads();
     }
+    uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]); // 375 x 14 B = 5.2 KB <= 64 x 27 x 4 B; paths are done
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
     const bool verbatim = s_cover < 3u;
     const uint32_t evn = min(s_evn, (uint32_t)FSV_EV_CAP);
@@ -822,12 +838,12 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     for (int ci = 0; ci < 6; ci++) {
         const int c = c0 + ci;
         if (c >= c1) continue;
-        const uint32_t own = fsv_base_fwd(A.store, xw, gs + c);
+        const uint32_t own = XB(gs + c);
         uint8_t nb = 0;
         if (verbatim) { s_out[c][1] = (uint8_t)own; nb = 1; }
         else {
             const int p = gs + c;
-            bool homo = (p > 0 && fsv_base_fwd(A.store, xw, p - 1) == own) || (p + 1 < xlen && fsv_base_fwd(A.store, xw, p + 1) == own);
+            bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < xlen && XB(p + 1) == own);
             const int arrived = (int)cnt[ci][5], instot = (int)cnt[ci][6];
             if (instot) {
                 int bc = 0; uint32_t bk = 0;
@@ -867,12 +883,13 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     uint32_t off = 0, tot = 0;
     for (int i = 0; i < 64; i++) { uint32_t v = s_scan[i]; if (i < lane) off += v; tot += v; }
     if (tot > FSV_CW_STRIDE) { // cannot happen with <= 12-base insertions winning at a few columns; keep the read as it is
-        for (int c = lane; c < glen; c += 64) dst[c] = (uint8_t)fsv_base_fwd(A.store, xw, gs + c);
+        for (int c = lane; c < glen; c += 64) dst[c] = (uint8_t)XB(gs + c);
         if (lane == 0) { A.cwin_len[gw] = (uint16_t)glen; atomicOr(&A.warn[r], 16u); }
         return;
     }
     for (int c = c0; c < c1; c++) for (int b = 0; b < s_out[c][0]; b++) dst[off++] = s_out[c][1 + b];
     if (lane == 0) A.cwin_len[gw] = (uint16_t)tot;
+#undef XB
 }
 
 // ------------------------------------------------------------------------------------------------ k_newlen / k_repack
