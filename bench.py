@@ -94,6 +94,7 @@ def main():
     regions = [synth.make_region(idx0 + i, start=(idx0 + i) * 60000) for i in range(n)]
     inputs = [pipeline.region_from_synth(r) for r in regions]
     truth = [(r.chrom, t.svtype, r.start + t.pos, t.length, t.gt) for r in regions for t in r.truth]
+    truth_left = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in regions for t in r.truth]
 
     ctx = _lib.Context(local)
     batch = pipeline.upload_regions(ctx, inputs)  # reads resident in HBM before timing starts
@@ -128,7 +129,7 @@ def main():
     mine = [l for l in lines if idx0 * 60000 <= int(l.split('\t')[1]) < (idx0 + n) * 60000]
     calls = pipeline.parse_calls(mine)
     tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.02, left_shift_ok=2000)
-    tp1, _, _, _ = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.02, left_shift_ok=0)
+    tp1, _, _, _ = pipeline.match_truth(calls, truth_left, bp_tol=1, len_tol=0.02, left_shift_ok=0)
 
     if rank == 0:
         a = stats_acc[-1][0]
@@ -150,7 +151,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{n} synthetic 50 kb regions per GPU, 30x HiFi-like reads U(10k,20k), 0.2% error, seed 1000+i "
                                    "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather"},
-            "sv_vs_truth": {"truth": len(truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok, "tp_within_1bp_unshifted": tp1},
+            "sv_vs_truth": {"truth": len(truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok, "tp_within_1bp_of_left_aligned_truth": tp1},
             "stage_ms": {k: round(v, 2) for k, v in a.items() if k.startswith("ms_")},
             "kernel_ms": {k: [round(v["ms"], 2), v["launches"]] for k, v in kern.items()},
             "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},

@@ -24,6 +24,7 @@ class TruthSV:
     gt: str       # '1/1' | '0/1'
     hap: int      # 1, 2 or 3 (both)
     seq: str = ""
+    pos_left: int = -1  # the same allele left-aligned (what aligners report inside repeats)
 
 
 @dataclass
@@ -77,6 +78,19 @@ def _add_errors(rng, seq: np.ndarray, rate: float) -> np.ndarray:
     if nins:
         res[~first] = _ALPHA[rng.integers(0, 4, size=nins)]
     return res
+
+
+def left_align(ref: np.ndarray, kind: str, pos: int, length: int, seq: np.ndarray = None):
+    """VCF-style left normalisation of a planted event, as a read aligner would report it inside a repeat"""
+    if kind == "DEL":
+        while pos > 0 and ref[pos - 1] == ref[pos + length - 1]:
+            pos -= 1
+        return pos
+    s = seq.copy()
+    while pos > 0 and ref[pos - 1] == s[-1]:
+        s = np.concatenate([ref[pos - 1:pos], s[:-1]])
+        pos -= 1
+    return pos
 
 
 def _segments(events, ref_len):
@@ -210,9 +224,14 @@ def make_region(i: int, width: int = 50_000, profile: str = "hifi", depth_per_ha
     lo, hi = min(lo, max(1000, width // 2)), min(hi, width)
     keep = min(3000, max(500, width // 8))
     a1, a2 = [], []
-    r1 = _sample_reads(rng, hap1, depth_per_hap, lo, hi, err, keep, _segments([(dpos, "DEL", dlen), (ipos, "INS", ilen)], width), a1)
-    r2 = _sample_reads(rng, hap2, depth_per_hap, lo, hi, err, keep,
-                       _segments([(p, k, (n if k == "DEL" else len(n))) for p, k, n in ev2], width), a2)
+    # the read records carry the events where an aligner would put them (left-aligned); the sequences are unaffected
+    seg1 = _segments([(left_align(ref, "DEL", dpos, dlen), "DEL", dlen), (left_align(ref, "INS", ipos, ilen, iseq), "INS", ilen)], width)
+    seg2 = _segments([(left_align(ref2, k, p, (n if k == "DEL" else len(n)), None if k == "DEL" else n), k, (n if k == "DEL" else len(n)))
+                      for p, k, n in ev2], width)
+    r1 = _sample_reads(rng, hap1, depth_per_hap, lo, hi, err, keep, seg1, a1)
+    r2 = _sample_reads(rng, hap2, depth_per_hap, lo, hi, err, keep, seg2, a2)
+    for t in truth:
+        t.pos_left = left_align(ref, t.svtype, t.pos, t.length, np.frombuffer(t.seq.encode(), dtype=np.uint8) if t.svtype == "INS" else None)
     truth.sort(key=lambda t: t.pos)
     return Region(i, chrom, start, ref.tobytes(), (hap1.tobytes(), hap2.tobytes()), (r1, r2), truth, (a1, a2))
 
