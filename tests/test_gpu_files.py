@@ -1,0 +1,46 @@
+"""The file-based drop-ins (scripts/3_assembly.py, scripts/4_sv_calling.py) on a two-region directory tree."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from focalsv_amd import fasta, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_region_directories_to_vcf(tmp_path):
+    out = str(tmp_path)
+    rs = [synth.make_region(i, start=10000 + i * 80000) for i in (1, 6)]
+    import random
+    rng = random.Random(5)
+    total = max(r.start + len(r.ref) for r in rs) + 20000
+    seq = [rng.choice("ACGT") for _ in range(total)]  # filler outside the windows
+    for r in rs:
+        synth.write_region_dir(r, os.path.join(out, "regions"))
+        seq[r.start:r.start + len(r.ref)] = r.ref.decode()
+    ref_fa = os.path.join(out, "ref.fa")
+    with open(ref_fa, "w") as f:
+        f.write(">chr21\n" + fasta.fold("".join(seq), 60) + "\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env)
+    for r in rs:
+        d = os.path.join(out, "regions", "Region_chr21_S%d_E%d" % (r.start, r.start + 50000))
+        hp1 = list(fasta.read_fasta(os.path.join(d, "HP1.fa")))
+        assert len(hp1) == 1 and len(hp1[0][1]) == len(r.haps[0])
+        assert os.path.exists(os.path.join(d, "PS1_hp1.asm.p_ctg.gfa.fa")) and os.path.exists(os.path.join(out, "log", "3_ASSEMBLY.log"))
+    vcf = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out],
+                                  env=env).decode().strip().splitlines()[-1]
+    assert vcf.endswith("final_vcf/dippav_variant_no_redundancy.vcf")
+    body = [l for l in open(vcf) if l[0] != '#']
+    calls = pipeline.parse_calls(body)
+    # without read records the FP filter keeps only calls longer than 250 bp (FP_filter_v1.py:56-90)
+    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth if t.length > 250]
+    tp, fp, fn, gt = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.0)
+    assert (tp, fp, fn) == (len(truth), 0, 0) and len(truth) >= 1
+    raw = [l for l in open(os.path.join(out, "SV", "chr21", "dippav_raw_variant.vcf")) if l[0] != '#']
+    truth_all = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth]
+    tp, fp, fn, gt = pipeline.match_truth(pipeline.parse_calls(raw), truth_all, bp_tol=1, len_tol=0.0)
+    assert (tp, fp, fn) == (len(truth_all), 0, 0)
