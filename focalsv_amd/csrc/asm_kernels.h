@@ -50,13 +50,21 @@ __device__ __forceinline__ uint64_t mix64(uint64_t key)
 }
 
 // One wavefront per read.  The minimizer recurrence is sequential, but what it emits at a position only depends on
-// the w entries around it (and on the k HPC bases behind them), so every lane replays the reference recurrence over
-// its own 1/64 of the read plus a warm-up of w+k+4 homopolymer runs in front and w+2 runs behind, and keeps only the
-// minimizers whose end position falls inside its own slice.  Lanes whose warm-up reaches the read start replay it
-// exactly from base 0 (the l < w+k start-up rules matter only there).  The w-slot ring and the k-slot run-length
-// queue live in LDS, transposed ([slot][lane]) so that lanes never share a bank.  Output order is arbitrary (k_uniq sorts).
-// Dynamic LDS: [read words][w x 64 hashes][w x 64 metas][w x 64 spans][64 x 64 run lengths].
-__host__ __device__ inline size_t sketch_lds_bytes(int w, uint32_t read_words) { return (size_t)read_words * 4 + (size_t)w * 64 * 13 + 64 * 64 + 16; }
+// the w entries around it (and on the k HPC bases behind them), so every lane replays the recurrence over its own 1/64
+// of the read plus a warm-up of w+k+4 homopolymer runs in front and w+2 runs behind, and keeps only the minimizers whose
+// end position falls inside its own slice.  Output order is arbitrary (k_uniq sorts).
+//
+// The reference keeps a w-slot ring and rescans it whenever the minimum slides out (two passes over w slots); in SIMT
+// some lane rescans at almost every step, so the whole wave would pay ~2w LDS reads per step.  The replay therefore
+// uses a monotone deque (hashes non-decreasing front to back, ties kept) that holds exactly the window elements which
+// can still become a minimum.  ha_sketch emits an element exactly once iff it equals the minimum of some window that
+// ends at or after the first full one -- as the "best" when that is replaced / slides out / the read ends, or as an
+// "identical k-mer" copy when a rescan (or the first full window) finds it (sketch.cpp:101-135) -- so here an element
+// is emitted the moment it joins the deque's front run.  The one irregular step is the first full window (l == w+k-1):
+// copies of the previous partial window's minimum are emitted and that minimum itself is dropped silently if the
+// incoming k-mer ties or beats it (sketch.cpp:101-106 run before 116-118 with l < w+k); replicated literally below.
+// Dynamic LDS: [w x 64 hashes][read words][w x 64 pos|span][w x 64 time|flag|rev][(k+1) x 64 run lengths].
+__host__ __device__ inline size_t sketch_lds_bytes(int w, uint32_t read_words) { return (size_t)read_words * 4 + (size_t)w * 64 * 14 + 64 * 64 + 16; }
 
 struct WordCache { // sequential base access through one cached 16-base word
     const uint32_t *p; uint32_t w; int idx;
@@ -78,17 +86,15 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
     const uint32_t cap = mz_off[r + 1] - mz_off[r];
     fsv_mz *out = mz + mz_off[r];
     if (w_per_read) w = w_per_read[r];
-    // carve the dynamic LDS (8-byte items first)
-    uint64_t *r_hash = (uint64_t *)s_dyn;                               // [w_max][64]
-    uint32_t *s_words = (uint32_t *)(r_hash + (size_t)w_max * 64);      // [lds_words]
-    uint32_t *r_meta = s_words + lds_words;                             // [w_max][64]   pos << 1 | rev
-    uint8_t *r_span = (uint8_t *)(r_meta + (size_t)w_max * 64);         // [w_max][64]
-    uint8_t *q_run = r_span + (size_t)w_max * 64;                       // [64][64]      saturating run lengths
-#define R_HASH(j) r_hash[(j) * 64 + lane]
-#define R_META(j) r_meta[(j) * 64 + lane]
-#define R_SPAN(j) r_span[(j) * 64 + lane]
+    uint64_t *d_hash = (uint64_t *)s_dyn;                               // [w_max][64]
+    uint32_t *s_words = (uint32_t *)(d_hash + (size_t)w_max * 64);      // [lds_words]
+    uint32_t *d_ps = s_words + lds_words;                               // [w_max][64]   pos << 8 | span
+    uint16_t *d_tf = (uint16_t *)(d_ps + (size_t)w_max * 64);           // [w_max][64]   (time & 0x3fff) << 2 | rev << 1 | emitted
+    uint8_t *q_run = (uint8_t *)(d_tf + (size_t)w_max * 64);            // [64][64]      saturating run lengths
+#define D_HASH(j) d_hash[(j) * 64 + lane]
+#define D_PS(j) d_ps[(j) * 64 + lane]
+#define D_TF(j) d_tf[(j) * 64 + lane]
 #define Q_RUN(j) q_run[(j) * 64 + lane]
-    // stage the read in LDS when it fits: the replay fetches bases one dependent load after another
     const uint32_t nwords = ((uint32_t)len + 15u) >> 4;
     const bool staged = nwords <= lds_words;
     if (staged) for (uint32_t i = lane; i < nwords; i += 64) s_words[i] = store[woff + i];
@@ -96,7 +102,6 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
     WordCache B{staged ? (const uint32_t *)s_words : store + woff, 0u, -1};
     const int c0 = (int)((long long)len * lane / 64), c1 = (int)((long long)len * (lane + 1) / 64);
     if (c1 <= c0) return;
-    // start of the replay: w+k+4 runs (bases when not compressing) in front of the slice, on a run boundary
     int b0 = c0;
     if (hpc) {
         while (b0 > 0 && B.get(b0 - 1) == B.get(b0)) b0--;
@@ -111,77 +116,94 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
     const uint64_t NONE = ~0ull;
     const uint64_t mask = (1ull << k) - 1;
     uint64_t km0 = 0, km1 = 0, km2 = 0, km3 = 0;
-    uint64_t best_h = NONE; uint32_t best_meta = 0; uint16_t best_span = 0;
-    int run_head = 0, run_cnt = 0, slot = 0, best_slot = 0, span = 0;
+    int run_head = 0, run_cnt = 0, span = 0;
+    int head = 0, cnt = 0;          // deque = slots (head + j) mod w, j < cnt
     int l = b0 > 0 ? w + k + 1 : 0; // past the start-up phase every "l >= ..." test of the reference holds
     int tail = -1;                  // runs still to replay once the slice is done
-    for (int j = 0; j < w; j++) { R_HASH(j) = NONE; R_META(j) = 0; R_SPAN(j) = 0; }
 
-#define EMIT(H, M, S)                                                                                      \
+#define EMIT_SLOT(sl)                                                                                      \
     do {                                                                                                   \
-        const int p_ = (int)((M) >> 1);                                                                    \
+        const uint32_t ps_ = D_PS(sl); const uint16_t tf_ = D_TF(sl);                                      \
+        const int p_ = (int)(ps_ >> 8);                                                                    \
         if (p_ >= c0 && p_ < c1) {                                                                         \
             const uint32_t at_ = atomicAdd(&mz_cnt[r], 1u);                                                \
-            if (at_ < cap) { fsv_mz m_; m_.hash = (H); m_.pos = (uint32_t)p_; m_.rev = (uint8_t)((M) & 1u); m_.span = (uint8_t)(S); m_.pad = 0; out[at_] = m_; } \
+            if (at_ < cap) { fsv_mz m_; m_.hash = D_HASH(sl); m_.pos = (uint32_t)p_; m_.rev = (uint8_t)((tf_ >> 1) & 1u); m_.span = (uint8_t)(ps_ & 0xffu); m_.pad = 0; out[at_] = m_; } \
             else atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC);                                             \
         }                                                                                                  \
+        D_TF(sl) = (uint16_t)(tf_ | 1u);                                                                   \
     } while (0)
+#define WRAP(x) ((x) >= w ? (x) - w : (x))
 
     int i = b0;
     for (; i < len; i++) {
         if (i >= c1) { if (tail < 0) tail = w + 2; if (tail-- == 0) break; }
         const uint32_t c = B.get(i);
-        uint64_t cur_h = NONE; uint32_t cur_meta = 0; uint16_t cur_span = 0;
+        uint64_t cur_h = NONE; uint32_t cur_ps = 0; uint32_t cur_rev = 0;
+        if (hpc) {
+            int run = 1;
+            while (i + run < len && B.get(i + run) == c) run++;
+            i += run - 1;
+            const int rs = min(run, 255); // saturating: one run >= 255 puts the span at >= 256 (= no minimizer) either way
+            Q_RUN((run_head + run_cnt++) & 63) = (uint8_t)rs;
+            span += rs;
+            if (run_cnt > k) { span -= Q_RUN(run_head); run_head = (run_head + 1) & 63; run_cnt--; }
+        } else {
+            span = l + 1 < k ? l + 1 : k;
+        }
+        km0 = (km0 << 1 | (uint64_t)(c & 1u)) & mask;
+        km1 = (km1 << 1 | (uint64_t)(c >> 1)) & mask;
+        km2 = km2 >> 1 | (uint64_t)(1u - (c & 1u)) << (k - 1);
+        km3 = km3 >> 1 | (uint64_t)(1u - (c >> 1)) << (k - 1);
+        if (km1 == km3) continue; // palindrome: not an entry (sketch.cpp:84)
+        const int z = km1 < km3 ? 0 : 1;
+        ++l;
+        if (l >= k && span < 256) {
+            cur_h = z ? mix64(km2) + mix64(km3) : mix64(km0) + mix64(km1);
+            cur_ps = ((uint32_t)i << 8) | (uint32_t)span;
+            cur_rev = (uint32_t)z;
+        }
+        const int tcur = l & 0x3fff; // entry time, modulo 2^14 (windows are at most 64 entries long)
+        // expire what has left the window of the last w entries
+        while (cnt > 0 && (((tcur - (int)(D_TF(head) >> 2)) & 0x3fff) >= w)) { head = WRAP(head + 1); cnt--; }
+        if (l == w + k - 1 && cnt > 0 && D_HASH(head) != NONE) {
+            // first full window (only lanes that replay from base 0 get here): copies of the partial window's minimum
+            // are emitted (sketch.cpp:101-106); the minimum itself is lost if the incoming k-mer ties or beats it (:116-118)
+            const uint64_t m = D_HASH(head);
+            int run = 1;
+            while (run < cnt && D_HASH(WRAP(head + run)) == m) run++;
+            for (int j = 0; j + 1 < run; j++) { const int sl = WRAP(head + j); EMIT_SLOT(sl); }
+            if (cur_h <= m) { const int sl = WRAP(head + run - 1); D_TF(sl) = (uint16_t)(D_TF(sl) | 1u); }
+        }
+        // keep hashes non-decreasing front to back (ties stay: they are the "identical k-mers")
+        while (cnt > 0 && D_HASH(WRAP(head + cnt - 1)) > cur_h) cnt--;
         {
-            if (hpc) {
-                int run = 1;
-                while (i + run < len && B.get(i + run) == c) run++;
-                i += run - 1;
-                const int rs = min(run, 255); // saturating: one run >= 255 puts the span at >= 256 (= no minimizer) either way
-                Q_RUN((run_head + run_cnt++) & 63) = (uint8_t)rs;
-                span += rs;
-                if (run_cnt > k) { span -= Q_RUN(run_head); run_head = (run_head + 1) & 63; run_cnt--; }
-            } else {
-                span = l + 1 < k ? l + 1 : k;
-            }
-            km0 = (km0 << 1 | (uint64_t)(c & 1u)) & mask;
-            km1 = (km1 << 1 | (uint64_t)(c >> 1)) & mask;
-            km2 = km2 >> 1 | (uint64_t)(1u - (c & 1u)) << (k - 1);
-            km3 = km3 >> 1 | (uint64_t)(1u - (c >> 1)) << (k - 1);
-            if (km1 == km3) continue; // palindrome: ring and slot are not advanced (sketch.cpp:84)
-            const int z = km1 < km3 ? 0 : 1;
-            ++l;
-            if (l >= k && span < 256) {
-                cur_h = z ? mix64(km2) + mix64(km3) : mix64(km0) + mix64(km1);
-                cur_meta = ((uint32_t)i << 1) | (uint32_t)z;
-                cur_span = (uint16_t)span;
-            }
+            const int sl = WRAP(head + cnt);
+            D_HASH(sl) = cur_h; D_PS(sl) = cur_ps; D_TF(sl) = (uint16_t)((uint32_t)tcur << 2 | cur_rev << 1);
+            cnt++;
         }
-        R_HASH(slot) = cur_h; R_META(slot) = cur_meta; R_SPAN(slot) = (uint8_t)cur_span;
-        if (l == w + k - 1 && best_h != NONE) {
-            for (int j = slot + 1; j < w; j++) if (best_h == R_HASH(j) && R_META(j) != best_meta) EMIT(R_HASH(j), R_META(j), R_SPAN(j));
-            for (int j = 0; j < slot; j++)     if (best_h == R_HASH(j) && R_META(j) != best_meta) EMIT(R_HASH(j), R_META(j), R_SPAN(j));
+        if (l >= w + k - 1) {
+            const uint64_t m = D_HASH(head);
+            if (m != NONE)
+                for (int j = 0; j < cnt; j++) {
+                    const int sl = WRAP(head + j);
+                    if (D_HASH(sl) != m) break;
+                    if (!(D_TF(sl) & 1u)) EMIT_SLOT(sl);
+                }
         }
-        if (cur_h <= best_h) {
-            if (l >= w + k && best_h != NONE) EMIT(best_h, best_meta, best_span);
-            best_h = cur_h; best_meta = cur_meta; best_span = cur_span; best_slot = slot;
-        } else if (slot == best_slot) {
-            if (l >= w + k - 1 && best_h != NONE) EMIT(best_h, best_meta, best_span);
-            best_h = NONE;
-            for (int j = slot + 1; j < w; j++) if (best_h >= R_HASH(j)) { best_h = R_HASH(j); best_meta = R_META(j); best_span = R_SPAN(j); best_slot = j; }
-            for (int j = 0; j <= slot; j++)    if (best_h >= R_HASH(j)) { best_h = R_HASH(j); best_meta = R_META(j); best_span = R_SPAN(j); best_slot = j; }
-            if (l >= w + k - 1 && best_h != NONE) {
-                for (int j = slot + 1; j < w; j++) if (best_h == R_HASH(j) && best_meta != R_META(j)) EMIT(R_HASH(j), R_META(j), R_SPAN(j));
-                for (int j = 0; j <= slot; j++)    if (best_h == R_HASH(j) && best_meta != R_META(j)) EMIT(R_HASH(j), R_META(j), R_SPAN(j));
-            }
-        }
-        if (++slot == w) slot = 0;
     }
-    if (i >= len && best_h != NONE) EMIT(best_h, best_meta, best_span); // the read's last window (sketch.cpp:134-135)
-#undef EMIT
-#undef R_HASH
-#undef R_META
-#undef R_SPAN
+    if (i >= len && l < w + k - 1 && cnt > 0 && D_HASH(head) != NONE) {
+        // a read shorter than one window: only the last minimum is reported (sketch.cpp:134-135)
+        const uint64_t m = D_HASH(head);
+        int run = 1;
+        while (run < cnt && D_HASH(WRAP(head + run)) == m) run++;
+        const int sl = WRAP(head + run - 1);
+        EMIT_SLOT(sl);
+    }
+#undef EMIT_SLOT
+#undef WRAP
+#undef D_HASH
+#undef D_PS
+#undef D_TF
 #undef Q_RUN
 }
 
@@ -375,7 +397,25 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
             }
             __syncthreads();
         }
-    // 4. chain DP: lane l examines predecessor i-1-l (nearest first on ties)
+    // 4. chain DP: lane l examines predecessor i-1-l (nearest first on ties).
+    //    Fast path: when every anchor sits on one diagonal (error-free reads: correction rounds 2, 3 and the final pass)
+    //    the DP provably links each anchor to its nearest predecessor -- gap 0 means no indel penalty, and
+    //    f[i-1] + min(d_i,k) >= f[j] + min(qe_i - qe_j, k) for every j < i-1 because min(.,k) is sub-additive, with the
+    //    nearest predecessor winning ties -- so the chain is the whole list and the score a running sum.
+    bool colinear;
+    {
+        const int d0 = (int)(uint32_t)s_key[0] - (int)(s_key[0] >> 32);
+        bool same = true;
+        for (int i = lane; i < n; i += 64) same = same && ((int)(uint32_t)s_key[i] - (int)(s_key[i] >> 32) == d0);
+        colinear = __all(same);
+    }
+    if (colinear) {
+        int acc = 0;
+        for (int i = 1 + lane; i < n; i += 64) acc += min((int)(s_key[i] >> 32) - (int)(s_key[i - 1] >> 32), A.k_score);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        for (int i = lane; i < n; i += 64) { s_aux[i] = (uint16_t)(i == 0 ? 0xffff : i - 1); s_f[i] = i == n - 1 ? A.k_score + acc : 0; }
+        __syncthreads();
+    } else
     for (int i = 0; i < n; i++) {
         const uint64_t ki = s_key[i];
         const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
