@@ -79,10 +79,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("FSV_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the N > 1 path on a one-GPU box
+    if backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     elif args.gpus > 1:
         sys.exit("launch with torch.distributed.run for --gpus > 1")
     dev = torch.device("cuda", local)
@@ -120,7 +126,7 @@ def main():
         stats_acc.append((res.asm_stats, res.aln_stats))
     fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())

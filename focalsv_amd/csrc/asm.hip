@@ -35,7 +35,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
 
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
-        cols, tmp, gwin_off, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -46,7 +46,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -107,7 +107,7 @@ struct Batch {
 
 // per-round geometry derived from the current read lengths
 struct Geometry {
-    std::vector<uint32_t> word_off, mz_off, gwin_off;
+    std::vector<uint32_t> word_off, mz_off, gwin_off, gwin_read;
     uint64_t task_bound = 0;
     uint32_t max_words = 1;
 };
@@ -126,6 +126,8 @@ int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len,
     }
     if (w + 4 >= (1ull << 32) || m >= (1ull << 32) || g >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "batch too large for 32-bit offsets; split it");
     G.word_off[B.n_reads] = (uint32_t)w; G.mz_off[B.n_reads] = (uint32_t)m; G.gwin_off[B.n_reads] = (uint32_t)g;
+    G.gwin_read.resize(g);
+    for (uint32_t r = 0; r < B.n_reads; r++) for (uint32_t x = G.gwin_off[r]; x < G.gwin_off[r + 1]; x++) G.gwin_read[x] = r;
     G.task_bound = 0;
     for (uint32_t s = 0; s < B.n_sets; s++) {
         uint64_t nw = 0;
@@ -324,6 +326,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         TRY(upload(ctx, W.len, len));
         TRY(upload(ctx, W.mz_off, G.mz_off));
         TRY(upload(ctx, W.gwin_off, G.gwin_off));
+        TRY(upload(ctx, W.gwin_read, G.gwin_read));
         if (G.task_bound >= (1ull << 31)) return fsv_fail(ctx, FSV_EUNSUP, "window task bound exceeds 2^31; split the batch");
         const uint32_t task_cap = (uint32_t)std::max<uint64_t>(G.task_bound, 1);
         TRY(ensure(ctx, W.tasks, (size_t)task_cap * sizeof(fsv_wtask)));
@@ -387,7 +390,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         ConsArgs C;
         C.store = store; C.word_off = (const uint32_t *)W.word_off.p; C.read_len = (const int32_t *)W.len.p;
         C.read_set = (const uint32_t *)W.read_set.p; C.set_start = (const uint32_t *)W.set_start.p; C.pair_base = (const uint32_t *)W.pair_base.p;
-        C.gwin_off = (const uint32_t *)W.gwin_off.p; C.ovl = (const fsv_ovl *)W.ovl.p; C.tasks = (const fsv_wtask *)W.tasks.p;
+        C.gwin_off = (const uint32_t *)W.gwin_off.p; C.gwin_read = (const uint32_t *)W.gwin_read.p; C.ovl = (const fsv_ovl *)W.ovl.p; C.tasks = (const fsv_wtask *)W.tasks.p;
         C.paths = (const fsv_wpath *)W.paths.p; C.cwin = (uint8_t *)W.cwin.p; C.cwin_len = (uint16_t *)W.cwin_len.p; C.warn = (uint32_t *)W.warn.p;
         C.n_reads = B.n_reads;
         W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_tasks * 128 + (uint64_t)n_gwin * (96 + 448));

@@ -714,6 +714,7 @@ struct ConsArgs {
     const uint32_t *set_start;
     const uint32_t *pair_base;
     const uint32_t *gwin_off;    // n_reads + 1: first grid window of every read
+    const uint32_t *gwin_read;   // n_gwin: read of every grid window
     const fsv_ovl *ovl;
     const fsv_wtask *tasks;
     const fsv_wpath *paths;
@@ -729,29 +730,24 @@ __device__ __forceinline__ bool vote_wins(int cnt, int total, bool homo)
     return homo && cnt * 1000 >= total * 515;
 }
 
-#define FSV_VOTE_STRIDE 192 // bytes per vote row: two 4-bit votes per byte for 375 columns (+ pad)
-
 __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
 {
-    // Votes are NOT accumulated with LDS atomics: the lanes walk their paths in lock-step, so all of them would hit
-    // the same column counters at once and serialise.  Every lane (= one overlap) fills its own row of per-column
-    // 4-bit votes; afterwards the lanes switch roles, take columns, and tally the rows.
-    //   vote nibble: 0xf = this overlap does not cover the column; else bits 0-2 = A C G T / 4 deleted, bit 3 = arrived after an insertion
-    // A match op votes for the backbone's own base, so y bases are fetched only at mismatches and insertions.
-    __shared__ __attribute__((aligned(16))) uint8_t s_vote[64][FSV_VOTE_STRIDE];
-    __shared__ uint32_t s_path[64][27];       // per lane: the 26 op words of its window path (odd stride: no bank conflicts); reused as s_out
+    // Per-column votes of one 375-bp grid window.  A match op votes for the backbone's own base, so a lane (= one
+    // overlap) only contributes (a) its coverage interval, through a difference array, and (b) its deviations --
+    // mismatches, deleted columns, insertions -- which it finds by skipping the all-match words of its 2-bit path.
+    // Deviations are sparse (HiFi: ~1.5 per window), so their LDS atomics do not collide the way per-step votes would.
+    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][6];  // per column: votes for A C G T that differ from the backbone, deleted, arrived-after-insertion
+    __shared__ int32_t s_cov[FSV_WINDOW + 2];      // coverage difference array -> arrived
+    __shared__ uint32_t s_path[64][27];            // per lane: the 26 op words of its window path (odd stride); reused as s_out
     __shared__ uint16_t s_evcol[FSV_EV_CAP];
     __shared__ uint32_t s_evkey[FSV_EV_CAP];
     __shared__ uint32_t s_evn, s_cover;
-    __shared__ uint32_t s_xraw[28];           // raw store words covering x[gs-16 .. gs+glen+16)
+    __shared__ uint32_t s_xraw[28];                // raw store words covering x[gs-16 .. gs+glen+16)
     __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
     const uint32_t gw = blockIdx.x;
     if (gw >= n_gwin) return;
-    // read of this grid window: largest r with gwin_off[r] <= gw
-    uint32_t lo = 0, hi = A.n_reads;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (A.gwin_off[mid] <= gw) lo = mid; else hi = mid; }
-    const uint32_t r = lo;
+    const uint32_t r = A.gwin_read[gw];
     const int g = (int)(gw - A.gwin_off[r]);
     const int xlen = A.read_len[r];
     const int gs = g * FSV_WINDOW, glen = min(FSV_WINDOW, xlen - gs);
@@ -760,131 +756,107 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     const uint32_t pbase = A.pair_base[s] + q * (ns - 1);
     const int xw0 = (gs >> 4) - 1; // first staged word (may be -1 at the read start: reads as 0, never used)
     if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((xlen + 15) >> 4)) ? A.store[xw + wi] : 0u; }
+    for (int i = lane; i < (FSV_WINDOW + 1) * 6; i += 64) (&s_cnt[0][0])[i] = 0;
+    for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
     if (lane == 0) { s_evn = 0; s_cover = 0; }
     __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
-    const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
-    uint32_t cnt[6][7]; // up to 6 columns per lane (375 / 64 rounded up), 7 counters each
+    for (uint32_t oi = lane; oi < ns - 1; oi += 64) {
+        const fsv_ovl o = A.ovl[pbase + oi];
+        const int j = g - o.x_s / FSV_WINDOW;
+        if (!o.valid || !o.is_match || j < 0 || j >= o.n_win) continue;
+        const uint32_t ti = (uint32_t)o.first_win + (uint32_t)j;
+        const fsv_wpath *P = A.paths + ti;
+        const uint4 h0 = *reinterpret_cast<const uint4 *>(P);                      // ry_start, ry_end, path_len|err, state|rev|pad
+        if ((h0.w & 0xffu) != 1u) continue;
+        const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16); // y_word, y_len
+        {
+            const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int k2 = 0; k2 < 7; k2++) cnt[i][k2] = 0;
-    // sets with more than 65 reads need several passes over the vote rows; counts are carried in registers
-    for (uint32_t obase = 0; obase < ns - 1; obase += 64) {
-        const uint32_t oi = obase + lane;
-        bool active = false;
-        for (int c = lane; c < 64 * (FSV_VOTE_STRIDE / 4); c += 64) ((uint32_t *)&s_vote[0][0])[c] = 0xffffffffu;
-        __syncthreads();
-        if (oi < ns - 1) {
-            const fsv_ovl o = A.ovl[pbase + oi];
-            const int j = g - o.x_s / FSV_WINDOW;
-            if (o.valid && o.is_match && j >= 0 && j < o.n_win) {
-                const uint32_t ti = (uint32_t)o.first_win + (uint32_t)j;
-                const fsv_wpath *P = A.paths + ti;
-                const uint4 h0 = *reinterpret_cast<const uint4 *>(P);                      // ry_start, ry_end, path_len|err, state|rev|pad
-                if (((h0.w) & 0xffu) == 1u) {
-                    active = true;
-                    const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16); // y_word, y_len
-                    {
-                        const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
-#pragma unroll
-                        for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
-                    }
-                    const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
-                    const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
+            for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
+        }
+        atomicAdd(&s_cover, 1u);
+        const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
+        const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
 #define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))
+        const int xs = max(gs, o.x_s) - gs;
+        bool pend = false;
+        if (j > 0) {
+            const uint4 hp = *reinterpret_cast<const uint4 *>(A.paths + ti - 1);
+            if ((hp.w & 0xffu) == 1u) {
+                const int gap = ry_start - (int)hp.y - 1;
+                if (gap > 0 && xs == 0) {
+                    pend = true;
+                    if (gap <= FSV_INS_MAXLEN) {
+                        uint32_t key = (uint32_t)gap << 24;
+                        for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
+                        uint32_t e = atomicAdd(&s_evn, 1u);
+                        if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
+                    }
+                }
+            }
+        }
+        // deviations: skip the all-match remainder of a path word at a time; n2 / n3 = y-only / x-only ops seen so far
 #define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
-                    int xp = max(gs, o.x_s) - gs, yp = ry_start;
-                    bool pend = false;
-                    if (j > 0) {
-                        const uint4 hp = *reinterpret_cast<const uint4 *>(A.paths + ti - 1);
-                        if ((hp.w & 0xffu) == 1u) {
-                            const int gap = ry_start - (int)hp.y - 1;
-                            if (gap > 0 && xp == 0) {
-                                pend = true;
-                                if (gap <= FSV_INS_MAXLEN) {
-                                    uint32_t key = (uint32_t)gap << 24;
-                                    for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
-                                    uint32_t e = atomicAdd(&s_evn, 1u);
-                                    if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
-                                }
-                            }
-                        }
+        int n2 = 0, n3 = 0;
+        for (int p = 0; p < plen;) {
+            const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1); // this word from field p on (fields past plen are 0)
+            if (rest == 0u && !pend) { p = ((p >> 4) + 1) << 4; continue; }
+            const uint32_t op = rest & 3u;
+            const int xp = xs + p - n2;
+            if (op == 2u) { // run of y-only ops in front of column xp
+                int L = 1;
+                while (p + L < plen && OP(p + L) == 2u) L++;
+                if (xp < glen) {
+                    pend = true;
+                    if (L <= FSV_INS_MAXLEN) {
+                        uint32_t key = (uint32_t)L << 24;
+                        const int yp = ry_start + p - n3;
+                        for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
+                        uint32_t e = atomicAdd(&s_evn, 1u);
+                        if (e < FSV_EV_CAP) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
                     }
-                    uint32_t acc = 0xffu; // the vote byte being assembled (two columns)
-                    for (int p = 0; p < plen;) {
-                        const uint32_t op = OP(p);
-                        if (op == 2u) {
-                            int L = 0;
-                            while (p + L < plen && OP(p + L) == 2u) L++;
-                            if (xp < glen) {
-                                pend = true;
-                                if (L <= FSV_INS_MAXLEN) {
-                                    uint32_t key = (uint32_t)L << 24;
-                                    for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
-                                    uint32_t e = atomicAdd(&s_evn, 1u);
-                                    if (e < FSV_EV_CAP) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
-                                }
-                            }
-                            yp += L; p += L;
-                            continue;
-                        }
-                        uint32_t v = pend ? 8u : 0u;
-                        pend = false;
-                        if (op == 3u) v |= 4u;
-                        else { v |= (op == 0u) ? XB(gs + xp) : YB(yp); yp++; }
-                        // two columns per byte: low nibble = even column
-                        if (xp & 1) { acc = (acc & 0x0fu) | (v << 4); s_vote[lane][xp >> 1] = (uint8_t)acc; acc = 0xffu; }
-                        else acc = 0xf0u | v;
-                        xp++; p++;
-                    }
-                    if (xp & 1) s_vote[lane][xp >> 1] = (uint8_t)acc; // last, odd-count column
-#undef YB
+                }
+                n2 += L; p += L;
+                continue;
+            }
+            if (pend) { atomicAdd(&s_cnt[xp][5], 1u); pend = false; }
+            if (op == 3u) { atomicAdd(&s_cnt[xp][4], 1u); n3++; }
+            else if (op == 1u) atomicAdd(&s_cnt[xp][YB(ry_start + p - n3)], 1u);
+            p++;
+        }
 #undef OP
-                }
-            }
-        }
-        const uint64_t am = __ballot(active);
-        if (lane == 0) s_cover += (uint32_t)__popcll(am);
-        __syncthreads();
-        // tally: this lane's columns over the rows that were filled in this pass
-#pragma unroll
-        for (int ci = 0; ci < 6; ci++) {
-            const int c = c0 + ci;
-            if (c < c1) {
-                uint64_t m = am;
-                while (m) {
-                    const int row = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const uint32_t v = (s_vote[row][c >> 1] >> ((c & 1) << 2)) & 0xfu;
-                    if (v != 0xfu) {
-                        const uint32_t code = v & 7u;
-#pragma unroll
-                        for (int b = 0; b < 5; b++) cnt[ci][b] += (code == (uint32_t)b);
-                        cnt[ci][5]++; cnt[ci][6] += (v >> 3) & 1u;
-                    }
-                }
-            }
-        }
-        __syncthreads();
+        // coverage interval: every x base of the task is consumed exactly once
+        const int xcols = plen - n2;
+        atomicAdd(&s_cov[xs], 1);
+        atomicAdd(&s_cov[xs + xcols], -1);
+#undef YB
     }
+    __syncthreads();
+    // arrived[c] = prefix sum of the difference array; each lane owns the contiguous columns [c0, c1)
+    const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
+    int run = 0;
+    for (int c = c0; c < c1; c++) run += s_cov[c];
+    s_scan[lane] = (uint32_t)run;
+    __syncthreads();
+    int before = 0;
+    for (int i = 0; i < lane; i++) before += (int)s_scan[i];
+    __syncthreads();
     uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]); // 375 x 14 B = 5.2 KB <= 64 x 27 x 4 B; paths are done
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
     const bool verbatim = s_cover < 3u;
     const uint32_t evn = min(s_evn, (uint32_t)FSV_EV_CAP);
     if (s_evn > FSV_EV_CAP && lane == 0) atomicOr(&A.warn[r], 8u);
-    // per-column decision
-#pragma unroll
-    for (int ci = 0; ci < 6; ci++) {
-        const int c = c0 + ci;
-        if (c >= c1) continue;
+    int arrived = before;
+    for (int c = c0; c < c1; c++) {
+        arrived += s_cov[c];
         const uint32_t own = XB(gs + c);
         uint8_t nb = 0;
         if (verbatim) { s_out[c][1] = (uint8_t)own; nb = 1; }
         else {
             const int p = gs + c;
             bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < xlen && XB(p + 1) == own);
-            const int arrived = (int)cnt[ci][5], instot = (int)cnt[ci][6];
+            const int instot = (int)s_cnt[c][5];
             if (instot) {
                 int bc = 0; uint32_t bk = 0;
                 for (uint32_t i = 0; i < evn; i++) {
@@ -901,9 +873,13 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                 }
             }
             int v[5];
+            int dev = 0;
 #pragma unroll
-            for (int b = 0; b < 5; b++) v[b] = (int)cnt[ci][b] + (own == (uint32_t)b);
-            const int total = v[0] + v[1] + v[2] + v[3] + v[4];
+            for (int b = 0; b < 5; b++) { v[b] = (int)s_cnt[c][b]; dev += v[b]; }
+            // matches vote for the backbone base; + the backbone's own weight of 1 (POA.cpp:269-307)
+#pragma unroll
+            for (int b = 0; b < 4; b++) if ((int)own == b) v[b] += arrived - dev + 1;
+            const int total = arrived + 1;
             int bestb = (int)own, bestc = 0;
 #pragma unroll
             for (int b = 0; b < 5; b++) if ((int)own == b) bestc = v[b];
@@ -915,7 +891,6 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         s_out[c][0] = nb;
     }
     __syncthreads();
-    // output offsets: each lane owns the contiguous chunk of columns [c0, c1)
     uint32_t mine = 0;
     for (int c = c0; c < c1; c++) mine += s_out[c][0];
     s_scan[lane] = mine;
