@@ -427,7 +427,15 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
             if (dq > 0 && dt > 0) {
                 const int gap = dq > dt ? dq - dt : dt - dq;
                 ti = s_ind[j] + gap; tl = s_sl[j] + dq;
-                if ((long long)ti * 1000 <= (long long)tl * A.bw) {
+                // 64-bit divisions cost ~150 VALU ops on gfx950; the operands fit 32 bits for every read below 2^17 bases
+                // (ti <= tl*bw/1000 <= 2621, sc <= 63): same quotient either way
+                if (tl < (1 << 17) && gap < (1 << 17) && A.bw <= 20) {
+                    if ((uint32_t)ti * 1000u <= (uint32_t)tl * (uint32_t)A.bw) {
+                        int sc = min(min(dq, dt), A.k_score);
+                        if (ti) sc -= (int)(((uint32_t)ti * (uint32_t)sc * 1000u) / ((uint32_t)tl * (uint32_t)A.bw));
+                        cand = sc + s_f[j];
+                    }
+                } else if ((long long)ti * 1000 <= (long long)tl * A.bw) {
                     int sc = min(min(dq, dt), A.k_score);
                     if (ti) sc -= (int)(((long long)ti * sc * 1000) / ((long long)tl * A.bw));
                     cand = sc + s_f[j];
@@ -613,9 +621,12 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     for (int i = 0; i < 13; i++) dst[i] = make_uint2(ops32[2 * i], ops32[2 * i + 1]);
 }
 
-// Full K6: forward pass keeping {D0, VP, VN} per column in a per-lane slice of an HBM scratch
-// ([column][word][lane], coalesced), the reference's walk back, generate_cigar's end trimming and greedy
-// gap left-shift, then the path is packed start-to-end.
+// Full K6: forward pass keeping {D0, VP, VN} of every column in a per-lane slice of an HBM scratch ([column][word][lane],
+// coalesced 512-byte stores), the reference's walk back, generate_cigar's end trimming and greedy gap left-shift; the
+// path under construction lives in LDS (2 bits per op) and is packed start-to-end at the end.
+// (A variant that checkpoints the DP state every 16 columns and recomputes blocks into an LDS tile during the walk back
+//  cut the scratch traffic 8x but ran 1.4x slower: the tile costs occupancy and the lanes cross block boundaries at
+//  different steps, so the wave replays each block several times.  Measured round 1, kept out.)
 struct PathSink {
     uint64_t *cols; uint32_t stride, lane;
     __device__ __forceinline__ void operator()(int i, uint64_t d0, uint64_t vp, uint64_t vn) const
@@ -623,6 +634,7 @@ struct PathSink {
         uint64_t *c = cols + (size_t)(i + 1) * 3 * stride + lane;
         c[0] = d0; c[stride] = vp; c[2 * (size_t)stride] = vn;
     }
+    __device__ __forceinline__ void block(int, const BpmState &) const {}
 };
 
 __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
@@ -630,6 +642,8 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
                                                 fsv_wpath *__restrict__ paths, uint64_t *__restrict__ cols, uint8_t *__restrict__ tmp,
                                                 uint32_t stride)
 {
+    __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
+    const int lane64 = threadIdx.x;
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     const uint32_t li = list_begin + slot;
     if (li >= list_end) return;
@@ -642,7 +656,9 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
     bpm_run(store, t, r, sink);
     if (r.err < 0) { P->state = 0; return; } // cannot happen: K5 matched this window
 #define COL(c, w) cols[((size_t)(c) * 3 + (w)) * stride + slot]
-#define TMP(i) tmp[(size_t)(i) * stride + slot]
+#define TMP(i) ((s_ops[(i) >> 4][lane64] >> (((i) & 15) << 1)) & 3u)
+#define TMP_SET(i, v) do { const int w_ = (i) >> 4, sh_ = ((i) & 15) << 1; s_ops[w_][lane64] = (s_ops[w_][lane64] & ~(3u << sh_)) | ((uint32_t)(v) << sh_); } while (0)
+    for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
     int end = r.end_site, err = r.err;
     int cur = err, col = n, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
     while (col > 0 && cur != 0) {
@@ -660,30 +676,30 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
         if (dir == 0) { if (diag != cur) dir = 1; col--; start--; }
         else if (dir == 2) { row--; start--; }
         else { col--; row++; }
-        TMP(plen) = (uint8_t)dir; plen++;
+        TMP_SET(plen, dir); plen++;
         cur = best;
     }
-    if (col > 0) { for (int i = 0; i < col; i++) TMP(plen + i) = 0; start -= col; plen += col; dir = 0; }
+    if (col > 0) { start -= col; plen += col; dir = 0; } // the rest of the path is matches: the fields are already 0
     if (dir != 3) start++;
     // generate_cigar: TMP is stored end-to-start
     if (err > 0) {
         int stop = -1;
-        for (int i = 0; i < plen && TMP(i) == 1; i++) { TMP(i) = 3; end--; stop = i; }
-        for (int i = plen - 1; i >= 0 && TMP(i) == 1; i--) { TMP(i) = 3; start++; }
+        for (int i = 0; i < plen && TMP(i) == 1; i++) { TMP_SET(i, 3); end--; stop = i; }
+        for (int i = plen - 1; i >= 0 && TMP(i) == 1; i--) { TMP_SET(i, 3); start++; }
         int xi = 0, yi = 0;
         for (int i = plen - 1; i > stop; i--) {
-            const uint8_t op = TMP(i);
+            const uint32_t op = TMP(i);
             if (op < 2) { xi++; yi++; continue; }
             // shift this gap towards the alignment start while the bases it passes still pair up (move_gap_greedy)
             int pi = i + 1, x2 = xi, y2 = yi;
             if (op == 3) y2--; else x2--;
             for (; pi < plen && x2 >= 0 && y2 >= 0; pi++, x2--, y2--) {
-                const uint8_t pv = TMP(pi);
+                const uint32_t pv = TMP(pi);
                 const bool same = fsv_base_fwd(store, t.x_word, t.x_start + x2) == task_ybase(store, t, start + y2);
                 if (pv >= 2 || (pv == 0 && !same)) break;
-                if (pv == 1 && same) { TMP(pi - 1) = 0; err--; }
-                else TMP(pi - 1) = pv;
-                TMP(pi) = op;
+                if (pv == 1 && same) { TMP_SET(pi - 1, 0); err--; }
+                else TMP_SET(pi - 1, pv);
+                TMP_SET(pi, op);
             }
             if (op == 2) yi++; else xi++;
         }
@@ -700,6 +716,7 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
     P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
 #undef COL
 #undef TMP
+#undef TMP_SET
 }
 
 // ------------------------------------------------------------------------------------------------ k_consensus

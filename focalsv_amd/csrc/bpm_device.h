@@ -111,9 +111,11 @@ __device__ __forceinline__ uint32_t fetch16_x(const uint32_t *__restrict__ store
     return sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
 }
 
-// Column sink for K6: called once per DP column with that column's D0 and the post-update VP/VN.
+// Hooks for K6: `sink` sees every DP column (D0 and the post-update VP/VN); `block` sees the whole state in front of
+// every 16-column block (K6 checkpoints it so that the walk back can recompute one block at a time).
 struct BpmNoSink {
     __device__ __forceinline__ void operator()(int, uint64_t, uint64_t, uint64_t) const {}
+    __device__ __forceinline__ void block(int, const BpmState &) const {}
 };
 
 template <class Sink>
@@ -138,6 +140,7 @@ __device__ __forceinline__ void bpm_run(const uint32_t *__restrict__ store, cons
         const uint32_t xn = fetch16_x(store, t.x_word, t.x_start + blk + 16);
         const Bases16 yn = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1 + blk + 16);
         const int lim = min(16, n - blk);
+        sink.block(blk >> 4, s);
         for (int j = 0; j < lim; j++) {
             const int i = blk + j;
             const uint32_t c = (xb >> (2 * j)) & 3u;
@@ -163,4 +166,31 @@ __device__ __forceinline__ void bpm_run(const uint32_t *__restrict__ store, cons
     int best;
     r.end_site = bpm_pick_end(s, err, n, k, best);
     r.err = best;
+}
+
+// Recompute the columns of block b (x indices 16b .. 16b+15) from the state in front of it; out(j, d0, vp, vn) for column 16b+j.
+template <class Out>
+__device__ __forceinline__ void bpm_replay_block(const uint32_t *__restrict__ store, const fsv_wtask &t, int b, BpmState s, Out out)
+{
+    const int n = t.x_len, k = t.k, blk = b << 4;
+    const uint64_t top = 1ull << (2 * k);
+    const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + blk);
+    const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, t.y_start - k + 2 * k + 1 + blk);
+    const int lim = min(16, n - blk);
+    for (int j = 0; j < lim; j++) {
+        const int i = blk + j;
+        const uint32_t c = (xb >> (2 * j)) & 3u;
+        uint64_t x = bpm_pick_eq(s, c) | s.vn;
+        uint64_t d0 = ((s.vp + (x & s.vp)) ^ s.vp) | x;
+        uint64_t hn = s.vp & d0;
+        uint64_t hp = s.vn | ~(s.vp | d0);
+        uint64_t sh = d0 >> 1;
+        s.vn = sh & hp;
+        s.vp = hn | ~(sh | hp);
+        out(j, d0, s.vp, s.vn);
+        if (i + 1 < n) {
+            s.eq0 >>= 1; s.eq1 >>= 1; s.eq2 >>= 1; s.eq3 >>= 1;
+            if ((yb.valid >> j) & 1u) bpm_eq_set(s, (yb.bits >> (2 * j)) & 3u, top);
+        }
+    }
 }

@@ -16,14 +16,21 @@ def compare_sigs(a, b, max_shift=500, min_size_sim=0.3):
 
 
 def eval_sig(sigs, read_sigs, max_dist, max_comp_svlen=300, max_shift=500, min_size_sim=0.3):
-    """read_sigs must be position-sorted: the scan stops at the first one more than max_dist to the right"""
+    """read_sigs must be position-sorted: the reference scans from the start, skips everything more than max_dist to
+    the left and stops at the first one more than max_dist to the right.  On sorted input that is a range query, so the
+    left end is found by bisection (same counts; falls back to the literal scan when the input is not sorted)."""
+    from bisect import bisect_left
+    pos = [b[2] for b in read_sigs]
+    is_sorted = all(pos[i] <= pos[i + 1] for i in range(len(pos) - 1))
     out = []
     for a in sigs:
         if a[3] > max_comp_svlen:
             out.append(60)
             continue
         n = 0
-        for b in read_sigs:
+        start = bisect_left(pos, a[2] - max_dist) if is_sorted else 0
+        for k in range(start, len(read_sigs)):
+            b = read_sigs[k]
             shift = b[2] - a[2]
             if shift < -max_dist:
                 continue
