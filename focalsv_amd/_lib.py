@@ -16,6 +16,7 @@ FSV_WINDOW, FSV_K_FULL, FSV_K_MAX = 375, 15, 31
 WTASK_DTYPE = np.dtype(
     [("x_word", "<u4"), ("y_word", "<u4"), ("x_start", "<i4"), ("y_start", "<i4"), ("y_len", "<i4"),
      ("x_len", "<u2"), ("k", "u1"), ("y_rev", "u1"), ("ovl", "<u4"), ("win", "<u4")], align=False)
+MZ_DTYPE = np.dtype([("hash", "<u8"), ("pos", "<u4"), ("rev", "u1"), ("span", "u1"), ("pad", "<u2")])
 WRES_DTYPE = np.dtype(
     [("end_site", "<i4"), ("err", "<i4"), ("y_beg", "<i4"), ("extra_begin", "<i2"), ("extra_end", "<i2")], align=False)
 assert WTASK_DTYPE.itemsize == 32 and WRES_DTYPE.itemsize == 16
@@ -109,6 +110,7 @@ def load():
         "fsv_assemble_batch": (C.c_int, [vp, C.POINTER(ReadSets), C.POINTER(AsmParams), C.POINTER(Contigs)]),
         "fsv_asm_last_stats": (C.c_int, [vp, C.POINTER(AsmStats)]),
         "fsv_asm_fetch_reads": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint32]),
+        "fsv_sketch_reads": (C.c_int, [vp, C.POINTER(ReadSets), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_uint64, vp]),
         "fsv_aln_default_params": (None, [C.POINTER(AlnParams)]),
         "fsv_align_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.POINTER(AlnParams), C.POINTER(Alns)]),
         "fsv_aln_last_stats": (C.c_int, [vp, C.POINTER(AlnStats)]),
@@ -237,6 +239,18 @@ class Context:
         n = out.n_contigs
         contigs = [seq[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
         return contigs, cset[:n].copy(), cnr[:n].copy(), status[:rs.n_sets].copy()
+
+    def sketch_reads(self, store_dev, word_off, read_len, w=51, k=51, hpc=1, variant=0):
+        """K1 exposed: per read, its minimizers in position order -> list of structured arrays (hash, pos, rev, span)"""
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        read_len = np.ascontiguousarray(read_len, dtype=np.int32)
+        ss = np.asarray([0, len(read_len)], dtype=np.uint32)
+        rs = ReadSets(C.c_void_p(store_dev), _ptr(word_off).value, _ptr(read_len).value, _ptr(ss).value, len(read_len), 1)
+        cap = int(read_len.sum()) + 64 * len(read_len) + 64
+        out = np.zeros(cap, dtype=MZ_DTYPE)
+        off = np.zeros(len(read_len) + 1, dtype=np.uint64)
+        self.check(self._lib.fsv_sketch_reads(self._h, C.byref(rs), w, k, hpc, variant, _ptr(out), cap, _ptr(off)), "fsv_sketch_reads")
+        return [out[int(off[i]):int(off[i + 1])].copy() for i in range(len(read_len))]
 
     def asm_stats(self):
         st = AsmStats()

@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, 
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 struct AlnWs {
-    DevBuf store, word_off, len, wper, pair_q, pair_t, mz, mz_off, mz_cnt, warn, chain, hdr, events, tasks, bt, rows, cg, cg_n, scores;
+    DevBuf store, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, tasks, bt, rows, cg, cg_n, scores;
     fsv_aln_stats stats;
-    std::vector<DevBuf *> all() { return {&store, &word_off, &len, &wper, &pair_q, &pair_t, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
+    std::vector<DevBuf *> all() { return {&store, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
 };
 
 void aln_ws_free(fsv_ctx *ctx)
@@ -514,7 +514,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     TRY(upload(ctx, W.pair_t, pair_t));
     std::vector<uint32_t> mz_off(nr + 1, 0);
     uint64_t m = 0;
-    for (uint32_t r = 0; r < nr; r++) { mz_off[r] = (uint32_t)m; m += (uint64_t)len[r] / 8 + 64; }
+    for (uint32_t r = 0; r < nr; r++) { mz_off[r] = (uint32_t)m; m += (uint64_t)len[r] + 64; } // worst case one minimizer per base
     if (m >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "alignment batch too large; split it");
     mz_off[nr] = (uint32_t)m;
     TRY(upload(ctx, W.mz_off, mz_off));
@@ -523,13 +523,25 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     TRY(ensure(ctx, W.warn, (size_t)nr * 4));
     FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)nr * 4, ctx->stream));
     FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)nr * 4, ctx->stream));
-    uint32_t max_words = 1; int w_max = 1;
-    for (uint32_t r = 0; r < nr; r++) { max_words = std::max<uint32_t>(max_words, (uint32_t)((len[r] + 15) / 16)); w_max = std::max<int>(w_max, wper[r]); }
-    const uint32_t lds_words = std::min<uint32_t>(max_words, 8192u);
-    FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(w_max, lds_words)));
-    hipLaunchKernelGGL(k_sketch, dim3(nr), dim3(64), sketch_lds_bytes(w_max, lds_words), ctx->stream, (const uint32_t *)W.store.p,
-                       (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p,
-                       (uint32_t *)W.mz_cnt.p, nr, P.w, P.k, 0, (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p, w_max, lds_words);
+    if (P.k & 1) {
+        const size_t total_words = word_off[nr];
+        TRY(ensure(ctx, W.sk_ends, (total_words * 16 + 64) * 4));
+        TRY(ensure(ctx, W.sk_low, (total_words + nr + 8) * 4));
+        TRY(ensure(ctx, W.sk_high, (total_words + nr + 8) * 4));
+        FSV_HIP(ctx, hipMemsetAsync(W.sk_low.p, 0, (total_words + nr + 8) * 4, ctx->stream));
+        FSV_HIP(ctx, hipMemsetAsync(W.sk_high.p, 0, (total_words + nr + 8) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_sketch_fast, dim3(nr), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, nr, P.w, P.k, 0,
+                           (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p);
+    } else {
+        uint32_t max_words = 1; int w_max = 1;
+        for (uint32_t r = 0; r < nr; r++) { max_words = std::max<uint32_t>(max_words, (uint32_t)((len[r] + 15) / 16)); w_max = std::max<int>(w_max, wper[r]); }
+        const uint32_t lds_words = std::min<uint32_t>(max_words, 8192u);
+        FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(w_max, lds_words)));
+        hipLaunchKernelGGL(k_sketch, dim3(nr), dim3(64), sketch_lds_bytes(w_max, lds_words), ctx->stream, (const uint32_t *)W.store.p,
+                           (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p,
+                           (uint32_t *)W.mz_cnt.p, nr, P.w, P.k, 0, (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p, w_max, lds_words);
+    }
     FSV_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_uniq<ALN_AMAX>, dim3(nr), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (uint32_t *)W.mz_cnt.p,
                        (uint32_t *)W.warn.p);

@@ -35,7 +35,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
 
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
-        cols, tmp, gwin_off, gwin_read, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -46,7 +46,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -112,7 +112,11 @@ struct Geometry {
     uint32_t max_words = 1;
 };
 
-int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len, Geometry &G)
+// minimizer slots of a read: the worst case is one per base (inside a long homopolymer or a short-unit tandem repeat every
+// k-mer ties with the window minimum and ha_sketch reports all of them); 16 B x bases is 2 % of HBM for 256 regions
+static inline uint64_t mz_slots(int64_t len, int) { return (uint64_t)len + 64; }
+
+int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len, Geometry &G, int mz_w = 51)
 {
     G.word_off.assign(B.n_reads + 1, 0); G.mz_off.assign(B.n_reads + 1, 0); G.gwin_off.assign(B.n_reads + 1, 0);
     G.max_words = 1;
@@ -121,7 +125,7 @@ int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len,
         G.word_off[r] = (uint32_t)w; G.mz_off[r] = (uint32_t)m; G.gwin_off[r] = (uint32_t)g;
         w += (uint64_t)(len[r] + 15) / 16;
         G.max_words = std::max<uint32_t>(G.max_words, (uint32_t)((len[r] + 15) / 16));
-        m += (uint64_t)len[r] / 8 + 64;
+        m += mz_slots(len[r], mz_w);
         g += (uint64_t)(len[r] + FSV_WINDOW - 1) / FSV_WINDOW;
     }
     if (w + 4 >= (1ull << 32) || m >= (1ull << 32) || g >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "batch too large for 32-bit offsets; split it");
@@ -150,12 +154,26 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, 64, ctx->stream));
     W.kt.begin(ctx, KN_SKETCH, (uint64_t)G.word_off[B.n_reads] * 4 + (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz));
     FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)B.n_reads * 4, ctx->stream));
-    const uint32_t lds_words = std::min<uint32_t>(G.max_words, 8192u);
-    FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(P.w, lds_words)));
-    hipLaunchKernelGGL(k_sketch, dim3(B.n_reads), dim3(64), sketch_lds_bytes(P.w, lds_words), ctx->stream, store, (const uint32_t *)W.word_off.p,
-                       (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
-                       P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, P.w, lds_words);
-    FSV_HIP(ctx, hipGetLastError());
+    if (P.k & 1) {
+        // position-parallel sketch (odd k): per-read scratch for run ends (4 B / base) and two bit planes, planes zeroed per launch
+        const size_t total_words = G.word_off[B.n_reads];
+        TRY(ensure(ctx, W.sk_ends, (total_words * 16 + 64) * 4));
+        TRY(ensure(ctx, W.sk_low, (total_words + B.n_reads + 8) * 4));
+        TRY(ensure(ctx, W.sk_high, (total_words + B.n_reads + 8) * 4));
+        FSV_HIP(ctx, hipMemsetAsync(W.sk_low.p, 0, (total_words + B.n_reads + 8) * 4, ctx->stream));
+        FSV_HIP(ctx, hipMemsetAsync(W.sk_high.p, 0, (total_words + B.n_reads + 8) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_sketch_fast, dim3(B.n_reads), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
+                           P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p);
+        FSV_HIP(ctx, hipGetLastError());
+    } else {
+        const uint32_t lds_words = std::min<uint32_t>(G.max_words, 8192u);
+        FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(P.w, lds_words)));
+        hipLaunchKernelGGL(k_sketch, dim3(B.n_reads), dim3(64), sketch_lds_bytes(P.w, lds_words), ctx->stream, store, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
+                           P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, P.w, lds_words);
+        FSV_HIP(ctx, hipGetLastError());
+    }
     W.kt.end(ctx);
     W.kt.begin(ctx, KN_UNIQ, (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz) * 2);
     hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
@@ -309,7 +327,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)B.n_reads * 4, ctx->stream));
 
     Geometry G;
-    TRY(make_geometry(ctx, B, len, G));
+    TRY(make_geometry(ctx, B, len, G, P.w));
     // round 0 reads the caller's store through the caller's word offsets
     std::vector<uint32_t> woff0(B.n_reads + 1);
     for (uint32_t r = 0; r <= B.n_reads; r++) {
@@ -404,7 +422,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         FSV_HIP(ctx, hipMemcpyAsync(nlen.data(), W.new_len.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         Geometry G2;
-        TRY(make_geometry(ctx, B, nlen, G2));
+        TRY(make_geometry(ctx, B, nlen, G2, P.w));
         DevBuf &dst = W.store[round & 1];
         const uint32_t total_words = G2.word_off[B.n_reads];
         TRY(ensure(ctx, dst, ((size_t)total_words + 8) * 4));
@@ -521,4 +539,69 @@ extern "C" int fsv_asm_fetch_reads(fsv_ctx *ctx, char *seq, uint64_t seq_cap, ui
     if (d_out.p) (void)hipFree(d_out.p);
     memcpy(off, o.data(), (n_reads + 1) * sizeof(uint64_t));
     return rc;
+}
+
+extern "C" int fsv_sketch_reads(fsv_ctx *ctx, const fsv_readsets *sets, int32_t w, int32_t k, int32_t hpc, int32_t variant, fsv_mz *out_mz,
+                                uint64_t out_cap, uint64_t *out_off)
+{
+    if (!ctx || !sets || !sets->store_dev || !sets->word_off || !sets->read_len || !out_mz || !out_off) return FSV_EINVAL;
+    if (k < 1 || k > 63 || w < 1 || w > 64) return fsv_fail(ctx, FSV_EINVAL, "k <= 63, w <= 64");
+    FSV_HIP(ctx, hipSetDevice(ctx->device));
+    AsmWs &W = *ws_get(ctx);
+    W.kt.reset();
+    Batch B;
+    B.n_reads = sets->n_reads; B.n_sets = 1; B.n_pairs = 0;
+    B.set_start = {0u, B.n_reads};
+    out_off[0] = 0;
+    if (B.n_reads == 0) return FSV_OK;
+    std::vector<int32_t> len(sets->read_len, sets->read_len + B.n_reads);
+    for (uint32_t r = 0; r < B.n_reads; r++) if (len[r] < 1 || len[r] >= (1 << 24)) return fsv_fail(ctx, FSV_EUNSUP, "read length must be in [1, 2^24)");
+    Geometry G;
+    TRY(make_geometry(ctx, B, len, G, w));
+    for (uint32_t r = 0; r <= B.n_reads; r++) G.word_off[r] = (uint32_t)sets->word_off[r];
+    TRY(upload(ctx, W.word_off, G.word_off));
+    TRY(upload(ctx, W.len, len));
+    TRY(upload(ctx, W.mz_off, G.mz_off));
+    TRY(ensure(ctx, W.warn, (size_t)B.n_reads * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+    fsv_asm_params P;
+    fsv_asm_default_params(&P);
+    P.w = w; P.k = (variant == 1) ? (k | 0) : k; P.hpc = hpc;
+    // overlap_stage picks the kernel by the parity of k; to force the replay kernel for an odd k, run its launch here
+    TRY(ensure(ctx, W.mz, (size_t)G.mz_off[B.n_reads] * sizeof(fsv_mz)));
+    TRY(ensure(ctx, W.mz_cnt, (size_t)B.n_reads * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+    if ((k & 1) && variant != 1) {
+        const size_t total_words = G.word_off[B.n_reads];
+        TRY(ensure(ctx, W.sk_ends, (total_words * 16 + 64) * 4));
+        TRY(ensure(ctx, W.sk_low, (total_words + B.n_reads + 8) * 4));
+        TRY(ensure(ctx, W.sk_high, (total_words + B.n_reads + 8) * 4));
+        FSV_HIP(ctx, hipMemsetAsync(W.sk_low.p, 0, (total_words + B.n_reads + 8) * 4, ctx->stream));
+        FSV_HIP(ctx, hipMemsetAsync(W.sk_high.p, 0, (total_words + B.n_reads + 8) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_sketch_fast, dim3(B.n_reads), dim3(256), 0, ctx->stream, sets->store_dev, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, w, k, hpc,
+                           (uint32_t *)W.warn.p, (const uint8_t *)nullptr, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p);
+    } else {
+        const uint32_t lds_words = std::min<uint32_t>(G.max_words, 8192u);
+        FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(w, lds_words)));
+        hipLaunchKernelGGL(k_sketch, dim3(B.n_reads), dim3(64), sketch_lds_bytes(w, lds_words), ctx->stream, sets->store_dev,
+                           (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p,
+                           (uint32_t *)W.mz_cnt.p, B.n_reads, w, k, hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, w, lds_words);
+    }
+    FSV_HIP(ctx, hipGetLastError());
+    std::vector<uint32_t> cnt(B.n_reads);
+    FSV_HIP(ctx, hipMemcpyAsync(cnt.data(), W.mz_cnt.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t tot = 0;
+    for (uint32_t r = 0; r < B.n_reads; r++) {
+        const uint32_t c = std::min<uint32_t>(cnt[r], G.mz_off[r + 1] - G.mz_off[r]);
+        if (tot + c > out_cap) return fsv_fail(ctx, FSV_ECAP, "out_mz too small");
+        FSV_HIP(ctx, hipMemcpyAsync(out_mz + tot, (const fsv_mz *)W.mz.p + G.mz_off[r], (size_t)c * sizeof(fsv_mz), hipMemcpyDeviceToHost, ctx->stream));
+        tot += c;
+        out_off[r + 1] = tot;
+    }
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t r = 0; r < B.n_reads; r++)
+        std::sort(out_mz + out_off[r], out_mz + out_off[r + 1], [](const fsv_mz &a, const fsv_mz &b) { return a.pos < b.pos; });
+    return FSV_OK;
 }

@@ -100,7 +100,10 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
     if (staged) for (uint32_t i = lane; i < nwords; i += 64) s_words[i] = store[woff + i];
     __syncthreads();
     WordCache B{staged ? (const uint32_t *)s_words : store + woff, 0u, -1};
-    const int c0 = (int)((long long)len * lane / 64), c1 = (int)((long long)len * (lane + 1) / 64);
+    // For even k palindromic k-mers are skipped (sketch.cpp:84), so a fixed warm-up cannot guarantee w entries: lane 0 then
+    // replays the whole read from base 0 (exact, 64x less parallel; hifiasm's k = 51 and minimap2's 19 are odd and use k_sketch_fast).
+    const bool single = (k & 1) == 0;
+    const int c0 = single ? 0 : (int)((long long)len * lane / 64), c1 = single ? (lane == 0 ? len : 0) : (int)((long long)len * (lane + 1) / 64);
     if (c1 <= c0) return;
     int b0 = c0;
     if (hpc) {
@@ -1017,4 +1020,169 @@ __global__ void k_unpack_reads(const uint32_t *__restrict__ store, const uint32_
     for (int i = threadIdx.x; i < len; i += blockDim.x) out[dst_off[r] + i] = "ACGT"[fsv_base_fwd(store, w, i)];
 }
 
+} // namespace
+
+namespace {
+// ------------------------------------------------------------------------------------------------ k_sketch_fast
+// Position-parallel form of ha_sketch (sketch.cpp:39-137) for odd k (hifiasm's 51, minimap2's 19): no sequential replay.
+//   phase 0  homopolymer compression in parallel: run ends are found per 16-base word, a block scan gives every kept
+//            base its entry index; the compressed bases go to two bit planes, the run-end positions to an array
+//            (per-read slices of an HBM scratch, L2-resident for the block that wrote them);
+//   phase 1  every entry's k-mer is cut out of the bit planes with funnel shifts (forward strand = bit-reversed,
+//            reverse strand = complemented), hashed, and the span is a difference of two run-end positions;
+//   phase 2  ha_sketch reports an entry iff it equals the minimum of some window of w entries that ends at or after the
+//            first full one (as the window's "best" or as an identical-k-mer copy); window minima and the test are
+//            brute-force scans of an LDS tile.  The irregular first full window (l == w+k-1: copies of the previous
+//            partial window's minimum are reported, that minimum itself only if the incoming k-mer is larger) and reads
+//            shorter than one window (only the last minimum) are handled explicitly.
+// Equivalent to the monotone-deque replay in k_sketch (which stays for even k); both are checked against the oracle.
+#define SKF_T 1024
+__global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                                     const int32_t *__restrict__ read_len, const uint32_t *__restrict__ mz_off,
+                                                     fsv_mz *__restrict__ mz, uint32_t *__restrict__ mz_cnt, uint32_t n_reads, int w, int k,
+                                                     int hpc, uint32_t *__restrict__ warn, const uint8_t *__restrict__ w_per_read,
+                                                     uint32_t *__restrict__ sc_ends, uint32_t *__restrict__ sc_low, uint32_t *__restrict__ sc_high)
+{
+    __shared__ uint64_t s_h[SKF_T + 2 * 64];
+    __shared__ uint64_t s_wmin[SKF_T + 64];
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_carry;
+    __shared__ uint64_t s_am, s_ah;   // start anomaly: minimum of the partial window, hash of entry T0
+    __shared__ int s_abest, s_short;  // its rightmost position; the single minimizer of a read shorter than one window
+    const int tid = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t woff = word_off[r];
+    const int len = read_len[r];
+    const uint32_t cap = mz_off[r + 1] - mz_off[r];
+    fsv_mz *out = mz + mz_off[r];
+    if (w_per_read) w = w_per_read[r];
+    uint32_t *ends = sc_ends + (size_t)woff * 16;          // entry -> index of the run's last base
+    uint32_t *low = sc_low + woff + r, *high = sc_high + woff + r; // bit planes of the compressed bases (zeroed by the host)
+    const uint64_t NONE = ~0ull;
+    const uint64_t kmask = (1ull << k) - 1;
+    // ---- phase 0
+    const int nwords = (len + 15) >> 4;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int wbase = 0; wbase < nwords; wbase += 256) {
+        const int wi = wbase + tid;
+        uint32_t flags = 0, word = 0;
+        int nb = 0;
+        if (wi < nwords) {
+            word = store[woff + wi];
+            nb = min(16, len - wi * 16);
+            if (hpc) {
+                const uint32_t nextb = (wi + 1 < nwords) ? (store[woff + wi + 1] & 3u) : 4u;
+                // base j ends a run when it differs from base j+1 (the read's last base always does)
+                const uint32_t shifted = (word >> 2) | (nextb << 30);
+                uint32_t d = word ^ shifted;
+                d = (d | (d >> 1)) & 0x55555555u; // field j non-zero <=> base j != base j+1
+                for (int j = 0; j < nb; j++) {
+                    const bool last = (wi * 16 + j == len - 1);
+                    if (last || ((d >> (2 * j)) & 1u) || (j == 15 && nextb == 4u)) flags |= 1u << j;
+                }
+            } else flags = nb >= 16 ? 0xffffu : ((1u << nb) - 1u);
+        }
+        const uint32_t cnt = __popc(flags);
+        s_scan[tid] = cnt;
+        __syncthreads();
+        // exclusive scan over the 256 threads (Hillis-Steele in LDS)
+        for (int off = 1; off < 256; off <<= 1) {
+            uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t incl = s_scan[tid], base = s_carry + incl - cnt;
+        if (cnt) {
+            uint32_t lo = 0, hi = 0, rank = 0;
+            for (int j = 0; j < nb; j++)
+                if ((flags >> j) & 1u) {
+                    const uint32_t b = (word >> (2 * j)) & 3u;
+                    lo |= (b & 1u) << rank; hi |= (b >> 1) << rank;
+                    ends[base + rank] = (uint32_t)(wi * 16 + j);
+                    rank++;
+                }
+            const uint32_t wd = base >> 5, sh = base & 31u;
+            atomicOr(&low[wd], lo << sh); atomicOr(&high[wd], hi << sh);
+            if (sh + cnt > 32) { atomicOr(&low[wd + 1], lo >> (32 - sh)); atomicOr(&high[wd + 1], hi >> (32 - sh)); }
+        }
+        __syncthreads();
+        if (tid == 255) s_carry += incl;
+        __syncthreads();
+    }
+    const int M = (int)s_carry; // entries
+    const int T0 = w + k - 2;   // entry index of the first full window (l == w+k-1)
+    __threadfence_block();
+    __syncthreads();
+    // k consecutive plane bits starting at entry a (a >= 0), bit i = entry a+i
+    auto cut = [&](const uint32_t *pl, int a) -> uint64_t {
+        const int wd = a >> 5, sh = a & 31;
+        const uint64_t lo64 = (uint64_t)pl[wd] | (uint64_t)pl[wd + 1] << 32;
+        uint64_t v = lo64 >> sh;
+        if (sh) v |= (uint64_t)pl[wd + 2] << (64 - sh);
+        return v & kmask;
+    };
+    auto entry_hash = [&](int e, int *z_out) -> uint64_t {
+        if (e < k - 1 || e >= M) return NONE;
+        const int span = (int)ends[e] - (e - k >= 0 ? (int)ends[e - k] : -1);
+        if (hpc && span >= 256) return NONE;
+        const uint64_t lo = cut(low, e - k + 1), hi = cut(high, e - k + 1);
+        // forward strand: oldest base in the top bit; reverse strand: complement, oldest base in bit 0
+        const uint64_t f0 = __brevll(lo) >> (64 - k), f1 = __brevll(hi) >> (64 - k);
+        const uint64_t r0 = ~lo & kmask, r1 = ~hi & kmask;
+        const int z = f1 < r1 ? 0 : 1;
+        if (z_out) *z_out = z;
+        return z ? mix64(r0) + mix64(r1) : mix64(f0) + mix64(f1);
+    };
+    auto emit = [&](int p) {
+        int z = 0;
+        const uint64_t h = entry_hash(p, &z);
+        const int span = hpc ? (int)ends[p] - (p - k >= 0 ? (int)ends[p - k] : -1) : k;
+        const uint32_t at = atomicAdd(&mz_cnt[r], 1u);
+        if (at < cap) { fsv_mz m; m.hash = h; m.pos = ends[p]; m.rev = (uint8_t)z; m.span = (uint8_t)span; m.pad = 0; out[at] = m; }
+        else atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC);
+    };
+    for (int t0 = 0; t0 < M; t0 += SKF_T) {
+        const int e0 = t0 - (w - 1); // entry held by s_h[0]
+        for (int idx = tid; idx < SKF_T + 2 * (w - 1); idx += 256) s_h[idx] = entry_hash(e0 + idx, nullptr);
+        __syncthreads();
+        // window minima: s_wmin[i] = min over entries (t0+i)-(w-1) .. (t0+i)
+        for (int i = tid; i < SKF_T + (w - 1); i += 256) {
+            uint64_t m = NONE;
+            for (int j = 0; j < w; j++) m = min(m, s_h[i + j]);
+            s_wmin[i] = m;
+        }
+        if (t0 == 0 && tid == 0) {
+            s_short = -1; s_abest = -1; s_am = NONE; s_ah = NONE;
+            if (M <= T0) { // shorter than one window: only the last minimum (rightmost on ties)
+                uint64_t m = NONE; int bp = -1;
+                for (int p = max(0, M - w); p < M; p++) { const uint64_t h = s_h[p - e0]; if (h != NONE && h <= m) { m = h; bp = p; } }
+                s_short = bp;
+            } else {
+                uint64_t m = NONE; int bp = -1;
+                for (int p = T0 - w + 1; p <= T0 - 1; p++) { const uint64_t h = s_h[p - e0]; if (h != NONE && h <= m) { m = h; bp = p; } }
+                s_am = m; s_abest = bp; s_ah = s_h[T0 - e0];
+            }
+        }
+        __syncthreads();
+        for (int pi = tid; pi < SKF_T; pi += 256) {
+            const int p = t0 + pi;
+            if (p >= M) break;
+            const uint64_t hp = s_h[pi + (w - 1)];
+            if (hp == NONE) continue;
+            bool e;
+            if (M <= T0) e = (p == s_short);
+            else {
+                e = false;
+                const int lo = max(p, T0), hi = min(p + w - 1, M - 1);
+                for (int t = lo; t <= hi && !e; t++) e = (s_wmin[t - t0] == hp);
+                if (p >= T0 - w + 1 && p <= T0 - 1 && s_am != NONE && hp == s_am) e = (p != s_abest) ? true : (s_ah > s_am);
+            }
+            if (e) emit(p);
+        }
+        __syncthreads();
+    }
+}
 } // namespace

@@ -207,6 +207,12 @@ int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out);
  * can be fetched as ASCII (same order as the input reads). */
 int fsv_asm_fetch_reads(fsv_ctx *ctx, char *seq, uint64_t seq_cap, uint64_t *off, uint32_t n_reads);
 
+/* ---- K1 exposed: minimizer sketch of every read (ha_sketch, sketch.cpp:39-137) -------------------------
+ * out_mz receives, per read, its minimizers in position order; out_off (n_reads+1) indexes them.
+ * variant: 0 = library's choice (position-parallel kernel for odd k, deque replay otherwise), 1 = force the replay kernel. */
+int fsv_sketch_reads(fsv_ctx *ctx, const fsv_readsets *sets, int32_t w, int32_t k, int32_t hpc, int32_t variant,
+                     fsv_mz *out_mz, uint64_t out_cap, uint64_t *out_off);
+
 /* ---- aligner boundary ---------------------------------------------------------
  * Replaces `minimap2 -a -x asm5 --cs -r2k ref_chr.fa assemblies.fa | samtools sort` and the pysam read-back
  * (focalsv/4_sv_calling/Dippav/DipPAV_variant_call.py:103-112; fields consumed by
