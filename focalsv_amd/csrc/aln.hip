@@ -40,8 +40,8 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
     const int lane = threadIdx.x;
     const uint32_t p = blockIdx.x, rq = pair_q[p], rt = pair_t[p];
     const int lenq = read_len[rq];
-    const fsv_mz *mq = mz + mz_off[rq], *mt = mz + mz_off[rt];
     const int nq = (int)mz_cnt[rq], nt = (int)mz_cnt[rt];
+    const fsv_mz *mq = mz + mz_off[rq] + nq, *mt = mz + mz_off[rt]; // contig: position-sorted copy, reference: hash-sorted
     AlnHeader h; h.qbeg = h.tbeg = h.qend = h.tend = 0; h.n_events = 0; h.n_chain = 0; h.rev = 0; h.status = 1;
     int n = 0, nrev = 0, nfwd = 0;
     for (int base = 0; base < nq; base += 64) {
@@ -85,18 +85,11 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
     }
     n = m2;
     if (n < P.min_anchors) { if (lane == 0) hdr[p] = h; return; }
-    int np = 1;
-    while (np < n) np <<= 1;
-    for (int i = n + lane; i < np; i += 64) s_key[i] = ~0ull;
-    __syncthreads();
-    for (int sz = 2; sz <= np; sz <<= 1)
-        for (int st = sz >> 1; st > 0; st >>= 1) {
-            for (int i = lane; i < np; i += 64) {
-                int j = i ^ st;
-                if (j > i) { bool up = (i & sz) == 0; uint64_t a = s_key[i], b = s_key[j]; if ((a > b) == up) { s_key[i] = b; s_key[j] = a; } }
-            }
-            __syncthreads();
-        }
+    // anchors arrive in contig order; on the reverse strand the contig coordinate was mirrored, so the order is reversed
+    if (rev) {
+        for (int i = lane; i < n / 2; i += 64) { const uint64_t a = s_key[i], b = s_key[n - 1 - i]; s_key[i] = b; s_key[n - 1 - i] = a; }
+        __syncthreads();
+    }
     for (int i = 0; i < n; i++) {
         const uint64_t ki = s_key[i];
         const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;

@@ -35,7 +35,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
 
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
-        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -46,7 +46,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -448,14 +448,34 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     TRY(upload(ctx, W.mz_off, G.mz_off));
     TRY(ensure(ctx, W.tasks, 64));
     TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0));
-    std::vector<fsv_ovl> hovl(B.n_pairs);
+    std::vector<fsv_ovl> hovl;
+    std::vector<uint32_t> hit_first(B.n_sets + 1, 0);
     if (B.n_pairs) {
+        TRY(ensure(ctx, W.hits, (size_t)B.n_pairs * sizeof(fsv_ovl)));
+        FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.counters.p + 3, 0, 4, ctx->stream));
         W.kt.begin(ctx, KN_EXACT, (uint64_t)B.n_pairs * sizeof(fsv_ovl) + W.stats.n_pairs * 0);
-    hipLaunchKernelGGL(k_exact, dim3(B.n_pairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
-                           (const uint32_t *)W.set_start.p, (const uint32_t *)W.pair_base.p, B.n_sets, (fsv_ovl *)W.ovl.p);
+        hipLaunchKernelGGL(k_exact, dim3(B.n_pairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
+                           (const uint32_t *)W.set_start.p, (const uint32_t *)W.pair_base.p, B.n_sets, (fsv_ovl *)W.ovl.p, (fsv_ovl *)W.hits.p,
+                           (uint32_t *)W.counters.p + 3);
         FSV_HIP(ctx, hipGetLastError());
-    W.kt.end(ctx);
-        FSV_HIP(ctx, hipMemcpyAsync(hovl.data(), W.ovl.p, (size_t)B.n_pairs * sizeof(fsv_ovl), hipMemcpyDeviceToHost, ctx->stream));
+        W.kt.end(ctx);
+        uint32_t nh = 0;
+        FSV_HIP(ctx, hipMemcpyAsync(&nh, (uint32_t *)W.counters.p + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<fsv_ovl> raw(nh);
+        if (nh) {
+            FSV_HIP(ctx, hipMemcpyAsync(raw.data(), W.hits.p, (size_t)nh * sizeof(fsv_ovl), hipMemcpyDeviceToHost, ctx->stream));
+            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        // the gather order depends on atomics: bucket by set, then by slot, so that the layout sees a reproducible list
+        for (auto &h : raw) hit_first[(uint32_t)h.first_win + 1]++;
+        for (uint32_t s2 = 0; s2 < B.n_sets; s2++) hit_first[s2 + 1] += hit_first[s2];
+        hovl.resize(nh);
+        std::vector<uint32_t> fill(hit_first.begin(), hit_first.end() - 1);
+        for (auto &h : raw) hovl[fill[(uint32_t)h.first_win]++] = h;
+        for (uint32_t s2 = 0; s2 < B.n_sets; s2++)
+            std::sort(hovl.begin() + hit_first[s2], hovl.begin() + hit_first[s2 + 1], [](const fsv_ovl &a, const fsv_ovl &b) { return a.chain_off < b.chain_off; });
+        W.stats.n_exact_overlaps = nh;
     }
     std::vector<uint32_t> hwarn(B.n_reads);
     FSV_HIP(ctx, hipMemcpyAsync(hwarn.data(), W.warn.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -473,9 +493,8 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         if (ns == 0) { out->set_status[s] = st; continue; }
         std::vector<std::vector<Piece>> contigs;
         bool fallback = false;
-        const uint32_t npairs_s = B.pair_base[s + 1] - B.pair_base[s];
-        for (uint32_t i = 0; i < npairs_s; i++) W.stats.n_exact_overlaps += (hovl[B.pair_base[s] + i].valid && hovl[B.pair_base[s] + i].exact);
-        layout_set(len.data() + r0, ns, npairs_s ? hovl.data() + B.pair_base[s] : nullptr, npairs_s, P.min_contig_reads, contigs, fallback);
+        const uint32_t nh_s = hit_first[s + 1] - hit_first[s];
+        layout_set(len.data() + r0, ns, nh_s ? hovl.data() + hit_first[s] : nullptr, nh_s, P.min_contig_reads, contigs, fallback);
         if (fallback) st |= FSV_W_NO_LAYOUT;
         for (auto &c : contigs) {
             uint64_t clen = 0;

@@ -244,23 +244,57 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
             }
             __syncthreads();
         }
-    // unique flags + block compaction (each thread owns a contiguous chunk)
+    // unique flags + block compaction (each thread owns a contiguous chunk; its survivors wait in registers until every
+    // thread has read its chunk, because they move towards lower indices, i.e. into other threads' chunks)
     const uint32_t per = (n + 255) / 256;
     const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+    uint64_t kh[UQ_MAX / 256], kp[UQ_MAX / 256];
     uint32_t cnt = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        bool u = (i == 0 || s_hash[i - 1] != s_hash[i]) && (i + 1 >= n || s_hash[i + 1] != s_hash[i]);
-        cnt += u;
+#pragma unroll
+    for (uint32_t j = 0; j < UQ_MAX / 256; j++) {
+        const uint32_t i = lo + j;
+        if (i < hi) {
+            const bool u = (i == 0 || s_hash[i - 1] != s_hash[i]) && (i + 1 >= n || s_hash[i + 1] != s_hash[i]);
+            if (u) { kh[cnt] = s_hash[i]; kp[cnt] = s_pay[i]; cnt++; }
+        }
     }
     s_scan[tid] = cnt;
     __syncthreads();
     if (tid == 0) { uint32_t acc = 0; for (int i = 0; i < 256; i++) { uint32_t c = s_scan[i]; s_scan[i] = acc; acc += c; } mz_cnt[r] = acc; }
     __syncthreads();
-    uint32_t o = s_scan[tid];
-    for (uint32_t i = lo; i < hi; i++) {
-        bool u = (i == 0 || s_hash[i - 1] != s_hash[i]) && (i + 1 >= n || s_hash[i + 1] != s_hash[i]);
-        if (u) { fsv_mz m; m.hash = s_hash[i]; uint64_t p = s_pay[i]; m.pos = (uint32_t)p; m.rev = (uint8_t)(p >> 32); m.span = (uint8_t)(p >> 40); m.pad = 0; a[o++] = m; }
-    }
+    const uint32_t m = mz_cnt[r];
+    const uint32_t o0 = s_scan[tid];
+    const uint32_t slot_cap = mz_off[r + 1] - mz_off[r];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < UQ_MAX / 256; j++)
+        if (j < cnt) { s_hash[o0 + j] = kh[j]; s_pay[o0 + j] = kp[j]; }
+    __syncthreads();
+    // [0, m): sorted by hash (the "target" role: binary-searched)
+    for (uint32_t i = tid; i < m; i += 256) { fsv_mz x; x.hash = s_hash[i]; const uint64_t p = s_pay[i]; x.pos = (uint32_t)p; x.rev = (uint8_t)(p >> 32); x.span = (uint8_t)(p >> 40); x.pad = 0; a[i] = x; }
+    // [m, 2m): the same minimizers sorted by position (the "query" role: anchors then come out in query order and the
+    // chain kernels need no per-pair sort)
+    if (2 * m <= slot_cap) {
+        uint32_t mp = 1;
+        while (mp < m) mp <<= 1;
+        for (uint32_t i = m + tid; i < mp; i += 256) { s_hash[i] = ~0ull; s_pay[i] = ~0ull; }
+        __syncthreads();
+        for (uint32_t sz = 2; sz <= mp; sz <<= 1)
+            for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+                for (uint32_t i = tid; i < mp; i += 256) {
+                    uint32_t j = i ^ st;
+                    if (j > i) {
+                        bool up = (i & sz) == 0;
+                        uint64_t pi = s_pay[i], pj = s_pay[j];
+                        bool gt = (uint32_t)pi > (uint32_t)pj || ((uint32_t)pi == (uint32_t)pj && pi > pj);
+                        if (pi == ~0ull && pj != ~0ull) gt = true; else if (pj == ~0ull) gt = false;
+                        if (gt == up) { uint64_t hi2 = s_hash[i], hj = s_hash[j]; s_hash[i] = hj; s_hash[j] = hi2; s_pay[i] = pj; s_pay[j] = pi; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = tid; i < m; i += 256) { fsv_mz x; x.hash = s_hash[i]; const uint64_t p = s_pay[i]; x.pos = (uint32_t)p; x.rev = (uint8_t)(p >> 32); x.span = (uint8_t)(p >> 40); x.pad = 0; a[m + i] = x; }
+    } else if (tid == 0) atomicOr(&warn[r], 32u); // cannot happen: at most one minimizer per base and slots hold len + 64
 }
 
 // ------------------------------------------------------------------------------------------------ k_chain
@@ -325,8 +359,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     t += (t >= q);
     const uint32_t rq = r0 + q, rt = r0 + t;
     const int lenq = A.read_len[rq], lent = A.read_len[rt];
-    const fsv_mz *mq = A.mz + A.mz_off[rq], *mt = A.mz + A.mz_off[rt];
     const int nq = (int)A.mz_cnt[rq], nt = (int)A.mz_cnt[rt];
+    const fsv_mz *mq = A.mz + A.mz_off[rq] + nq, *mt = A.mz + A.mz_off[rt]; // q: position-sorted copy, t: hash-sorted
     fsv_ovl o;
     o.q = q; o.t = t; o.x_s = o.x_e = o.y_s = o.y_e = 0; o.score = 0; o.n_chain = 0; o.chain_off = 0; o.first_win = 0; o.n_win = 0;
     o.align_len = 0; o.err_sum = 0; o.rev = 0; o.is_match = 0; o.exact = 0; o.valid = 0;
@@ -383,23 +417,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     }
     n = m2;
     if (n < A.min_anchors) { if (lane == 0) A.ovl[p] = o; return; }
-    // 3. sort by (qe, te)
-    int np = 1;
-    while (np < n) np <<= 1;
-    for (int i = n + lane; i < np; i += 64) s_key[i] = ~0ull;
-    __syncthreads();
-    for (int sz = 2; sz <= np; sz <<= 1)
-        for (int st = sz >> 1; st > 0; st >>= 1) {
-            for (int i = lane; i < np; i += 64) {
-                int j = i ^ st;
-                if (j > i) {
-                    bool up = (i & sz) == 0;
-                    uint64_t a = s_key[i], b = s_key[j];
-                    if ((a > b) == up) { s_key[i] = b; s_key[j] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    // 3. anchors are already in query order: q's minimizers were walked by position and both compactions keep the order
+    //    (query positions are distinct, so (qe, te) order == qe order)
     // 4. chain DP: lane l examines predecessor i-1-l (nearest first on ties).
     //    Fast path: when every anchor sits on one diagonal (error-free reads: correction rounds 2, 3 and the final pass)
     //    the DP provably links each anchor to its nearest predecessor -- gap 0 means no indel penalty, and
@@ -977,7 +996,8 @@ __global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwi
 // if_exact_match (Assembly.cpp:894-974): the two overlap intervals must be the same string.  One wavefront per overlap slot.
 __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                               const int32_t *__restrict__ read_len, const uint32_t *__restrict__ set_start,
-                                              const uint32_t *__restrict__ pair_base, uint32_t n_sets, fsv_ovl *__restrict__ ovl)
+                                              const uint32_t *__restrict__ pair_base, uint32_t n_sets, fsv_ovl *__restrict__ ovl,
+                                              fsv_ovl *__restrict__ hits, uint32_t *__restrict__ n_hits)
 {
     const uint32_t p = blockIdx.x;
     const int lane = threadIdx.x;
@@ -992,12 +1012,23 @@ __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store
     if (same) {
         const uint32_t xw = word_off[rq], yw = word_off[rt];
         const int ylen = read_len[rt];
+        // 16 bases per lane and trip: XOR of two fetched words
         bool diff = false;
-        for (int i = lane; i < L && !diff; i += 64)
-            diff = fsv_base_fwd(store, xw, o.x_s + i) != fsv_base_at(store, yw, ylen, o.rev, o.y_s + i);
+        for (int i = lane * 16; i < L && !diff; i += 64 * 16) {
+            const uint32_t xb = fetch16_x(store, xw, o.x_s + i);
+            const Bases16 yb = fetch16(store, yw, ylen, o.rev, o.y_s + i);
+            uint32_t d = xb ^ yb.bits;
+            const int lim = min(16, L - i);
+            if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+            diff = d != 0u;
+        }
         same = !__any(diff);
     }
-    if (lane == 0) { o.exact = same ? 1 : 0; ovl[p] = o; }
+    if (lane == 0 && same) {
+        // exact hits are gathered for the host layout (a few per cent of the slots); the record carries its set and slot
+        o.exact = 1; o.first_win = (int32_t)lo; o.chain_off = (int32_t)p;
+        hits[atomicAdd(n_hits, 1u)] = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_stitch

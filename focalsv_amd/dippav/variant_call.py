@@ -23,14 +23,19 @@ class WindowedRef:
 
     def __init__(self):
         self.wins: List[Tuple[int, str]] = []
+        self._starts: List[int] = []
 
     def add(self, start: int, seq: str):
         self.wins.append((start, seq))
         self.wins.sort()
+        self._starts = [w[0] for w in self.wins]
 
     def _find(self, pos):
-        for s, q in self.wins:
-            if s <= pos < s + len(q):
+        from bisect import bisect_right
+        i = bisect_right(self._starts, pos) - 1
+        if i >= 0:
+            s, q = self.wins[i]
+            if pos < s + len(q):
                 return s, q
         raise IndexError(f"reference position {pos} outside the loaded windows")
 

@@ -15,11 +15,15 @@ HEADER_LINES = [
     '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n',
 ]
 
-_COMP = {'N': 'N', 'A': 'T', 'T': 'A', 'G': 'C', 'C': 'G'}
+_COMP = str.maketrans('NATGC', 'NTACG')
 
 
 def reverse_complement(seq):
-    return ''.join(_COMP[c] for c in seq.upper()[::-1])
+    """upper-cased reverse complement; any other letter raises, like the reference's dict lookup (CCS.py:582-588)"""
+    s = seq.upper()
+    if s.strip('NATGC'):
+        raise KeyError(s.strip('NATGC')[0])
+    return s[::-1].translate(_COMP)
 
 
 def allele_sequence(sig, ref_seq, contigs):

@@ -101,8 +101,10 @@ def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', 
         rr = []
         for r in regions:
             if r.chrom == chrom:
-                ref.add(r.start, r.ref.decode())
+                ref.wins.append((r.start, r.ref.decode()))
                 rr += r.read_records
+        ref.wins.sort()
+        ref._starts = [w[0] for w in ref.wins]
         paired, body = call_chromosome(records, chrom, ref, contig_seq, data_type)
         raw += body
         read_sigs[chrom] = reads_signature.reads_signatures(rr, 50)
