@@ -7,6 +7,8 @@
 #include "asm_kernels.h"
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,6 +45,8 @@ struct AsmWs {
     uint32_t n_reads = 0;
     fsv_asm_stats stats;
     KTimes kt;
+    void *h_pin = nullptr; size_t h_pin_cap = 0; // pinned host staging (exact hits)
+    std::vector<uint32_t> hit_idx;
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
@@ -55,6 +59,7 @@ void ws_free(fsv_ctx *ctx)
     AsmWs *w = (AsmWs *)ctx->asm_ws;
     if (!w) return;
     for (DevBuf *b : w->all()) if (b->p) (void)hipFree(b->p);
+    if (w->h_pin) (void)hipHostFree(w->h_pin);
     delete w;
     ctx->asm_ws = nullptr;
 }
@@ -203,21 +208,21 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
 // arc (q,+) -> (t,rev); its complement is (t,!rev) -> (q,-).  Mirrors ma_hit_contained / ma_hit2arc / asg_arc_del_trans
 // on error-free linear data (Overlaps.cpp:1198, 2152, 4531; Overlaps.h:178-246) and ma_ug_seq for the sequence.
 struct Piece { uint32_t read, rev, len; };
-void layout_set(const int32_t *len, uint32_t n, const fsv_ovl *hit, uint32_t n_hit, int min_reads, std::vector<std::vector<Piece>> &contigs,
-                bool &fallback)
+void layout_set(const int32_t *len, uint32_t n, const fsv_ovl *hits, const uint32_t *idx, uint32_t n_hit, int min_reads,
+                std::vector<std::vector<Piece>> &contigs, bool &fallback)
 {
     std::vector<uint8_t> contained(n, 0), used(n, 0);
     std::vector<int32_t> succ(2 * n, -1), sovl(2 * n, 0), pred(2 * n, -1);
     fallback = false;
     for (uint32_t i = 0; i < n_hit; i++) {
-        const fsv_ovl &h = hit[i];
+        const fsv_ovl &h = hits[idx[i]];
         if (!h.valid || !h.exact) continue;
         bool qfull = h.x_s == 0 && h.x_e == len[h.q] - 1, tfull = h.y_s == 0 && h.y_e == len[h.t] - 1;
         if (qfull && tfull) { if (h.q > h.t) contained[h.q] = 1; }
         else if (qfull) contained[h.q] = 1;
     }
     for (uint32_t i = 0; i < n_hit; i++) {
-        const fsv_ovl &h = hit[i];
+        const fsv_ovl &h = hits[idx[i]];
         if (!h.valid || !h.exact || contained[h.q] || contained[h.t]) continue;
         const int L = h.x_e - h.x_s + 1;
         int a, b;
@@ -443,12 +448,15 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
 
     // final overlaps on the corrected reads
     Timer tf(ctx);
+    auto tr0 = std::chrono::steady_clock::now();
+    auto trace = [&](const char *what) { if (getenv("FSV_TRACE")) { (void)hipStreamSynchronize(ctx->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[fsv] final %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tr0).count()); tr0 = t; } };
     TRY(upload(ctx, W.word_off, G.word_off));
     TRY(upload(ctx, W.len, len));
     TRY(upload(ctx, W.mz_off, G.mz_off));
     TRY(ensure(ctx, W.tasks, 64));
     TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0));
-    std::vector<fsv_ovl> hovl;
+    trace("overlaps");
+    const fsv_ovl *hraw = nullptr;
     std::vector<uint32_t> hit_first(B.n_sets + 1, 0);
     if (B.n_pairs) {
         TRY(ensure(ctx, W.hits, (size_t)B.n_pairs * sizeof(fsv_ovl)));
@@ -462,21 +470,26 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         uint32_t nh = 0;
         FSV_HIP(ctx, hipMemcpyAsync(&nh, (uint32_t *)W.counters.p + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        std::vector<fsv_ovl> raw(nh);
+        if ((size_t)nh * sizeof(fsv_ovl) > W.h_pin_cap) {
+            if (W.h_pin) FSV_HIP(ctx, hipHostFree(W.h_pin));
+            W.h_pin = nullptr; W.h_pin_cap = (size_t)nh * sizeof(fsv_ovl) * 5 / 4 + 4096;
+            FSV_HIP(ctx, hipHostMalloc(&W.h_pin, W.h_pin_cap, hipHostMallocDefault));
+        }
+        hraw = (const fsv_ovl *)W.h_pin;
         if (nh) {
-            FSV_HIP(ctx, hipMemcpyAsync(raw.data(), W.hits.p, (size_t)nh * sizeof(fsv_ovl), hipMemcpyDeviceToHost, ctx->stream));
+            FSV_HIP(ctx, hipMemcpyAsync(W.h_pin, W.hits.p, (size_t)nh * sizeof(fsv_ovl), hipMemcpyDeviceToHost, ctx->stream));
             FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        // the gather order depends on atomics: bucket by set, then by slot, so that the layout sees a reproducible list
-        for (auto &h : raw) hit_first[(uint32_t)h.first_win + 1]++;
+        // the gather order depends on atomics; bucket by set (counting sort over indices).  The order inside a set does not
+        // matter: the layout's containment marks and "longest arc, smallest target on ties" choices are order-independent.
+        for (uint32_t i = 0; i < nh; i++) hit_first[(uint32_t)hraw[i].first_win + 1]++;
         for (uint32_t s2 = 0; s2 < B.n_sets; s2++) hit_first[s2 + 1] += hit_first[s2];
-        hovl.resize(nh);
+        W.hit_idx.resize(nh);
         std::vector<uint32_t> fill(hit_first.begin(), hit_first.end() - 1);
-        for (auto &h : raw) hovl[fill[(uint32_t)h.first_win]++] = h;
-        for (uint32_t s2 = 0; s2 < B.n_sets; s2++)
-            std::sort(hovl.begin() + hit_first[s2], hovl.begin() + hit_first[s2 + 1], [](const fsv_ovl &a, const fsv_ovl &b) { return a.chain_off < b.chain_off; });
+        for (uint32_t i = 0; i < nh; i++) W.hit_idx[fill[(uint32_t)hraw[i].first_win]++] = i;
         W.stats.n_exact_overlaps = nh;
     }
+    trace("exact+gather");
     std::vector<uint32_t> hwarn(B.n_reads);
     FSV_HIP(ctx, hipMemcpyAsync(hwarn.data(), W.warn.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
     FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -494,7 +507,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         std::vector<std::vector<Piece>> contigs;
         bool fallback = false;
         const uint32_t nh_s = hit_first[s + 1] - hit_first[s];
-        layout_set(len.data() + r0, ns, nh_s ? hovl.data() + hit_first[s] : nullptr, nh_s, P.min_contig_reads, contigs, fallback);
+        layout_set(len.data() + r0, ns, hraw, nh_s ? W.hit_idx.data() + hit_first[s] : nullptr, nh_s, P.min_contig_reads, contigs, fallback);
         if (fallback) st |= FSV_W_NO_LAYOUT;
         for (auto &c : contigs) {
             uint64_t clen = 0;
@@ -506,6 +519,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         }
         out->set_status[s] = st;
     }
+    trace("layout");
     if (rc_out != FSV_OK) return rc_out;
     out->n_contigs = nc;
     if (!pieces.empty()) {
@@ -519,6 +533,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         FSV_HIP(ctx, hipMemcpyAsync(out->seq, W.contig_out.p, used, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    trace("stitch+d2h");
     W.stats.ms_final += tf.stop();
     W.h_word_off = G.word_off; W.h_len = len; W.cur_store = store; W.n_reads = B.n_reads;
     // algorithmic bytes: 2-bit operands + result of every DP task, reads in once per pass, contigs out
