@@ -418,7 +418,7 @@ extern "C" int fsv_aln_last_stats(const fsv_ctx *ctx, fsv_aln_stats *out)
 
 static int check_aln_params(fsv_ctx *ctx, const fsv_aln_params &P)
 {
-    if (P.k < 1 || P.k > 31 || P.w < 1 || P.w > 64 || P.lookback != 64 || P.min_anchors < 2 || P.pad < 0 || P.a < 0 || P.b < 0 || P.q < 0 || P.e < 0 || P.max_cells < 1)
+    if (P.k < 1 || P.k > 31 || P.w < 1 || P.w > 255 || P.lookback != 64 || P.min_anchors < 2 || P.pad < 0 || P.a < 0 || P.b < 0 || P.q < 0 || P.e < 0 || P.max_cells < 1)
         return fsv_fail(ctx, FSV_EINVAL, "fsv_aln_params out of range");
     return FSV_OK;
 }
@@ -490,13 +490,13 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     }
     for (uint32_t r = 0; r < n_refs; r++) {
         uint64_t w = std::max<uint64_t>((uint64_t)P.w, group_len[r] / 3000 + 1);
-        wper[r] = (uint8_t)std::min<uint64_t>(w, 64);
+        wper[r] = (uint8_t)std::min<uint64_t>(w, 255);
     }
     for (uint32_t p = 0; p < np; p++) {
         const uint32_t r = contig_ref[p];
         const uint64_t L = group_len[r];
         wper[n_refs + p] = wper[r];
-        if (L / 3000 + 1 > 64 || L >= (1u << 24)) pre_status[p] = FSV_EUNSUP;
+        if (L / 3000 + 1 > 255 || L >= (1u << 24) || (!(P.k & 1) && L / 3000 + 1 > 64)) pre_status[p] = FSV_EUNSUP; // the replay kernel (even k) holds w <= 64
         else if (slen[n_refs + p] < (uint64_t)P.k || slen[r] < (uint64_t)P.k) pre_status[p] = 1;
     }
     Timer tseed(ctx);

@@ -195,7 +195,21 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     A.ovl = (fsv_ovl *)W.ovl.p; A.tasks = (fsv_wtask *)W.tasks.p; A.task_counter = (uint32_t *)W.counters.p; A.task_cap = task_cap;
     A.overflow = (uint32_t *)W.counters.p + 1; A.warn = (uint32_t *)W.warn.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
     A.n_sets = B.n_sets; A.k_score = P.k; A.min_anchors = P.min_anchors; A.min_ovlp = P.min_ovlp; A.bw = bw; A.emit_tasks = emit_tasks ? 1 : 0;
-    W.kt.begin(ctx, KN_CHAIN, (uint64_t)B.n_pairs * (2ull * 600 * sizeof(fsv_mz) / 4 + sizeof(fsv_ovl)));
+    // algorithmic bytes of the pairwise join: every ordered pair reads both unique-minimizer lists (16 B each) and writes one
+    // overlap slot; the window tasks it emits are added once their number is known
+    uint64_t chain_bytes = (uint64_t)B.n_pairs * sizeof(fsv_ovl);
+    {
+        std::vector<uint32_t> cnt(B.n_reads);
+        FSV_HIP(ctx, hipMemcpyAsync(cnt.data(), W.mz_cnt.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t s2 = 0; s2 < B.n_sets; s2++) {
+            const uint64_t ns = B.set_start[s2 + 1] - B.set_start[s2];
+            uint64_t tot = 0;
+            for (uint32_t r = B.set_start[s2]; r < B.set_start[s2 + 1]; r++) tot += cnt[r];
+            if (ns > 1) chain_bytes += 2 * (ns - 1) * tot * sizeof(fsv_mz);
+        }
+    }
+    W.kt.begin(ctx, KN_CHAIN, chain_bytes);
     hipLaunchKernelGGL(k_chain, dim3(B.n_pairs), dim3(64), 0, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);

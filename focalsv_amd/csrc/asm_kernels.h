@@ -1074,8 +1074,8 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
                                                      int hpc, uint32_t *__restrict__ warn, const uint8_t *__restrict__ w_per_read,
                                                      uint32_t *__restrict__ sc_ends, uint32_t *__restrict__ sc_low, uint32_t *__restrict__ sc_high)
 {
-    __shared__ uint64_t s_h[SKF_T + 2 * 64];
-    __shared__ uint64_t s_wmin[SKF_T + 64];
+    __shared__ uint64_t s_h[SKF_T + 2 * 256];   // w <= 255
+    __shared__ uint64_t s_wmin[SKF_T + 256];
     __shared__ uint32_t s_scan[256];
     __shared__ uint32_t s_carry;
     __shared__ uint64_t s_am, s_ah;   // start anomaly: minimum of the partial window, hash of entry T0

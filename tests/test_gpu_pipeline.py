@@ -52,3 +52,24 @@ def test_calls_match_truth_and_oracle_path(ctx):
         ref.add(r.start, r.ref.decode())
     _, body = call_chromosome(recs, "chr21", ref, contig_seq, 'CCS')
     assert body == res.raw_lines
+
+
+def test_real_bed_geometry_config3(ctx, golden_dir):
+    """BASELINE.json configs[2] geometry: region widths of the reference's chr21 auto-mode BED (14 kb .. >100 kb), synthetic reads
+    laid over them; every planted SV must come back within 1 bp of the left-aligned truth."""
+    import json
+    import os
+    bed = json.load(open(os.path.join(golden_dir, "bed_chr21_regions.json")))["chr21"]
+    picks = sorted(bed, key=lambda r: r[1] - r[0])
+    chosen = [picks[0], picks[len(picks) // 2], picks[-8], picks[len(picks) // 3]]  # smallest, median, a wide one (> 60 kb)
+    rs = [synth.make_region(300 + i, width=b - a, start=a) for i, (a, b) in enumerate(chosen)]
+    batch = pipeline.upload_regions(ctx, [pipeline.region_from_synth(r) for r in rs])
+    try:
+        res = pipeline.run_hot_path(ctx, batch)
+    finally:
+        batch.free(ctx)
+    assert (res.set_status == 0).all() and (res.contig_status == 0).all()
+    calls = pipeline.parse_calls(res.lines)
+    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth]
+    tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.02)
+    assert (tp, fp, fn) == (len(truth), 0, 0), (calls, truth)
