@@ -391,28 +391,34 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             TRY(ensure(ctx, W.paths, (size_t)n_tasks * sizeof(fsv_wpath)));
             TRY(ensure(ctx, W.dp_list, (size_t)n_tasks * 4));
             W.kt.begin(ctx, KN_PATH_FAST, (uint64_t)n_tasks * (48 + 128));
-    hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
+            hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
                                (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, n_tasks, (fsv_wpath *)W.paths.p,
-                               (uint32_t *)W.dp_list.p, (uint32_t *)W.counters.p + 2);
+                               (uint32_t *)W.dp_list.p, (uint32_t *)W.counters.p + 2, (uint32_t *)W.counters.p + 6);
             FSV_HIP(ctx, hipGetLastError());
-    W.kt.end(ctx);
-            FSV_HIP(ctx, hipMemcpyAsync(cnt, W.counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            W.kt.end(ctx);
+            uint32_t cnt2[8];
+            FSV_HIP(ctx, hipMemcpyAsync(cnt2, W.counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
             FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            const uint32_t n_dp = cnt[2];
-            W.stats.n_path_dp += n_dp;
-            if (n_dp) {
-                // the DP list order depends on atomics; sort it so that scratch slots (and nothing else) are reproducible
-                const uint32_t chunk = std::min<uint32_t>(n_dp, 1u << 18);
+            const uint32_t n_dp = cnt2[2], n_dp_wide = cnt2[6];
+            W.stats.n_path_dp += n_dp + n_dp_wide;
+            // narrow bands: [0, n_dp) of the list with 32-bit column words; wide bands: the last n_dp_wide entries with 64-bit words
+            for (int wide = 0; wide < 2; wide++) {
+                const uint32_t n_here = wide ? n_dp_wide : n_dp, list0 = wide ? n_tasks - n_dp_wide : 0u;
+                if (!n_here) continue;
+                const uint32_t chunk = std::min<uint32_t>(n_here, 1u << 18);
                 const uint32_t stride = (chunk + 63) / 64 * 64;
-                TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * 8));
-                TRY(ensure(ctx, W.tmp, (size_t)stride * (FSV_PATH_CAP + 64)));
-                for (uint32_t b = 0; b < n_dp; b += chunk) {
-                    const uint32_t e = std::min(n_dp, b + chunk);
+                TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * (wide ? 8 : 4)));
+                for (uint32_t b = 0; b < n_here; b += chunk) {
+                    const uint32_t e = std::min(n_here, b + chunk);
                     W.kt.begin(ctx, KN_PATH_DP, (uint64_t)(e - b) * (32 + 196 + 128));
-    hipLaunchKernelGGL(k_path_dp, dim3(fsv_grid_for(e - b, 64)), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                                       (const uint32_t *)W.dp_list.p, b, e, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p, (uint8_t *)W.tmp.p, stride);
+                    if (wide)
+                        hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(fsv_grid_for(e - b, 64)), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                                           (const uint32_t *)W.dp_list.p, list0 + b, list0 + e, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p, stride);
+                    else
+                        hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(fsv_grid_for(e - b, 64)), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                                           (const uint32_t *)W.dp_list.p, list0 + b, list0 + e, (fsv_wpath *)W.paths.p, (uint32_t *)W.cols.p, stride);
                     FSV_HIP(ctx, hipGetLastError());
-    W.kt.end(ctx);
+                    W.kt.end(ctx);
                 }
             }
             W.stats.ms_path += tp.stop();

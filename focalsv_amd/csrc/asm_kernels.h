@@ -586,7 +586,8 @@ __device__ __forceinline__ uint32_t task_ybase(const uint32_t *__restrict__ stor
 // exactly err mismatches (try_cigar).  Everything else is queued for the DP kernel.
 __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ store, const fsv_ovl *__restrict__ ovl,
                                                    const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res, uint32_t n_tasks,
-                                                   fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list, uint32_t *__restrict__ dp_count)
+                                                   fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list, uint32_t *__restrict__ dp_count,
+                                                   uint32_t *__restrict__ dp_count_wide)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n_tasks) return;
@@ -624,8 +625,11 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
         ok = (mm == r.err);
     }
     if (!ok) {
+        // queued for the DP kernel: narrow bands (k <= 15: the three column words fit 32 bits each) fill the list from the
+        // front, wide ones from the back, so that each launch of k_path_dp is homogeneous
         P->state = 2;
-        dp_list[atomicAdd(dp_count, 1u)] = tid;
+        if (t.k <= 15) dp_list[atomicAdd(dp_count, 1u)] = tid;
+        else dp_list[n_tasks - 1u - atomicAdd(dp_count_wide, 1u)] = tid;
         return;
     }
     // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops (3) and
@@ -649,20 +653,22 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
 // (A variant that checkpoints the DP state every 16 columns and recomputes blocks into an LDS tile during the walk back
 //  cut the scratch traffic 8x but ran 1.4x slower: the tile costs occupancy and the lanes cross block boundaries at
 //  different steps, so the wave replays each block several times.  Measured round 1, kept out.)
-struct PathSink {
-    uint64_t *cols; uint32_t stride, lane;
+// WordT = uint32_t for bands of at most 31 diagonals (k <= 15): the walk back only looks at bits below the band width, so the
+// low halves of D0 / VP / VN are all it needs and the scratch traffic halves; uint64_t for the doubled thresholds (k <= 31).
+template <class WordT> struct PathSink {
+    WordT *cols; uint32_t stride, lane;
     __device__ __forceinline__ void operator()(int i, uint64_t d0, uint64_t vp, uint64_t vn) const
     {
-        uint64_t *c = cols + (size_t)(i + 1) * 3 * stride + lane;
-        c[0] = d0; c[stride] = vp; c[2 * (size_t)stride] = vn;
+        WordT *c = cols + (size_t)(i + 1) * 3 * stride + lane;
+        c[0] = (WordT)d0; c[stride] = (WordT)vp; c[2 * (size_t)stride] = (WordT)vn;
     }
     __device__ __forceinline__ void block(int, const BpmState &) const {}
 };
 
+template <class WordT>
 __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
                                                 const uint32_t *__restrict__ dp_list, uint32_t list_begin, uint32_t list_end,
-                                                fsv_wpath *__restrict__ paths, uint64_t *__restrict__ cols, uint8_t *__restrict__ tmp,
-                                                uint32_t stride)
+                                                fsv_wpath *__restrict__ paths, WordT *__restrict__ cols, uint32_t stride)
 {
     __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
     const int lane64 = threadIdx.x;
@@ -674,10 +680,10 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
     fsv_wpath *P = paths + tid;
     const int n = t.x_len, k = t.k, band = 2 * k + 1;
     fsv_wres r;
-    PathSink sink{cols, stride, slot};
+    PathSink<WordT> sink{cols, stride, slot};
     bpm_run(store, t, r, sink);
     if (r.err < 0) { P->state = 0; return; } // cannot happen: K5 matched this window
-#define COL(c, w) cols[((size_t)(c) * 3 + (w)) * stride + slot]
+#define COL(c, w) ((uint64_t)cols[((size_t)(c) * 3 + (w)) * stride + slot])
 #define TMP(i) ((s_ops[(i) >> 4][lane64] >> (((i) & 15) << 1)) & 3u)
 #define TMP_SET(i, v) do { const int w_ = (i) >> 4, sh_ = ((i) & 15) << 1; s_ops[w_][lane64] = (s_ops[w_][lane64] & ~(3u << sh_)) | ((uint32_t)(v) << sh_); } while (0)
     for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
