@@ -144,13 +144,26 @@ def main():
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else (None, None)
         peak = 8000.0
         roof = None
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this
+        # process); FETCH_SIZE carries the gfx950 x2 correction for streaming reads, see profiles/*_pmc_hbm_traffic.json
+        traffic = None
+        try:
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json"))
+            pk = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))["kernels"]
+            alias = {"k_sketch": "k_sketch_fast", "k5_bpm": "k5_bpm_kernel", "k_uniq": "k_uniq<4096>"}
+            e = pk.get(alias.get(dom[0], dom[0])) if dom[0] else None
+            if e:
+                traffic = int((e["fetch_bytes_x2"] + e["write_bytes"]) / max(1, e["launches"]))
+        except Exception:
+            traffic = None
         if dom[0]:
             k = dom[1]
             ach = (k["algo_bytes"] / max(1, k["launches"])) / (k["ms"] / max(1, k["launches"]) * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 6),
-                    "traffic": None, "launches_per_step": k["launches"], "avg_launch_ms": round(k["ms"] / max(1, k["launches"]), 4),
+                    "traffic": traffic, "launches_per_step": k["launches"], "avg_launch_ms": round(k["ms"] / max(1, k["launches"]), 4),
                     "algo_bytes_per_launch": int(k["algo_bytes"] / max(1, k["launches"])),
-                    "note": "integer DP with operands in registers/LDS: the binding roof is VALU issue, not HBM (DESIGN.md)"}
+                    "note": "algorithmic bytes = what the kernel's formulation must read and write (DESIGN.md section 3 table); this path is integer DP / "
+                            "join work served from LDS and L2, so the HBM fraction is small by construction (SURVEY.md 7)"}
         out = {
             "metric": "target regions/sec (50 kb, 30x HiFi)", "value": round(world * n * args.steps / dt, 3), "unit": "regions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),

@@ -10,6 +10,8 @@
 #include "asm_kernels.h"
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -500,8 +502,11 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
         else if (slen[n_refs + p] < (uint64_t)P.k || slen[r] < (uint64_t)P.k) pre_status[p] = 1;
     }
     Timer tseed(ctx);
+    auto tr0 = std::chrono::steady_clock::now();
+    auto trace = [&](const char *what) { if (getenv("FSV_TRACE")) { (void)hipStreamSynchronize(ctx->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[fsv] align %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tr0).count()); tr0 = t; } };
     std::vector<uint32_t> word_off; std::vector<int32_t> len;
     TRY(pack_pairs(ctx, W, seq, slen, word_off, len));
+    trace("pack+h2d");
     TRY(upload(ctx, W.wper, wper));
     TRY(upload(ctx, W.pair_q, pair_q));
     TRY(upload(ctx, W.pair_t, pair_t));
@@ -539,6 +544,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     hipLaunchKernelGGL(k_uniq<ALN_AMAX>, dim3(nr), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (uint32_t *)W.mz_cnt.p,
                        (uint32_t *)W.warn.p);
     FSV_HIP(ctx, hipGetLastError());
+    trace("sketch+uniq");
     W.stats.ms_seed = tseed.stop();
     Timer tchain(ctx);
     TRY(ensure(ctx, W.chain, (size_t)np * ALN_AMAX * 8));
@@ -548,6 +554,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
                        (const fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (const uint32_t *)W.mz_cnt.p, (const uint32_t *)W.pair_q.p,
                        (const uint32_t *)W.pair_t.p, (uint64_t *)W.chain.p, (AlnHeader *)W.hdr.p, P);
     FSV_HIP(ctx, hipGetLastError());
+    trace("chain");
     W.stats.ms_chain = tchain.stop();
     Timer tev(ctx);
     hipLaunchKernelGGL(k_aln_events, dim3(np), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
@@ -563,6 +570,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
             FSV_HIP(ctx, hipMemcpyAsync(events.data() + (size_t)p * ALN_EV_CAP, (const AlnEvent *)W.events.p + (size_t)p * ALN_EV_CAP,
                                         (size_t)hdr[p].n_events * sizeof(AlnEvent), hipMemcpyDeviceToHost, ctx->stream));
     FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    trace("events");
     W.stats.ms_events = tev.stop();
     // DP tasks
     Timer tdp(ctx);
@@ -593,6 +601,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
         FSV_HIP(ctx, hipMemcpyAsync(cg.data(), W.cg.p, cg.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    trace("dp");
     W.stats.ms_dp = tdp.stop();
     W.stats.n_pairs = np; W.stats.n_events = tasks.size();
     // stitch: S, M runs, events, S
@@ -625,6 +634,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
         }
         out->contig_status[p] = st;
     }
+    trace("stitch");
     W.stats.ms_total = ttot.stop();
     return FSV_OK;
 }
