@@ -37,7 +37,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
 
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
-        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, upair_base, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -50,7 +50,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &upair_base, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -106,8 +106,8 @@ uint8_t thr_for_len_host(int x_len)
 }
 
 struct Batch {
-    uint32_t n_reads = 0, n_sets = 0, n_pairs = 0;
-    std::vector<uint32_t> set_start, read_set, pair_base;
+    uint32_t n_reads = 0, n_sets = 0, n_pairs = 0, n_upairs = 0;
+    std::vector<uint32_t> set_start, read_set, pair_base, upair_base;
 };
 
 // per-round geometry derived from the current read lengths
@@ -190,13 +190,13 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     Timer tc(ctx);
     ChainArgs A;
     A.store = store; A.word_off = (const uint32_t *)W.word_off.p; A.read_len = (const int32_t *)W.len.p;
-    A.set_start = (const uint32_t *)W.set_start.p; A.pair_base = (const uint32_t *)W.pair_base.p;
+    A.set_start = (const uint32_t *)W.set_start.p; A.pair_base = (const uint32_t *)W.pair_base.p; A.upair_base = (const uint32_t *)W.upair_base.p;
     A.mz = (const fsv_mz *)W.mz.p; A.mz_off = (const uint32_t *)W.mz_off.p; A.mz_cnt = (const uint32_t *)W.mz_cnt.p;
     A.ovl = (fsv_ovl *)W.ovl.p; A.tasks = (fsv_wtask *)W.tasks.p; A.task_counter = (uint32_t *)W.counters.p; A.task_cap = task_cap;
     A.overflow = (uint32_t *)W.counters.p + 1; A.warn = (uint32_t *)W.warn.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
     A.n_sets = B.n_sets; A.k_score = P.k; A.min_anchors = P.min_anchors; A.min_ovlp = P.min_ovlp; A.bw = bw; A.emit_tasks = emit_tasks ? 1 : 0;
-    // algorithmic bytes of the pairwise join: every ordered pair reads both unique-minimizer lists (16 B each) and writes one
-    // overlap slot; the window tasks it emits are added once their number is known
+    // algorithmic bytes of the pairwise join: every unordered pair reads both unique-minimizer lists (16 B each) and writes two
+    // overlap slots; the window tasks it emits are added once their number is known
     uint64_t chain_bytes = (uint64_t)B.n_pairs * sizeof(fsv_ovl);
     {
         std::vector<uint32_t> cnt(B.n_reads);
@@ -206,11 +206,11 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
             const uint64_t ns = B.set_start[s2 + 1] - B.set_start[s2];
             uint64_t tot = 0;
             for (uint32_t r = B.set_start[s2]; r < B.set_start[s2 + 1]; r++) tot += cnt[r];
-            if (ns > 1) chain_bytes += 2 * (ns - 1) * tot * sizeof(fsv_mz);
+            if (ns > 1) chain_bytes += (ns - 1) * tot * sizeof(fsv_mz); // every unordered pair reads both lists once
         }
     }
     W.kt.begin(ctx, KN_CHAIN, chain_bytes);
-    hipLaunchKernelGGL(k_chain, dim3(B.n_pairs), dim3(64), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_chain, dim3(B.n_upairs), dim3(64), 0, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
     W.stats.ms_chain += tc.stop();
@@ -322,17 +322,19 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     if (B.n_reads == 0 || B.n_sets == 0) return FSV_OK;
     B.set_start.assign(sets->set_start, sets->set_start + B.n_sets + 1);
     if (B.set_start[0] != 0 || B.set_start[B.n_sets] != B.n_reads) return fsv_fail(ctx, FSV_EINVAL, "set_start must span [0, n_reads]");
-    B.read_set.resize(B.n_reads); B.pair_base.resize(B.n_sets + 1);
+    B.read_set.resize(B.n_reads); B.pair_base.resize(B.n_sets + 1); B.upair_base.resize(B.n_sets + 1);
     uint64_t np = 0;
     for (uint32_t s = 0; s < B.n_sets; s++) {
         if (B.set_start[s + 1] < B.set_start[s]) return fsv_fail(ctx, FSV_EINVAL, "set_start not monotone");
         uint64_t ns = B.set_start[s + 1] - B.set_start[s];
         B.pair_base[s] = (uint32_t)np;
+        B.upair_base[s] = (uint32_t)(np / 2);
         np += ns > 1 ? ns * (ns - 1) : 0;
         for (uint32_t r = B.set_start[s]; r < B.set_start[s + 1]; r++) B.read_set[r] = s;
     }
     if (np >= (1ull << 31)) return fsv_fail(ctx, FSV_EUNSUP, "too many read pairs in one batch; split it");
     B.pair_base[B.n_sets] = (uint32_t)np; B.n_pairs = (uint32_t)np;
+    B.upair_base[B.n_sets] = (uint32_t)(np / 2); B.n_upairs = (uint32_t)(np / 2);
     std::vector<int32_t> len(sets->read_len, sets->read_len + B.n_reads);
     for (uint32_t r = 0; r < B.n_reads; r++) if (len[r] < 1 || len[r] >= (1 << 24)) return fsv_fail(ctx, FSV_EUNSUP, "read length must be in [1, 2^24)");
 
@@ -342,6 +344,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     TRY(upload(ctx, W.set_start, B.set_start));
     TRY(upload(ctx, W.read_set, B.read_set));
     TRY(upload(ctx, W.pair_base, B.pair_base));
+    TRY(upload(ctx, W.upair_base, B.upair_base));
     TRY(ensure(ctx, W.warn, (size_t)B.n_reads * 4));
     FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)B.n_reads * 4, ctx->stream));
 

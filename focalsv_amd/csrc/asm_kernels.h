@@ -324,7 +324,8 @@ struct ChainArgs {
     const uint32_t *word_off;
     const int32_t *read_len;
     const uint32_t *set_start;   // n_sets + 1
-    const uint32_t *pair_base;   // n_sets + 1
+    const uint32_t *pair_base;   // n_sets + 1: ordered-pair slots
+    const uint32_t *upair_base;  // n_sets + 1: unordered pairs (one block each)
     const fsv_mz *mz;
     const uint32_t *mz_off;
     const uint32_t *mz_cnt;
@@ -348,15 +349,20 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     int32_t *const s_f = s_dp, *const s_ind = s_dp + FSV_AMAX, *const s_sl = s_dp + 2 * FSV_AMAX;
     __shared__ uint16_t s_chain[FSV_AMAX];
     const int lane = threadIdx.x;
-    const uint32_t p = blockIdx.x;
-    // locate the set: largest s with pair_base[s] <= p
+    // One block per UNORDERED pair (q < t) of a set: the chain is computed with q as the query and the overlap of t on q is
+    // its mirror image (oracle/asm.c collect_overlaps); both ordered slots and both window-task lists are written here.
+    const uint32_t up = blockIdx.x;
     uint32_t lo = 0, hi = A.n_sets;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (A.pair_base[mid] <= p) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (A.upair_base[mid] <= up) lo = mid; else hi = mid; }
     const uint32_t s = lo, r0 = A.set_start[s], ns = A.set_start[s + 1] - r0;
-    const uint32_t idx = p - A.pair_base[s];
-    const uint32_t q = idx / (ns - 1);
-    uint32_t t = idx % (ns - 1);
-    t += (t >= q);
+    const uint32_t idx = up - A.upair_base[s];
+    // row q holds the pairs (q, q+1..ns-1): rows start at q*(2ns-q-1)/2
+    uint32_t q = (uint32_t)((2.0 * ns - 1.0 - sqrt((2.0 * ns - 1.0) * (2.0 * ns - 1.0) - 8.0 * (double)idx)) * 0.5);
+    while (q > 0 && (uint64_t)q * (2ull * ns - q - 1) / 2 > idx) q--;
+    while ((uint64_t)(q + 1) * (2ull * ns - q - 2) / 2 <= idx) q++;
+    const uint32_t t = q + 1 + (idx - (uint32_t)((uint64_t)q * (2ull * ns - q - 1) / 2));
+    const uint32_t p = A.pair_base[s] + q * (ns - 1) + (t - 1);   // ordered slot (q, t), t > q
+    const uint32_t pm = A.pair_base[s] + t * (ns - 1) + q;        // ordered slot (t, q), q < t
     const uint32_t rq = r0 + q, rt = r0 + t;
     const int lenq = A.read_len[rq], lent = A.read_len[rt];
     const int nq = (int)A.mz_cnt[rq], nt = (int)A.mz_cnt[rt];
@@ -364,6 +370,9 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     fsv_ovl o;
     o.q = q; o.t = t; o.x_s = o.x_e = o.y_s = o.y_e = 0; o.score = 0; o.n_chain = 0; o.chain_off = 0; o.first_win = 0; o.n_win = 0;
     o.align_len = 0; o.err_sum = 0; o.rev = 0; o.is_match = 0; o.exact = 0; o.valid = 0;
+    fsv_ovl om = o; // the mirrored overlap (t on q)
+    om.q = t; om.t = q;
+#define PUT_BOTH() do { if (lane == 0) { A.ovl[p] = o; A.ovl[pm] = om; } } while (0)
 
     // 1. anchors: every q minimizer is looked up in t's sorted unique list; t's hashes are staged in LDS (s_f/s_ind are
     //    free until the DP) so that the ~10 probes per lookup are LDS reads instead of dependent global loads
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         __syncthreads();
     }
     n = m2;
-    if (n < A.min_anchors) { if (lane == 0) A.ovl[p] = o; return; }
+    if (n < A.min_anchors) { PUT_BOTH(); return; }
     // 3. anchors are already in query order: q's minimizers were walked by position and both compactions keep the order
     //    (query positions are distinct, so (qe, te) order == qe order)
     // 4. chain DP: lane l examines predecessor i-1-l (nearest first on ties).
@@ -483,41 +492,84 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     if (lane == 0) { int c = best; while (c != 0xffff) { s_chain[cnt++] = (uint16_t)c; c = s_aux[c]; } }
     cnt = __shfl(cnt, 0, 64);
     __syncthreads();
-    if (cnt < A.min_anchors) { if (lane == 0) A.ovl[p] = o; return; }
+    if (cnt < A.min_anchors) { PUT_BOTH(); return; }
     const int first = s_chain[cnt - 1];
     int xs = (int)(s_key[first] >> 32), ys = (int)(uint32_t)s_key[first];
     int xe = (int)(s_key[best] >> 32), ye = (int)(uint32_t)s_key[best];
     { int m = min(xs, ys); xs -= m; ys -= m; int r = min(lenq - 1 - xe, lent - 1 - ye); xe += r; ye += r; }
-    if (xe - xs + 1 < A.min_ovlp) { if (lane == 0) A.ovl[p] = o; return; }
+    if (xe - xs + 1 < A.min_ovlp) { PUT_BOTH(); return; }
     o.x_s = xs; o.x_e = xe; o.y_s = ys; o.y_e = ye; o.rev = (uint8_t)rev; o.score = s_f[best]; o.n_chain = cnt; o.valid = 1;
     o.n_win = xe / FSV_WINDOW - xs / FSV_WINDOW + 1;
-    if (!A.emit_tasks) { o.n_win = 0; if (lane == 0) A.ovl[p] = o; return; }
-    // 7. window tasks
+    // mirror: same anchors seen from t; on the reverse strand both coordinates are measured from the other read end
+    om.rev = (uint8_t)rev; om.score = o.score; om.n_chain = cnt; om.valid = 1;
+    if (!rev) { om.x_s = ys; om.x_e = ye; om.y_s = xs; om.y_e = xe; }
+    else { om.x_s = lent - 1 - ye; om.x_e = lent - 1 - ys; om.y_s = lenq - 1 - xe; om.y_e = lenq - 1 - xs; }
+    om.n_win = om.x_e / FSV_WINDOW - om.x_s / FSV_WINDOW + 1;
+    if (!A.emit_tasks) { o.n_win = 0; om.n_win = 0; PUT_BOTH(); return; }
+    // 7. window tasks of both directions
     uint32_t first_win = 0;
-    if (lane == 0) first_win = atomicAdd(A.task_counter, (uint32_t)o.n_win);
+    if (lane == 0) first_win = atomicAdd(A.task_counter, (uint32_t)(o.n_win + om.n_win));
     first_win = __shfl(first_win, 0, 64);
-    if ((uint64_t)first_win + (uint32_t)o.n_win > A.task_cap) {
-        if (lane == 0) { atomicExch(A.overflow, 1u); o.valid = 0; o.n_win = 0; A.ovl[p] = o; }
+    if ((uint64_t)first_win + (uint32_t)(o.n_win + om.n_win) > A.task_cap) {
+        if (lane == 0) { atomicExch(A.overflow, 1u); o.valid = 0; o.n_win = 0; om.valid = 0; om.n_win = 0; A.ovl[p] = o; A.ovl[pm] = om; }
         return;
     }
     o.first_win = (int32_t)first_win;
-    const int w0 = xs / FSV_WINDOW;
+    om.first_win = (int32_t)(first_win + (uint32_t)o.n_win);
     const uint32_t xw = A.word_off[rq], yw = A.word_off[rt];
-    for (int j = lane; j < o.n_win; j += 64) {
-        const int gs = (w0 + j) * FSV_WINDOW, ge = gs + FSV_WINDOW - 1;
-        const int x_start = max(gs, xs);
-        const int x_len = min(ge, xe) - x_start + 1;
-        // diagonal of the last chain anchor with qe <= x_start (chain is stored end-to-start)
-        int lo2 = 0, hi2 = cnt; // in start-to-end order: element e = s_chain[cnt-1-e]
-        while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; int qe = (int)(s_key[s_chain[cnt - 1 - mid]] >> 32); if (qe <= x_start) lo2 = mid + 1; else hi2 = mid; }
-        const uint64_t ka = s_key[s_chain[cnt - 1 - (lo2 == 0 ? 0 : lo2 - 1)]];
-        const int diag = (int)(uint32_t)ka - (int)(ka >> 32);
-        fsv_wtask w;
-        w.x_word = xw; w.y_word = yw; w.x_start = x_start; w.y_start = x_start + diag; w.y_len = lent;
-        w.x_len = (uint16_t)x_len; w.k = A.thr_tab[x_len]; w.y_rev = (uint8_t)rev; w.ovl = p; w.win = (uint32_t)j;
-        A.tasks[first_win + j] = w;
+    // chain anchor e (start-to-end order, 0 <= e < cnt)
+#define CH_Q(e) ((int)(s_key[s_chain[cnt - 1 - (e)]] >> 32))
+#define CH_T(e) ((int)(uint32_t)s_key[s_chain[cnt - 1 - (e)]])
+    {
+        const int w0 = xs / FSV_WINDOW;
+        for (int j = lane; j < o.n_win; j += 64) {
+            const int gs = (w0 + j) * FSV_WINDOW, ge = gs + FSV_WINDOW - 1;
+            const int x_start = max(gs, xs);
+            const int x_len = min(ge, xe) - x_start + 1;
+            // diagonal of the last chain anchor with qe <= x_start, else of the first one
+            int lo2 = 0, hi2 = cnt;
+            while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (CH_Q(mid) <= x_start) lo2 = mid + 1; else hi2 = mid; }
+            const int e = lo2 == 0 ? 0 : lo2 - 1;
+            const int diag = CH_T(e) - CH_Q(e);
+            fsv_wtask w;
+            w.x_word = xw; w.y_word = yw; w.x_start = x_start; w.y_start = x_start + diag; w.y_len = lent;
+            w.x_len = (uint16_t)x_len; w.k = A.thr_tab[x_len]; w.y_rev = (uint8_t)rev; w.ovl = p; w.win = (uint32_t)j;
+            A.tasks[first_win + j] = w;
+        }
     }
-    if (lane == 0) A.ovl[p] = o;
+    {
+        // mirrored direction: query t, target q.  Mirrored anchor of e: same strand (ct_e, cq_e) in the same order;
+        // reverse strand (lent-1-ct_e, lenq-1-cq_e) in reversed order.
+        const int mxs = om.x_s, mxe = om.x_e, w0 = mxs / FSV_WINDOW;
+        for (int j = lane; j < om.n_win; j += 64) {
+            const int gs = (w0 + j) * FSV_WINDOW, ge = gs + FSV_WINDOW - 1;
+            const int x_start = max(gs, mxs);
+            const int x_len = min(ge, mxe) - x_start + 1;
+            int diag;
+            if (!rev) {
+                int lo2 = 0, hi2 = cnt; // last anchor with ct <= x_start
+                while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (CH_T(mid) <= x_start) lo2 = mid + 1; else hi2 = mid; }
+                const int e = lo2 == 0 ? 0 : lo2 - 1;
+                diag = CH_Q(e) - CH_T(e);
+            } else {
+                // mirrored query coordinate lent-1-ct_e decreases with e: the last mirrored anchor with coordinate <= x_start is the
+                // smallest e with ct_e >= lent-1-x_start; none -> the first mirrored anchor (e = cnt-1)
+                const int thr = lent - 1 - x_start;
+                int lo2 = 0, hi2 = cnt; // first e with ct_e >= thr
+                while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (CH_T(mid) < thr) lo2 = mid + 1; else hi2 = mid; }
+                const int e = lo2 == cnt ? cnt - 1 : lo2;
+                diag = (lenq - 1 - CH_Q(e)) - (lent - 1 - CH_T(e));
+            }
+            fsv_wtask w;
+            w.x_word = yw; w.y_word = xw; w.x_start = x_start; w.y_start = x_start + diag; w.y_len = lenq;
+            w.x_len = (uint16_t)x_len; w.k = A.thr_tab[x_len]; w.y_rev = (uint8_t)rev; w.ovl = pm; w.win = (uint32_t)j;
+            A.tasks[om.first_win + j] = w;
+        }
+    }
+#undef CH_Q
+#undef CH_T
+    PUT_BOTH();
+#undef PUT_BOTH
 }
 
 // ------------------------------------------------------------------------------------------------ k_rescue_accept

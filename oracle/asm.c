@@ -294,28 +294,53 @@ typedef struct {
     int *len;
 } readset;
 
+static int ovl_cmp(const void *a, const void *b)
+{
+    const orc_ovl *x = (const orc_ovl *)a, *y = (const orc_ovl *)b;
+    if (x->q != y->q) return x->q < y->q ? -1 : 1;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return 0;
+}
+
+/* An overlap is a symmetric object: every unordered pair (a < b) is chained once, with a as the query, and the overlap of
+ * b on a is the mirror image of the same chain (hifiasm recomputes it from b's side, anchor.cpp:207-300; mirroring halves the
+ * chaining work and both directions agree on the anchors).  On the reverse strand the mirrored coordinates are measured from
+ * the other end of both reads and the anchor order flips. */
 static void collect_overlaps(const readset *R, const orc_asm_params *P, int bw, orc_mz **uq, int *nuq, orc_ovl **ovl_out,
                              int32_t **cq_out, int32_t **ct_out, int *n_out)
 {
-    int q, t, n = 0, cap = 1024, chain_cap = 0, ccap = 1 << 16, cused = 0;
+    int q, t, n = 0, cap = 1024, chain_cap = 0, ccap = 1 << 16, cused = 0, i;
     orc_ovl *ov = (orc_ovl *)malloc(sizeof(orc_ovl) * (size_t)cap);
     int32_t *cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)ccap), *ct = (int32_t *)malloc(sizeof(int32_t) * (size_t)ccap);
     for (q = 0; q < R->n; q++) if (nuq[q] > chain_cap) chain_cap = nuq[q];
     for (q = 0; q < R->n; q++)
-        for (t = 0; t < R->n; t++) {
-            orc_ovl o;
-            if (q == t) continue;
-            if (cused + chain_cap > ccap) {
-                ccap = (cused + chain_cap) * 2;
+        for (t = q + 1; t < R->n; t++) {
+            orc_ovl o, m;
+            const int lenq = R->len[q], lent = R->len[t];
+            if (cused + 2 * chain_cap > ccap) {
+                ccap = (cused + 2 * chain_cap) * 2;
                 cq = (int32_t *)realloc(cq, sizeof(int32_t) * (size_t)ccap);
                 ct = (int32_t *)realloc(ct, sizeof(int32_t) * (size_t)ccap);
             }
-            if (!orc_chain_pair(uq[q], nuq[q], R->len[q], uq[t], nuq[t], R->len[t], P, bw, &o, cq + cused, ct + cused, chain_cap)) continue;
+            if (!orc_chain_pair(uq[q], nuq[q], lenq, uq[t], nuq[t], lent, P, bw, &o, cq + cused, ct + cused, chain_cap)) continue;
             o.q = (uint32_t)q; o.t = (uint32_t)t; o.chain_off = cused;
-            cused += o.n_chain;
-            if (n == cap) { cap *= 2; ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)cap); }
-            ov[n++] = o;
+            m = o;
+            m.q = (uint32_t)t; m.t = (uint32_t)q; m.chain_off = cused + o.n_chain;
+            if (!o.rev) {
+                m.x_s = o.y_s; m.x_e = o.y_e; m.y_s = o.x_s; m.y_e = o.x_e;
+                for (i = 0; i < o.n_chain; i++) { cq[m.chain_off + i] = ct[o.chain_off + i]; ct[m.chain_off + i] = cq[o.chain_off + i]; }
+            } else {
+                m.x_s = lent - 1 - o.y_e; m.x_e = lent - 1 - o.y_s; m.y_s = lenq - 1 - o.x_e; m.y_e = lenq - 1 - o.x_s;
+                for (i = 0; i < o.n_chain; i++) {
+                    const int src = o.chain_off + o.n_chain - 1 - i;
+                    cq[m.chain_off + i] = lent - 1 - ct[src]; ct[m.chain_off + i] = lenq - 1 - cq[src];
+                }
+            }
+            cused += 2 * o.n_chain;
+            if (n + 2 > cap) { cap *= 2; ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)cap); }
+            ov[n++] = o; ov[n++] = m;
         }
+    qsort(ov, (size_t)n, sizeof(orc_ovl), ovl_cmp); /* the consumers expect the overlaps of one query to be contiguous */
     *ovl_out = ov; *cq_out = cq; *ct_out = ct; *n_out = n;
 }
 
