@@ -25,7 +25,7 @@ namespace {
 
 struct AlnHeader { int32_t qbeg, tbeg, qend, tend, n_events, n_chain, rev, status; };
 struct AlnEvent { int32_t qs, qe, ts, te; };   // inclusive
-struct NwTask { uint32_t pair; int32_t qs, ql, ts, tl; uint32_t cg_off; uint64_t bt_off; uint64_t row_off; };
+struct NwTask { uint32_t pair; int32_t qs, ql, ts, tl; uint32_t cg_off; uint64_t bt_off; uint64_t row_off; uint32_t out_idx, pad; };
 
 __device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
 
@@ -215,20 +215,21 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
 // One workgroup per event, cells of one anti-diagonal in parallel.  Rolling rows indexed by the query position:
 //   H on diagonals d-1 and d-2, and the E/F/E2/F2 values *leaving* each cell of diagonal d-1.
 // Per cell one traceback byte with ksw2's layout (ksw2.h:115-118).
+template <int QCAP> // queries up to QCAP bases keep their rolling rows in LDS (11 x QCAP x 4 B); small events get many blocks per CU
 __global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                             const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                             const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                             const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all, int32_t *__restrict__ rows_all,
                                             uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
 {
-    __shared__ int32_t s_rows[11 * NW_LDS_Q];
+    __shared__ int32_t s_rows[11 * QCAP];
     const NwTask T = tasks[blockIdx.x];
     const uint32_t qw = word_off[pair_q[T.pair]], tw = word_off[pair_t[T.pair]];
     const int lenq = read_len[pair_q[T.pair]], rev = hdr[T.pair].rev;
     const int ql = T.ql, tl = T.tl;
     const bool two = P.q2 >= 0;
-    int32_t *rows = ql <= NW_LDS_Q ? s_rows : rows_all + T.row_off;
-    const int stride = ql <= NW_LDS_Q ? NW_LDS_Q : ql;
+    int32_t *rows = ql <= QCAP ? s_rows : rows_all + T.row_off;
+    const int stride = ql <= QCAP ? QCAP : ql;
     uint8_t *bt = bt_all + T.bt_off;
     // rows: H[3], Eo[2], Fo[2], E2o[2], F2o[2]
 #define HROW(d) (rows + (size_t)(((d) % 3 + 3) % 3) * stride)
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, 
         (void)H1;
     }
     if (threadIdx.x != 0) return;
-    scores[blockIdx.x] = HROW(ql + tl - 2)[ql - 1];
+    scores[T.out_idx] = HROW(ql + tl - 2)[ql - 1];
     // ksw_backtrack, emitted end-to-start then reversed in place
     uint32_t *cg = cg_all + T.cg_off;
     int n = 0, i = tl - 1, j = ql - 1, state = 0;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, 
     if (i >= 0) put(2, (uint32_t)(i + 1));
     if (j >= 0) put(1, (uint32_t)(j + 1));
     for (int k2 = 0; k2 < n / 2; k2++) { uint32_t t = cg[k2]; cg[k2] = cg[n - 1 - k2]; cg[n - 1 - k2] = t; }
-    cg_n[blockIdx.x] = over ? 0xffffffffu : (uint32_t)n;
+    cg_n[T.out_idx] = over ? 0xffffffffu : (uint32_t)n;
 #undef HROW
 #undef EROW
 #undef FROW
@@ -313,9 +314,9 @@ __global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, 
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 struct AlnWs {
-    DevBuf store, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, tasks, bt, rows, cg, cg_n, scores;
+    DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, tasks, bt, rows, cg, cg_n, scores;
     fsv_aln_stats stats;
-    std::vector<DevBuf *> all() { return {&store, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
+    std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
 };
 
 void aln_ws_free(fsv_ctx *ctx)
@@ -356,40 +357,91 @@ struct Timer {
 };
 
 // packs pairs (query, target) into a store; returns lens / offsets
+// ASCII -> 2-bit store on the device: one thread per output word, 16 source bytes each (N and anything else -> A,
+// as fsv_pack_reads does on the host)
+__global__ __launch_bounds__(256) void k_pack_ascii(const char *__restrict__ ascii, const uint64_t *__restrict__ asc_off,
+                                                    const uint32_t *__restrict__ word_off, const int32_t *__restrict__ read_len,
+                                                    uint32_t n_reads, uint32_t total_words, uint32_t *__restrict__ words)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= total_words) return;
+    uint32_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (word_off[mid] <= w) lo = mid; else hi = mid; }
+    const uint32_t r = lo;
+    const int len = read_len[r];
+    const int b0 = (int)(w - word_off[r]) * 16;
+    const char *src = ascii + asc_off[r] + b0;
+    uint32_t v = 0;
+    for (int j = 0; j < 16 && b0 + j < len; j++) {
+        const char c = src[j];
+        const uint32_t code = (c == 'C' || c == 'c') ? 1u : (c == 'G' || c == 'g') ? 2u : (c == 'T' || c == 't') ? 3u : 0u;
+        v |= code << (2 * j);
+    }
+    words[w] = v;
+}
+
+// sequences (already concatenated by the caller in two buffers: reference windows, contigs) -> device 2-bit store
 int pack_pairs(fsv_ctx *ctx, AlnWs &W, const std::vector<const char *> &seq, const std::vector<uint64_t> &slen, std::vector<uint32_t> &word_off,
                std::vector<int32_t> &len)
 {
     const uint32_t n = (uint32_t)seq.size();
-    std::vector<uint64_t> off(n + 1, 0);
-    for (uint32_t r = 0; r < n; r++) off[r + 1] = off[r] + slen[r];
-    std::vector<char> cat(off[n] + 1);
-    for (uint32_t r = 0; r < n; r++) memcpy(cat.data() + off[r], seq[r], slen[r]);
-    const size_t cap = fsv_pack_bound(off.data(), n);
-    if (cap >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "alignment batch too large; split it");
-    std::vector<uint32_t> words(cap);
-    std::vector<uint64_t> woff(n + 1);
-    TRY(fsv_pack_reads(cat.data(), off.data(), n, words.data(), cap, woff.data()));
-    word_off.resize(n + 1); len.resize(n);
-    for (uint32_t r = 0; r <= n; r++) word_off[r] = (uint32_t)woff[r];
-    for (uint32_t r = 0; r < n; r++) len[r] = (int32_t)slen[r];
-    TRY(upload(ctx, W.store, words));
+    word_off.assign(n + 1, 0); len.resize(n);
+    std::vector<uint64_t> asc_off(n + 1, 0);
+    uint64_t w = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        word_off[r] = (uint32_t)w; len[r] = (int32_t)slen[r];
+        w += (slen[r] + 15) / 16;
+        asc_off[r + 1] = asc_off[r] + slen[r];
+    }
+    if (w + 8 >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "alignment batch too large; split it");
+    word_off[n] = (uint32_t)w;
+    TRY(ensure(ctx, W.ascii, asc_off[n] + 64));
+    // consecutive sequences that are adjacent in host memory go up in one copy (the callers pass two contiguous buffers)
+    for (uint32_t r = 0; r < n;) {
+        uint32_t e = r + 1;
+        while (e < n && seq[e] == seq[e - 1] + slen[e - 1]) e++;
+        FSV_HIP(ctx, hipMemcpyAsync((char *)W.ascii.p + asc_off[r], seq[r], asc_off[e] - asc_off[r], hipMemcpyHostToDevice, ctx->stream));
+        r = e;
+    }
+    TRY(upload(ctx, W.asc_off, asc_off));
     TRY(upload(ctx, W.word_off, word_off));
     TRY(upload(ctx, W.len, len));
+    TRY(ensure(ctx, W.store, (w + 8) * 4));
+    FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.store.p + w, 0, 32, ctx->stream));
+    hipLaunchKernelGGL(k_pack_ascii, dim3(fsv_grid_for(w, 256)), dim3(256), 0, ctx->stream, (const char *)W.ascii.p, (const uint64_t *)W.asc_off.p,
+                       (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, n, (uint32_t)w, (uint32_t *)W.store.p);
+    FSV_HIP(ctx, hipGetLastError());
     return FSV_OK;
 }
 
 int run_nw(fsv_ctx *ctx, AlnWs &W, const std::vector<NwTask> &tasks, uint64_t bt_bytes, uint64_t row_words, const fsv_aln_params &P)
 {
-    TRY(upload(ctx, W.tasks, tasks));
+    // small events first in the array (stable), so that each launch covers a contiguous range and outputs keep their task index
+    const size_t n = tasks.size();
+    std::vector<uint32_t> order(n);
+    size_t ns = 0;
+    for (size_t i = 0; i < n; i++) if (tasks[i].ql <= 256) order[ns++] = (uint32_t)i;
+    size_t nl = ns;
+    for (size_t i = 0; i < n; i++) if (tasks[i].ql > 256) order[nl++] = (uint32_t)i;
+    std::vector<NwTask> sorted(n);
+    for (size_t i = 0; i < n; i++) { sorted[i] = tasks[order[i]]; sorted[i].cg_off = order[i] * (uint32_t)ALN_CG_CAP; sorted[i].out_idx = order[i]; }
+    TRY(upload(ctx, W.tasks, sorted));
     TRY(ensure(ctx, W.bt, bt_bytes + 16));
     TRY(ensure(ctx, W.rows, row_words * 4 + 16));
-    TRY(ensure(ctx, W.cg, tasks.size() * (size_t)ALN_CG_CAP * 4));
-    TRY(ensure(ctx, W.cg_n, tasks.size() * 4));
-    TRY(ensure(ctx, W.scores, tasks.size() * 4));
-    hipLaunchKernelGGL(k_nw, dim3((uint32_t)tasks.size()), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
-                       (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
-                       (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (int32_t *)W.rows.p,
-                       (uint32_t *)W.cg.p, (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
+    TRY(ensure(ctx, W.cg, n * (size_t)ALN_CG_CAP * 4));
+    TRY(ensure(ctx, W.cg_n, n * 4));
+    TRY(ensure(ctx, W.scores, n * 4));
+    if (ns)
+        hipLaunchKernelGGL(k_nw<256>, dim3((uint32_t)ns), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
+                           (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (int32_t *)W.rows.p, (uint32_t *)W.cg.p, (uint32_t *)W.cg_n.p,
+                           (int32_t *)W.scores.p, P);
+    FSV_HIP(ctx, hipGetLastError());
+    if (n > ns)
+        hipLaunchKernelGGL(k_nw<NW_LDS_Q>, dim3((uint32_t)(n - ns)), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p,
+                           (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
+                           (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + ns, (uint8_t *)W.bt.p, (int32_t *)W.rows.p, (uint32_t *)W.cg.p,
+                           (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
     return FSV_OK;
 }
@@ -442,7 +494,7 @@ extern "C" int fsv_nw(fsv_ctx *ctx, const char *target, int32_t tl, const char *
     TRY(upload(ctx, W.pair_q, std::vector<uint32_t>{0u}));
     TRY(upload(ctx, W.pair_t, std::vector<uint32_t>{1u}));
     std::vector<NwTask> tasks(1);
-    tasks[0] = NwTask{0u, 0, ql, 0, tl, 0u, 0ull, 0ull};
+    tasks[0] = NwTask{0u, 0, ql, 0, tl, 0u, 0ull, 0ull, 0u, 0u};
     TRY(run_nw(ctx, W, tasks, (uint64_t)tl * ql, ql > NW_LDS_Q ? 11ull * ql : 0, P));
     uint32_t n = 0; int32_t sc = 0;
     FSV_HIP(ctx, hipMemcpyAsync(&n, W.cg_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -583,6 +635,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
         for (int e = 0; e < hdr[p].n_events; e++) {
             const AlnEvent &ev = events[(size_t)p * ALN_EV_CAP + e];
             NwTask t;
+            t.out_idx = 0; t.pad = 0;
             t.pair = p; t.qs = ev.qs; t.ql = ev.qe - ev.qs + 1; t.ts = ev.ts; t.tl = ev.te - ev.ts + 1;
             t.cg_off = (uint32_t)(tasks.size() * ALN_CG_CAP); t.bt_off = bt; t.row_off = rows;
             bt += (uint64_t)t.ql * t.tl;
