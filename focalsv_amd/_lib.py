@@ -237,6 +237,7 @@ class Context:
         p = params if params is not None else self.default_asm_params()
         self.check(self._lib.fsv_assemble_batch(self._h, C.byref(rs), C.byref(p), C.byref(out)), "fsv_assemble_batch")
         n = out.n_contigs
+        self._last_contig_bytes = int(off[n])
         contigs = [seq[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
         return contigs, cset[:n].copy(), cnr[:n].copy(), status[:rs.n_sets].copy()
 
@@ -275,21 +276,27 @@ class Context:
     def align_batch(self, contigs, contig_ref, refs, params=None):
         """fsv_align_batch.  contigs / refs: lists of bytes; contig_ref[i] = index of the window contig i belongs to.
         -> (records ndarray[ALN_REC_DTYPE], cigar ndarray[uint32], contig_status ndarray[int32])"""
-        n = len(contigs)
+        from_dev = contigs is None   # contigs of the last assemble_batch, still on the device
+        n = len(contig_ref) if from_dev else len(contigs)
         coff = np.zeros(n + 1, dtype=np.uint64)
-        np.cumsum([len(c) for c in contigs], out=coff[1:])
         roff = np.zeros(len(refs) + 1, dtype=np.uint64)
         np.cumsum([len(r) for r in refs], out=roff[1:])
-        cseq = np.frombuffer(b"".join(contigs) + b"\0", dtype=np.uint8)
+        if from_dev:
+            cseq = None
+            total = int(self._last_contig_bytes)
+        else:
+            np.cumsum([len(c) for c in contigs], out=coff[1:])
+            cseq = np.frombuffer(b"".join(contigs) + b"\0", dtype=np.uint8)
+            total = int(coff[-1])
         rseq = np.frombuffer(b"".join(refs) + b"\0", dtype=np.uint8)
         cref = np.ascontiguousarray(contig_ref, dtype=np.uint32)
         rec = np.zeros(max(1, n), dtype=ALN_REC_DTYPE)
-        cap = int(coff[-1]) // 8 + 4096 * max(1, n)
+        cap = total // 8 + 4096 * max(1, n)
         cigar = np.zeros(cap, dtype=np.uint32)
         status = np.zeros(max(1, n), dtype=np.int32)
         out = Alns(_ptr(rec).value, len(rec), 0, _ptr(cigar).value, cap, 0, _ptr(status).value)
         p = params if params is not None else self.default_aln_params()
-        self.check(self._lib.fsv_align_batch(self._h, _ptr(cseq), _ptr(coff), n, _ptr(cref), _ptr(rseq), _ptr(roff), len(refs), C.byref(p),
+        self.check(self._lib.fsv_align_batch(self._h, None if from_dev else _ptr(cseq), _ptr(coff), n, _ptr(cref), _ptr(rseq), _ptr(roff), len(refs), C.byref(p),
                                              C.byref(out)), "fsv_align_batch")
         return rec[: out.n_rec].copy(), cigar[: out.n_cigar].copy(), status[:n].copy()
 

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_pack_ascii(const char *__restrict__ asc
 
 // sequences (already concatenated by the caller in two buffers: reference windows, contigs) -> device 2-bit store
 int pack_pairs(fsv_ctx *ctx, AlnWs &W, const std::vector<const char *> &seq, const std::vector<uint64_t> &slen, std::vector<uint32_t> &word_off,
-               std::vector<int32_t> &len)
+               std::vector<int32_t> &len, const char *dev_src = nullptr, uint32_t dev_first = 0)
 {
     const uint32_t n = (uint32_t)seq.size();
     word_off.assign(n + 1, 0); len.resize(n);
@@ -397,9 +397,13 @@ int pack_pairs(fsv_ctx *ctx, AlnWs &W, const std::vector<const char *> &seq, con
     word_off[n] = (uint32_t)w;
     TRY(ensure(ctx, W.ascii, asc_off[n] + 64));
     // consecutive sequences that are adjacent in host memory go up in one copy (the callers pass two contiguous buffers)
-    for (uint32_t r = 0; r < n;) {
+    // sequences dev_first.. are already on the device, back to back at dev_src (contigs of the last assembly): one D2D copy
+    const uint32_t n_host = dev_src ? dev_first : n;
+    if (dev_src && n > dev_first)
+        FSV_HIP(ctx, hipMemcpyAsync((char *)W.ascii.p + asc_off[dev_first], dev_src, asc_off[n] - asc_off[dev_first], hipMemcpyDeviceToDevice, ctx->stream));
+    for (uint32_t r = 0; r < n_host;) {
         uint32_t e = r + 1;
-        while (e < n && seq[e] == seq[e - 1] + slen[e - 1]) e++;
+        while (e < n_host && seq[e] == seq[e - 1] + slen[e - 1]) e++;
         FSV_HIP(ctx, hipMemcpyAsync((char *)W.ascii.p + asc_off[r], seq[r], asc_off[e] - asc_off[r], hipMemcpyHostToDevice, ctx->stream));
         r = e;
     }
@@ -513,7 +517,13 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     if (!ctx || !out || !out->rec || !out->cigar || !out->contig_status) return FSV_EINVAL;
     out->n_rec = 0; out->n_cigar = 0;
     if (n_contigs == 0) return FSV_OK;
-    if (!contig_seq || !contig_off || !contig_ref || !ref_seq || !ref_off) return FSV_EINVAL;
+    // contig_seq == NULL: align the contigs of the last fsv_assemble_batch on this context straight from device memory
+    const bool from_dev = contig_seq == nullptr;
+    if (from_dev) {
+        if (!ctx->last_contigs_dev || ctx->last_contig_off.size() != (size_t)n_contigs + 1) return fsv_fail(ctx, FSV_EINVAL, "no assembled contigs of that count on this context");
+        contig_off = ctx->last_contig_off.data();
+    }
+    if (!contig_off || !contig_ref || !ref_seq || !ref_off) return FSV_EINVAL;
     if (out->rec_cap < n_contigs) return fsv_fail(ctx, FSV_ECAP, "rec_cap must be >= n_contigs");
     fsv_aln_params P;
     if (params) P = *params; else fsv_aln_default_params(&P);
@@ -537,7 +547,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     }
     for (uint32_t p = 0; p < np; p++) {
         if (contig_ref[p] >= n_refs) return fsv_fail(ctx, FSV_EINVAL, "contig_ref out of range");
-        seq[n_refs + p] = contig_seq + contig_off[p]; slen[n_refs + p] = contig_off[p + 1] - contig_off[p];
+        seq[n_refs + p] = from_dev ? nullptr : contig_seq + contig_off[p]; slen[n_refs + p] = contig_off[p + 1] - contig_off[p];
         if (slen[n_refs + p] == 0) return fsv_fail(ctx, FSV_EINVAL, "empty contig");
         group_len[contig_ref[p]] = std::max(group_len[contig_ref[p]], slen[n_refs + p]);
         pair_q[p] = n_refs + p; pair_t[p] = contig_ref[p];
@@ -557,7 +567,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     auto tr0 = std::chrono::steady_clock::now();
     auto trace = [&](const char *what) { if (getenv("FSV_TRACE")) { (void)hipStreamSynchronize(ctx->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[fsv] align %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tr0).count()); tr0 = t; } };
     std::vector<uint32_t> word_off; std::vector<int32_t> len;
-    TRY(pack_pairs(ctx, W, seq, slen, word_off, len));
+    TRY(pack_pairs(ctx, W, seq, slen, word_off, len, from_dev ? ctx->last_contigs_dev + contig_off[0] : nullptr, n_refs));
     trace("pack+h2d");
     TRY(upload(ctx, W.wper, wper));
     TRY(upload(ctx, W.pair_q, pair_q));

@@ -545,6 +545,8 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     trace("layout");
     if (rc_out != FSV_OK) return rc_out;
     out->n_contigs = nc;
+    ctx->last_contigs_dev = nullptr;
+    ctx->last_contig_off.assign(out->off, out->off + nc + 1);
     if (!pieces.empty()) {
         TRY(upload(ctx, W.pieces, pieces));
         TRY(ensure(ctx, W.contig_out, used + 16));
@@ -553,6 +555,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
                            (const int32_t *)W.len.p, (const fsv_piece *)W.pieces.p, (char *)W.contig_out.p);
         FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
+        ctx->last_contigs_dev = (const char *)W.contig_out.p;
         FSV_HIP(ctx, hipMemcpyAsync(out->seq, W.contig_out.p, used, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "focalsv_hip.h"
 
 struct fsv_ctx {
@@ -16,6 +17,9 @@ struct fsv_ctx {
     std::string last_error;
     void *asm_ws = nullptr;                 // assembly workspace (asm.hip)
     void (*asm_ws_free)(fsv_ctx *) = nullptr;
+    // contigs of the last fsv_assemble_batch, still on the device (ASCII, back to back) for a device-resident hand-off to the aligner
+    const char *last_contigs_dev = nullptr;
+    std::vector<uint64_t> last_contig_off;
     void *aln_ws = nullptr;                 // alignment workspace (aln.hip)
     void (*aln_ws_free)(fsv_ctx *) = nullptr;
 };

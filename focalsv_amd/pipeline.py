@@ -89,7 +89,8 @@ def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', 
         counters[hp] += 1
         cref.append(ri)
         keep_contigs.append((ri, hp, c))
-    rec, cigar, contig_status = ctx.align_batch(contigs, cref, [r.ref for r in regions], aln_params) if contigs else (np.zeros(0, _lib.ALN_REC_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.int32))
+    # contigs=None: the aligner takes them from device memory, where the assembler left them
+    rec, cigar, contig_status = ctx.align_batch(None, cref, [r.ref for r in regions], aln_params) if contigs else (np.zeros(0, _lib.ALN_REC_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.int32))
     aln_stats = ctx.aln_stats() if contigs else {}
     records = records_from_alignment(rec, cigar, names, [regions[i].chrom for i in cref], [regions[i].start for i in cref])
     contig_seq = {n: c.decode() for n, c in zip(names, contigs)}

@@ -251,7 +251,9 @@ typedef struct fsv_alns {
     int32_t  *contig_status; /* host, n_contigs: 0 aligned, 1 no chain (unaligned), <0 FSV_E* for that contig */
 } fsv_alns;
 
-/* contig i is aligned to reference window contig_ref[i] */
+/* contig i is aligned to reference window contig_ref[i].
+ * contig_seq == NULL (contig_off ignored): align the n_contigs contigs of the last fsv_assemble_batch on this context straight
+ * from device memory, in their output order -- the device-resident hand-off between the two boundaries. */
 int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint64_t *contig_off, uint32_t n_contigs,
                     const uint32_t *contig_ref, const char *ref_seq, const uint64_t *ref_off, uint32_t n_refs,
                     const fsv_aln_params *params, fsv_alns *out);
