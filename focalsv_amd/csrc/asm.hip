@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 namespace {
 
@@ -522,17 +524,32 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     uint64_t used = 0;
     uint32_t nc = 0;
     int rc_out = FSV_OK;
+    // the sets are independent: lay them out on a few host threads, then emit the contigs in set order
+    struct SetLayout { std::vector<std::vector<Piece>> contigs; bool fallback = false; };
+    std::vector<SetLayout> lay(B.n_sets);
+    {
+        const uint32_t nthr = std::max(1u, std::min({8u, std::thread::hardware_concurrency(), B.n_sets / 16 + 1}));
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() {
+            for (uint32_t s = next.fetch_add(1); s < B.n_sets; s = next.fetch_add(1)) {
+                const uint32_t r0 = B.set_start[s], ns = B.set_start[s + 1] - r0;
+                if (ns == 0) continue;
+                const uint32_t nh_s = hit_first[s + 1] - hit_first[s];
+                layout_set(len.data() + r0, ns, hraw, nh_s ? W.hit_idx.data() + hit_first[s] : nullptr, nh_s, P.min_contig_reads, lay[s].contigs, lay[s].fallback);
+            }
+        };
+        std::vector<std::thread> thr;
+        for (uint32_t t = 1; t < nthr; t++) thr.emplace_back(work);
+        work();
+        for (auto &t : thr) t.join();
+    }
     for (uint32_t s = 0; s < B.n_sets && rc_out == FSV_OK; s++) {
         const uint32_t r0 = B.set_start[s], ns = B.set_start[s + 1] - r0;
         int32_t st = 0;
         for (uint32_t r = r0; r < r0 + ns; r++) st |= (int32_t)(hwarn[r] & 3u);
         if (ns == 0) { out->set_status[s] = st; continue; }
-        std::vector<std::vector<Piece>> contigs;
-        bool fallback = false;
-        const uint32_t nh_s = hit_first[s + 1] - hit_first[s];
-        layout_set(len.data() + r0, ns, hraw, nh_s ? W.hit_idx.data() + hit_first[s] : nullptr, nh_s, P.min_contig_reads, contigs, fallback);
-        if (fallback) st |= FSV_W_NO_LAYOUT;
-        for (auto &c : contigs) {
+        if (lay[s].fallback) st |= FSV_W_NO_LAYOUT;
+        for (auto &c : lay[s].contigs) {
             uint64_t clen = 0;
             for (auto &pc : c) clen += pc.len;
             if (nc >= out->contig_cap || used + clen > out->seq_cap) { rc_out = fsv_fail(ctx, FSV_ECAP, "contig output buffers too small (use fsv_assemble_batch_bound)"); break; }
