@@ -174,6 +174,7 @@ def main():
             "stage_ms": {k: round(v, 2) for k, v in a.items() if k.startswith("ms_")},
             "kernel_ms": {k: [round(v["ms"], 2), v["launches"]] for k, v in kern.items()},
             "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},
+            "host_ms": res.host_ms,
             "algo_bytes_per_region": int((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) / n),
             "hbm_roofline_whole_path": {"GBps": round((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) * args.steps / dt / 1e9 * 1.0, 3), "frac": round((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) * args.steps / dt / 8e12, 6)},
             "roofline": roof,

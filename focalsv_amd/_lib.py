@@ -149,6 +149,42 @@ def pack_reads(reads):
     return words, word_off, lens.astype(np.int32)
 
 
+def join_refs(refs):
+    """reference windows (list of bytes) -> (concatenated uint8 array, uint64 offsets) as fsv_align_batch takes them"""
+    roff = np.zeros(len(refs) + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in refs], out=roff[1:])
+    return np.frombuffer(b"".join(refs) + b"\0", dtype=np.uint8), roff
+
+
+class ContigBatch:
+    """The contigs of one fsv_assemble_batch call: a read-only sequence of `bytes`, cut out of the library's output buffer
+    on access (a batch is tens of MB; most callers touch a few contigs or none -- the aligner takes them from the device)."""
+
+    def __init__(self, seq: np.ndarray, off: np.ndarray):
+        self._seq, self._off = seq, off
+
+    def __len__(self):
+        return len(self._off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._seq[int(self._off[i]):int(self._off[i + 1])].tobytes()
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def length(self, i) -> int:
+        return int(self._off[i + 1] - self._off[i])
+
+
 class Context:
     """One fsv_ctx (= one GPU + one stream).  Raises FsvError(FSV_ENODEV) without an MI355X."""
 
@@ -238,8 +274,7 @@ class Context:
         self.check(self._lib.fsv_assemble_batch(self._h, C.byref(rs), C.byref(p), C.byref(out)), "fsv_assemble_batch")
         n = out.n_contigs
         self._last_contig_bytes = int(off[n])
-        contigs = [seq[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
-        return contigs, cset[:n].copy(), cnr[:n].copy(), status[:rs.n_sets].copy()
+        return ContigBatch(seq, off[: n + 1].copy()), cset[:n].copy(), cnr[:n].copy(), status[:rs.n_sets].copy()
 
     def sketch_reads(self, store_dev, word_off, read_len, w=51, k=51, hpc=1, variant=0):
         """K1 exposed: per read, its minimizers in position order -> list of structured arrays (hash, pos, rev, span)"""
@@ -279,8 +314,11 @@ class Context:
         from_dev = contigs is None   # contigs of the last assemble_batch, still on the device
         n = len(contig_ref) if from_dev else len(contigs)
         coff = np.zeros(n + 1, dtype=np.uint64)
-        roff = np.zeros(len(refs) + 1, dtype=np.uint64)
-        np.cumsum([len(r) for r in refs], out=roff[1:])
+        if isinstance(refs, tuple):   # already joined by join_refs()
+            rseq, roff = refs
+        else:
+            rseq, roff = join_refs(refs)
+        n_refs = len(roff) - 1
         if from_dev:
             cseq = None
             total = int(self._last_contig_bytes)
@@ -288,15 +326,14 @@ class Context:
             np.cumsum([len(c) for c in contigs], out=coff[1:])
             cseq = np.frombuffer(b"".join(contigs) + b"\0", dtype=np.uint8)
             total = int(coff[-1])
-        rseq = np.frombuffer(b"".join(refs) + b"\0", dtype=np.uint8)
         cref = np.ascontiguousarray(contig_ref, dtype=np.uint32)
         rec = np.zeros(max(1, n), dtype=ALN_REC_DTYPE)
         cap = total // 8 + 4096 * max(1, n)
-        cigar = np.zeros(cap, dtype=np.uint32)
+        cigar = np.empty(cap, dtype=np.uint32)
         status = np.zeros(max(1, n), dtype=np.int32)
         out = Alns(_ptr(rec).value, len(rec), 0, _ptr(cigar).value, cap, 0, _ptr(status).value)
         p = params if params is not None else self.default_aln_params()
-        self.check(self._lib.fsv_align_batch(self._h, None if from_dev else _ptr(cseq), _ptr(coff), n, _ptr(cref), _ptr(rseq), _ptr(roff), len(refs), C.byref(p),
+        self.check(self._lib.fsv_align_batch(self._h, None if from_dev else _ptr(cseq), _ptr(coff), n, _ptr(cref), _ptr(rseq), _ptr(roff), n_refs, C.byref(p),
                                              C.byref(out)), "fsv_align_batch")
         return rec[: out.n_rec].copy(), cigar[: out.n_cigar].copy(), status[:n].copy()
 

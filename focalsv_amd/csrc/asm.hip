@@ -39,7 +39,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
 
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
-        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, upair_base, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, upair_base, upair_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -52,7 +52,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &upair_base, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &upair_base, &upair_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -200,6 +200,7 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     // algorithmic bytes of the pairwise join: every unordered pair reads both unique-minimizer lists (16 B each) and writes two
     // overlap slots; the window tasks it emits are added once their number is known
     uint64_t chain_bytes = (uint64_t)B.n_pairs * sizeof(fsv_ovl);
+    uint32_t max_cnt = 0;
     {
         std::vector<uint32_t> cnt(B.n_reads);
         FSV_HIP(ctx, hipMemcpyAsync(cnt.data(), W.mz_cnt.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -207,12 +208,15 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
         for (uint32_t s2 = 0; s2 < B.n_sets; s2++) {
             const uint64_t ns = B.set_start[s2 + 1] - B.set_start[s2];
             uint64_t tot = 0;
-            for (uint32_t r = B.set_start[s2]; r < B.set_start[s2 + 1]; r++) tot += cnt[r];
+            for (uint32_t r = B.set_start[s2]; r < B.set_start[s2 + 1]; r++) { tot += cnt[r]; if (ns > 1) max_cnt = std::max(max_cnt, cnt[r]); }
             if (ns > 1) chain_bytes += (ns - 1) * tot * sizeof(fsv_mz); // every unordered pair reads both lists once
         }
     }
+    // LDS per pair = 24 B x the longest minimizer list of the batch (rounded up to 64, at most FSV_AMAX): more pairs per CU
+    A.upair_tab = (const uint4 *)W.upair_tab.p;
+    A.amax = (int32_t)std::min<uint32_t>(FSV_AMAX, std::max<uint32_t>(64u, (max_cnt + 63u) / 64u * 64u));
     W.kt.begin(ctx, KN_CHAIN, chain_bytes);
-    hipLaunchKernelGGL(k_chain, dim3(B.n_upairs), dim3(64), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_chain, dim3(B.n_upairs), dim3(64), (size_t)A.amax * 24, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
     W.stats.ms_chain += tc.stop();
@@ -347,6 +351,12 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     TRY(upload(ctx, W.read_set, B.read_set));
     TRY(upload(ctx, W.pair_base, B.pair_base));
     TRY(upload(ctx, W.upair_base, B.upair_base));
+    if (B.n_upairs) {
+        TRY(ensure(ctx, W.upair_tab, (size_t)B.n_upairs * sizeof(uint4)));
+        hipLaunchKernelGGL(k_pair_tab, dim3((B.n_upairs + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)W.set_start.p,
+                           (const uint32_t *)W.pair_base.p, (const uint32_t *)W.upair_base.p, B.n_sets, B.n_upairs, (uint4 *)W.upair_tab.p);
+        FSV_HIP(ctx, hipGetLastError());
+    }
     TRY(ensure(ctx, W.warn, (size_t)B.n_reads * 4));
     FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)B.n_reads * 4, ctx->stream));
 

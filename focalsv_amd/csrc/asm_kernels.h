@@ -326,6 +326,8 @@ struct ChainArgs {
     const uint32_t *set_start;   // n_sets + 1
     const uint32_t *pair_base;   // n_sets + 1: ordered-pair slots
     const uint32_t *upair_base;  // n_sets + 1: unordered pairs (one block each)
+    const uint4 *upair_tab;      // per unordered pair: {first read of the set, q | t << 16, slot (q,t), slot (t,q)}  (k_pair_tab)
+    int32_t amax;                // anchors per pair held in LDS (multiple of 64, <= FSV_AMAX): sizes the dynamic LDS
     const fsv_mz *mz;
     const uint32_t *mz_off;
     const uint32_t *mz_cnt;
@@ -340,30 +342,41 @@ struct ChainArgs {
     int32_t k_score, min_anchors, min_ovlp, bw, emit_tasks;
 };
 
-// One wavefront per ordered read pair (q, t) of a set.
-__global__ __launch_bounds__(64) void k_chain(ChainArgs A)
+// The unordered pairs of every set, enumerated once per batch: block b of k_chain reads one 16-byte record instead of
+// searching the set table and inverting the triangular index (a dozen dependent global loads per block).
+__global__ void k_pair_tab(const uint32_t *__restrict__ set_start, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ upair_base,
+                           uint32_t n_sets, uint32_t n_upairs, uint4 *__restrict__ tab)
 {
-    __shared__ uint64_t s_key[FSV_AMAX];  // qe << 32 | te   (raw te first, strand-corrected later)
-    __shared__ uint16_t s_aux[FSV_AMAX];  // t span | strand << 8 ; later: predecessor index
-    __shared__ __attribute__((aligned(8))) int32_t s_dp[3 * FSV_AMAX]; // s_f | s_ind | s_sl ; the first two double as the staged t hashes
-    int32_t *const s_f = s_dp, *const s_ind = s_dp + FSV_AMAX, *const s_sl = s_dp + 2 * FSV_AMAX;
-    __shared__ uint16_t s_chain[FSV_AMAX];
-    const int lane = threadIdx.x;
-    // One block per UNORDERED pair (q < t) of a set: the chain is computed with q as the query and the overlap of t on q is
-    // its mirror image (oracle/asm.c collect_overlaps); both ordered slots and both window-task lists are written here.
-    const uint32_t up = blockIdx.x;
-    uint32_t lo = 0, hi = A.n_sets;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (A.upair_base[mid] <= up) lo = mid; else hi = mid; }
-    const uint32_t s = lo, r0 = A.set_start[s], ns = A.set_start[s + 1] - r0;
-    const uint32_t idx = up - A.upair_base[s];
+    const uint32_t up = blockIdx.x * blockDim.x + threadIdx.x;
+    if (up >= n_upairs) return;
+    uint32_t lo = 0, hi = n_sets;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (upair_base[mid] <= up) lo = mid; else hi = mid; }
+    const uint32_t s = lo, r0 = set_start[s], ns = set_start[s + 1] - r0;
+    const uint32_t idx = up - upair_base[s];
     // row q holds the pairs (q, q+1..ns-1): rows start at q*(2ns-q-1)/2
     uint32_t q = (uint32_t)((2.0 * ns - 1.0 - sqrt((2.0 * ns - 1.0) * (2.0 * ns - 1.0) - 8.0 * (double)idx)) * 0.5);
     while (q > 0 && (uint64_t)q * (2ull * ns - q - 1) / 2 > idx) q--;
     while ((uint64_t)(q + 1) * (2ull * ns - q - 2) / 2 <= idx) q++;
     const uint32_t t = q + 1 + (idx - (uint32_t)((uint64_t)q * (2ull * ns - q - 1) / 2));
-    const uint32_t p = A.pair_base[s] + q * (ns - 1) + (t - 1);   // ordered slot (q, t), t > q
-    const uint32_t pm = A.pair_base[s] + t * (ns - 1) + q;        // ordered slot (t, q), q < t
-    const uint32_t rq = r0 + q, rt = r0 + t;
+    tab[up] = make_uint4(r0, q | t << 16, pair_base[s] + q * (ns - 1) + (t - 1), pair_base[s] + t * (ns - 1) + q);
+}
+
+// One wavefront per UNORDERED read pair (q < t) of a set: the chain is computed with q as the query and the overlap of t on
+// q is its mirror image (oracle/asm.c collect_overlaps); both ordered slots and both window-task lists are written here.
+__global__ __launch_bounds__(64) void k_chain(ChainArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int AMAX = A.amax;
+    uint64_t *const s_key = (uint64_t *)s_raw;                      // qe << 32 | te   (raw te first, strand-corrected later)
+    int32_t *const s_dp = (int32_t *)(s_raw + 8 * (size_t)AMAX);    // s_f | s_ind | s_sl ; doubles as the staged t records
+    uint16_t *const s_aux = (uint16_t *)(s_raw + 20 * (size_t)AMAX); // t span | strand << 8 ; later: predecessor index
+    uint16_t *const s_chain = (uint16_t *)(s_raw + 22 * (size_t)AMAX);
+    int32_t *const s_f = s_dp, *const s_ind = s_dp + AMAX, *const s_sl = s_dp + 2 * AMAX;
+    const int lane = threadIdx.x;
+    const uint4 pt = A.upair_tab[blockIdx.x];
+    const uint32_t q = pt.y & 0xffffu, t = pt.y >> 16;
+    const uint32_t p = pt.z, pm = pt.w;     // ordered slots (q, t) and (t, q)
+    const uint32_t rq = pt.x + q, rt = pt.x + t;
     const int lenq = A.read_len[rq], lent = A.read_len[rt];
     const int nq = (int)A.mz_cnt[rq], nt = (int)A.mz_cnt[rt];
     const fsv_mz *mq = A.mz + A.mz_off[rq] + nq, *mt = A.mz + A.mz_off[rt]; // q: position-sorted copy, t: hash-sorted
@@ -374,34 +387,62 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     om.q = t; om.t = q;
 #define PUT_BOTH() do { if (lane == 0) { A.ovl[p] = o; A.ovl[pm] = om; } } while (0)
 
-    // 1. anchors: every q minimizer is looked up in t's sorted unique list; t's hashes are staged in LDS (s_f/s_ind are
-    //    free until the DP) so that the ~10 probes per lookup are LDS reads instead of dependent global loads
+    // 1. anchors: every q minimizer is looked up in t's sorted unique list.  All global loads are issued up front -- t's
+    //    records go to LDS (hash 8 B + {pos, span, strand} 4 B: s_dp is free until the DP), q's records to registers (16 B
+    //    per lane per 64 minimizers) -- so a pair pays one memory latency instead of two per batch of 64 lookups; the ~10
+    //    probes of a lookup are LDS reads.
     uint64_t *s_th = (uint64_t *)s_dp;
-    const bool t_in_lds = nt <= FSV_AMAX;
-    if (t_in_lds) for (int i = lane; i < nt; i += 64) s_th[i] = mt[i].hash;
+    uint32_t *s_tp = (uint32_t *)(s_dp + 2 * AMAX);
+    const bool t_in_lds = nt <= AMAX && lent < (1 << 23);
+    const uint4 *mq4 = (const uint4 *)mq, *mt4 = (const uint4 *)mt;
+    constexpr int QR = FSV_AMAX / 64;   // AMAX <= FSV_AMAX
+    uint4 qa[QR];
+    const bool q_in_regs = nq <= AMAX;
+    if (q_in_regs) {
+#pragma unroll
+        for (int u = 0; u < QR; u++) { const int i = u * 64 + lane; qa[u] = i < nq ? mq4[i] : make_uint4(0, 0, 0, 0); }
+    }
+    if (t_in_lds)
+        for (int i = lane; i < nt; i += 64) {
+            const uint4 b = mt4[i];
+            s_th[i] = (uint64_t)b.x | (uint64_t)b.y << 32;
+            s_tp[i] = b.z | (b.w & 0xffu) << 31 | ((b.w >> 8) & 0xffu) << 23; // pos < 2^23 | span << 23 | strand << 31
+        }
     __syncthreads();
     int n = 0, nrev = 0, nfwd = 0;
-    for (int base = 0; base < nq; base += 64) {
-        int i = base + lane;
+    auto lookup = [&](int i, const uint4 av) {
         bool hit = false; uint64_t key = 0; uint16_t aux = 0;
         if (i < nq) {
-            fsv_mz a = mq[i];
+            const uint64_t ah = (uint64_t)av.x | (uint64_t)av.y << 32;
+            const uint32_t arev = av.w & 0xffu;
             int l2 = 0, h2 = nt;
-            if (t_in_lds) { while (l2 < h2) { int mid = (l2 + h2) >> 1; if (s_th[mid] < a.hash) l2 = mid + 1; else h2 = mid; } }
-            else { while (l2 < h2) { int mid = (l2 + h2) >> 1; if (mt[mid].hash < a.hash) l2 = mid + 1; else h2 = mid; } }
-            if (l2 < nt && (t_in_lds ? s_th[l2] : mt[l2].hash) == a.hash) {
-                fsv_mz b = mt[l2];
-                hit = true; key = (uint64_t)a.pos << 32 | b.pos; aux = (uint16_t)(b.span | ((a.rev ^ b.rev) << 8));
+            if (t_in_lds) {
+                while (l2 < h2) { int mid = (l2 + h2) >> 1; if (s_th[mid] < ah) l2 = mid + 1; else h2 = mid; }
+                if (l2 < nt && s_th[l2] == ah) {
+                    const uint32_t tp = s_tp[l2];
+                    hit = true; key = (uint64_t)av.z << 32 | (tp & 0x7fffffu); aux = (uint16_t)(((tp >> 23) & 0xffu) | ((arev ^ (tp >> 31)) << 8));
+                }
+            } else {
+                while (l2 < h2) { int mid = (l2 + h2) >> 1; if (mt[mid].hash < ah) l2 = mid + 1; else h2 = mid; }
+                if (l2 < nt && mt[l2].hash == ah) {
+                    fsv_mz b = mt[l2];
+                    hit = true; key = (uint64_t)av.z << 32 | b.pos; aux = (uint16_t)(b.span | ((arev ^ b.rev) << 8));
+                }
             }
         }
         uint64_t m = __ballot(hit);
         int at = n + __popcll(m & ((1ull << lane) - 1));
-        if (hit && at < FSV_AMAX) { s_key[at] = key; s_aux[at] = aux; }
+        if (hit && at < AMAX) { s_key[at] = key; s_aux[at] = aux; }
         nrev += __popcll(__ballot(hit && (aux >> 8)));
         nfwd += __popcll(__ballot(hit && !(aux >> 8)));
         n += __popcll(m);
-    }
-    if (n > FSV_AMAX) { if (lane == 0) atomicOr(&A.warn[rq], (uint32_t)FSV_W_ANCHOR_TRUNC); n = FSV_AMAX; }
+    };
+    if (q_in_regs) {
+#pragma unroll
+        for (int u = 0; u < QR; u++) { if (u * 64 < nq) lookup(u * 64 + lane, qa[u]); }
+    } else
+        for (int base = 0; base < nq; base += 64) { const int i = base + lane; lookup(i, i < nq ? mq4[i] : make_uint4(0, 0, 0, 0)); }
+    if (n > AMAX) { if (lane == 0) atomicOr(&A.warn[rq], (uint32_t)FSV_W_ANCHOR_TRUNC); n = AMAX; }
     __syncthreads();
     // 2. majority strand, strand-corrected te, compaction
     const int rev = nrev > nfwd;
@@ -487,10 +528,33 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     for (int i = lane; i < n; i += 64) { long long v = (long long)s_f[i] * 4096 + (4095 - i); bk = v > bk ? v : bk; }
     bk = wave_max_i64(bk);
     const int best = 4095 - (int)(bk & 4095);
-    // 6. walk back (lane 0), chain stored end-to-start in s_chain
+    // 6. walk back, chain stored end-to-start in s_chain.  A step-by-step walk is ~n dependent LDS reads; instead every
+    //    anchor learns the start of its run of "predecessor == previous anchor" links (a max-scan; s_ind is free after the
+    //    DP) and the walk copies whole runs, one dependent step per break in the chain.
     int cnt = 0;
-    if (lane == 0) { int c = best; while (c != 0xffff) { s_chain[cnt++] = (uint16_t)c; c = s_aux[c]; } }
-    cnt = __shfl(cnt, 0, 64);
+    if (colinear) {
+        for (int e = lane; e <= best; e += 64) s_chain[e] = (uint16_t)(best - e);
+        cnt = best + 1;
+    } else {
+        int carry = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            int v = (i < n && i > 0 && s_aux[i] == (uint16_t)(i - 1)) ? -1 : i; // run start candidate
+            if (i >= n) v = -1;
+            for (int off = 1; off < 64; off <<= 1) { const int o2 = __shfl_up(v, off, 64); if (lane >= off) v = max(v, o2); }
+            v = max(v, carry);
+            if (i < n) s_ind[i] = v;
+            carry = __shfl(v, 63, 64);
+        }
+        __syncthreads();
+        int c = best;
+        while (c != 0xffff) {
+            const int r = s_ind[c];
+            for (int e = lane; e <= c - r; e += 64) s_chain[cnt + e] = (uint16_t)(c - e);
+            cnt += c - r + 1;
+            c = s_aux[r];
+        }
+    }
     __syncthreads();
     if (cnt < A.min_anchors) { PUT_BOTH(); return; }
     const int first = s_chain[cnt - 1];

@@ -7,6 +7,7 @@ Region-level data parallelism: `shard_regions` deals regions to ranks largest-fi
 collective while computing); `gather_vcf` is the one exchange step -- the analogue of `cat chr*/...vcf | vcf-sort`
 (focalsv/focalsv.py:66-70) -- an all-gather of per-rank VCF bytes (RCCL on GPUs, gloo in the CPU tests).
 """
+import threading
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -38,6 +39,7 @@ class DeviceBatch:
     regions: List[RegionInput]
     packed: PackedBatch
     store_dev: int
+    refs: tuple = None               # reference windows joined for fsv_align_batch (_lib.join_refs)
 
     def free(self, ctx):
         if self.store_dev:
@@ -50,11 +52,36 @@ class CallResult:
     header: List[str]
     lines: List[str]                 # final VCF body (after FP filter and redundancy removal)
     raw_lines: List[str]
-    contigs: List[Tuple[int, int, bytes]]   # (region, hp, sequence)
+    contig_batch: Sequence[bytes]           # contig sequences, cut out of the batch buffer on access
+    contig_region: List[int]
+    contig_hp: List[int]
     set_status: np.ndarray
     contig_status: np.ndarray
     asm_stats: Dict
     aln_stats: Dict
+    host_ms: Dict = field(default_factory=dict)   # wall time of the host-side stages of this call
+
+    @property
+    def contigs(self) -> List[Tuple[int, int, bytes]]:
+        """(region, hp, sequence) per contig"""
+        return [(ri, hp, self.contig_batch[i]) for i, (ri, hp) in enumerate(zip(self.contig_region, self.contig_hp))]
+
+
+class _ContigText:
+    """contig name -> sequence text for vcf.allele_sequence, decoded on first use (only contigs carrying an INS are touched)"""
+
+    def __init__(self, names, batch):
+        self._idx = {n: i for i, n in enumerate(names)}
+        self._batch, self._cache = batch, {}
+
+    def __contains__(self, name):
+        return name in self._idx
+
+    def __getitem__(self, name):
+        s = self._cache.get(name)
+        if s is None:
+            s = self._cache[name] = self._batch[self._idx[name]].decode()
+        return s
 
 
 def region_from_synth(r, flank_start: int = 0) -> RegionInput:
@@ -74,44 +101,80 @@ def upload_regions(ctx: _lib.Context, regions: Sequence[RegionInput]) -> DeviceB
         sets.append(r.reads_hp1)
         sets.append(r.reads_hp2)
     packed = pack_sets(sets)
-    return DeviceBatch(list(regions), packed, ctx.upload(packed.words))
+    return DeviceBatch(list(regions), packed, ctx.upload(packed.words), _lib.join_refs([r.ref for r in regions]))
 
 
 def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> CallResult:
     regions, pk = batch.regions, batch.packed
+    chroms = sorted({r.chrom for r in regions}, key=lambda c: (len(c), c))
+    # the read-side evidence (reads_signature) does not depend on the contigs: a host thread extracts it while the GPU
+    # assembles (the ctypes call releases the GIL)
+    read_sigs: Dict[str, dict] = {}
+    refs: Dict[str, WindowedRef] = {}
+    side_err: List[BaseException] = []
+
+    def _read_side():
+        try:
+            for chrom in chroms:
+                ref = WindowedRef()
+                ref.wins = sorted((r.start, r.ref.decode()) for r in regions if r.chrom == chrom)
+                ref._starts = [w[0] for w in ref.wins]
+                refs[chrom] = ref
+            for chrom in chroms:
+                rr = [rec for r in regions if r.chrom == chrom for rec in r.read_records]
+                read_sigs[chrom] = reads_signature.reads_signatures(rr, 50)
+        except BaseException as e:   # re-raised on the calling thread
+            side_err.append(e)
+
+    side = threading.Thread(target=_read_side, name="fsv-read-signatures")
+    side.start()
+    try:
+        return _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err)
+    finally:
+        side.join()
+
+
+def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err) -> CallResult:
+    import time
+    host_ms, t_prev = {}, [time.perf_counter()]
+
+    def lap(name):
+        t = time.perf_counter()
+        host_ms[name] = round((t - t_prev[0]) * 1e3, 2)
+        t_prev[0] = t
+
     contigs, cset, cnr, set_status = ctx.assemble_batch(batch.store_dev, pk.word_off, pk.read_len, pk.set_start, asm_params)
+    lap("assemble_call")
     asm_stats = ctx.asm_stats()
     # reformat_fasta (DipPAV_variant_call.py:14-23): contigs are numbered per haplotype across the whole call
-    names, cref, keep_contigs, counters = [], [], [], {1: 0, 2: 0}
-    for c, s in zip(contigs, cset):
+    names, cref, chp, counters = [], [], [], {1: 0, 2: 0}
+    for s in cset:
         ri, hp = int(s) // 2, int(s) % 2 + 1
         names.append("contig_hp%d_%d" % (hp, counters[hp]))
         counters[hp] += 1
         cref.append(ri)
-        keep_contigs.append((ri, hp, c))
+        chp.append(hp)
     # contigs=None: the aligner takes them from device memory, where the assembler left them
-    rec, cigar, contig_status = ctx.align_batch(None, cref, [r.ref for r in regions], aln_params) if contigs else (np.zeros(0, _lib.ALN_REC_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.int32))
-    aln_stats = ctx.aln_stats() if contigs else {}
+    rec, cigar, contig_status = ctx.align_batch(None, cref, batch.refs or [r.ref for r in regions], aln_params) if len(contigs) else (np.zeros(0, _lib.ALN_REC_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.int32))
+    aln_stats = ctx.aln_stats() if len(contigs) else {}
+    lap("align_call")
     records = records_from_alignment(rec, cigar, names, [regions[i].chrom for i in cref], [regions[i].start for i in cref])
-    contig_seq = {n: c.decode() for n, c in zip(names, contigs)}
+    contig_seq = _ContigText(names, contigs)
     raw, final = [], []
-    chroms = sorted({r.chrom for r in regions}, key=lambda c: (len(c), c))
-    read_sigs = {}
+    lap("records")
+    side.join()
+    lap("wait_read_side")
+    if side_err:
+        raise side_err[0]
     for chrom in chroms:
-        ref = WindowedRef()
-        rr = []
-        for r in regions:
-            if r.chrom == chrom:
-                ref.wins.append((r.start, r.ref.decode()))
-                rr += r.read_records
-        ref.wins.sort()
-        ref._starts = [w[0] for w in ref.wins]
-        paired, body = call_chromosome(records, chrom, ref, contig_seq, data_type)
+        paired, body = call_chromosome(records, chrom, refs[chrom], contig_seq, data_type)
         raw += body
-        read_sigs[chrom] = reads_signature.reads_signatures(rr, 50)
+    lap("signatures_vcf")
     kept = fp_filter.filter_lines(vcf.HEADER_LINES, raw, read_sigs)
+    lap("fp_filter")
     header, final, dropped = redundancy.collapse(vcf.HEADER_LINES, kept)
-    return CallResult(header, final, raw, keep_contigs, set_status, contig_status, asm_stats, aln_stats)
+    lap("redundancy")
+    return CallResult(header, final, raw, contigs, cref, chp, set_status, contig_status, asm_stats, aln_stats, host_ms)
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU
