@@ -497,8 +497,8 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         TRY(ensure(ctx, W.hits, (size_t)B.n_pairs * sizeof(fsv_ovl)));
         FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.counters.p + 3, 0, 4, ctx->stream));
         W.kt.begin(ctx, KN_EXACT, (uint64_t)B.n_pairs * sizeof(fsv_ovl) + W.stats.n_pairs * 0);
-        hipLaunchKernelGGL(k_exact, dim3(B.n_pairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
-                           (const uint32_t *)W.set_start.p, (const uint32_t *)W.pair_base.p, B.n_sets, (fsv_ovl *)W.ovl.p, (fsv_ovl *)W.hits.p,
+        hipLaunchKernelGGL(k_exact, dim3(B.n_upairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
+                           (const uint32_t *)W.read_set.p, (const uint4 *)W.upair_tab.p, (const fsv_ovl *)W.ovl.p, (fsv_ovl *)W.hits.p,
                            (uint32_t *)W.counters.p + 3);
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);

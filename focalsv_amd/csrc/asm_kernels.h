@@ -1115,40 +1115,48 @@ __global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwi
 }
 
 // ------------------------------------------------------------------------------------------------ k_exact
-// if_exact_match (Assembly.cpp:894-974): the two overlap intervals must be the same string.  One wavefront per overlap slot.
+// if_exact_match (Assembly.cpp:894-974): the two overlap intervals must be the same string.  One wavefront per unordered
+// pair: the overlap of t on q covers the same bases as the overlap of q on t, so one comparison decides both slots.
+// The comparison issues four 16-base fetches per lane before it looks at any of them (the early exit costs a memory
+// round trip per test, and most valid overlaps of the final pass are exact).
 __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
-                                              const int32_t *__restrict__ read_len, const uint32_t *__restrict__ set_start,
-                                              const uint32_t *__restrict__ pair_base, uint32_t n_sets, fsv_ovl *__restrict__ ovl,
+                                              const int32_t *__restrict__ read_len, const uint32_t *__restrict__ read_set,
+                                              const uint4 *__restrict__ upair_tab, const fsv_ovl *__restrict__ ovl,
                                               fsv_ovl *__restrict__ hits, uint32_t *__restrict__ n_hits)
 {
-    const uint32_t p = blockIdx.x;
+    const uint4 pt = upair_tab[blockIdx.x];
     const int lane = threadIdx.x;
-    fsv_ovl o = ovl[p];
+    fsv_ovl o = ovl[pt.z];
     if (!o.valid) return;
-    uint32_t lo = 0, hi = n_sets;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (pair_base[mid] <= p) lo = mid; else hi = mid; }
-    const uint32_t r0 = set_start[lo];
-    const uint32_t rq = r0 + o.q, rt = r0 + o.t;
+    const uint32_t rq = pt.x + o.q, rt = pt.x + o.t;
     const int L = o.x_e - o.x_s + 1;
     bool same = (L == o.y_e - o.y_s + 1);
     if (same) {
         const uint32_t xw = word_off[rq], yw = word_off[rt];
         const int ylen = read_len[rt];
-        // 16 bases per lane and trip: XOR of two fetched words
-        bool diff = false;
-        for (int i = lane * 16; i < L && !diff; i += 64 * 16) {
-            const uint32_t xb = fetch16_x(store, xw, o.x_s + i);
-            const Bases16 yb = fetch16(store, yw, ylen, o.rev, o.y_s + i);
-            uint32_t d = xb ^ yb.bits;
-            const int lim = min(16, L - i);
-            if (lim < 16) d &= (1u << (2 * lim)) - 1u;
-            diff = d != 0u;
+        uint32_t acc = 0;
+        for (int i0 = lane * 16; i0 < L; i0 += 4 * 64 * 16) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 64 * 16;
+                if (i < L) {
+                    const uint32_t xb = fetch16_x(store, xw, o.x_s + i);
+                    const Bases16 yb = fetch16(store, yw, ylen, o.rev, o.y_s + i);
+                    uint32_t d = xb ^ yb.bits;
+                    const int lim = min(16, L - i);
+                    if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+                    acc |= d;
+                }
+            }
+            if (__any(acc != 0u)) break;
         }
-        same = !__any(diff);
+        same = !__any(acc != 0u);
     }
-    if (lane == 0 && same) {
+    if (lane < 2 && same) {
         // exact hits are gathered for the host layout (a few per cent of the slots); the record carries its set and slot
-        o.exact = 1; o.first_win = (int32_t)lo; o.chain_off = (int32_t)p;
+        const uint32_t slot = lane ? pt.w : pt.z;
+        if (lane) o = ovl[slot];
+        o.exact = 1; o.first_win = (int32_t)read_set[pt.x]; o.chain_off = (int32_t)slot;
         hits[atomicAdd(n_hits, 1u)] = o;
     }
 }
@@ -1190,6 +1198,7 @@ namespace {
 //            shorter than one window (only the last minimum) are handled explicitly.
 // Equivalent to the monotone-deque replay in k_sketch (which stays for even k); both are checked against the oracle.
 #define SKF_T 1024
+#define SKF_V ((SKF_T + 2 * 256 + 255) / 256)   // elements of the doubling passes per thread
 __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                                      const int32_t *__restrict__ read_len, const uint32_t *__restrict__ mz_off,
                                                      fsv_mz *__restrict__ mz, uint32_t *__restrict__ mz_cnt, uint32_t n_reads, int w, int k,
@@ -1197,8 +1206,8 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
                                                      uint32_t *__restrict__ sc_ends, uint32_t *__restrict__ sc_low, uint32_t *__restrict__ sc_high)
 {
     __shared__ uint64_t s_h[SKF_T + 2 * 256];   // w <= 255
-    __shared__ uint64_t s_wmin[SKF_T + 256];
-    __shared__ uint32_t s_scan[256];
+    __shared__ uint64_t s_wmin[SKF_T + 2 * 256];
+    __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_carry;
     __shared__ uint64_t s_am, s_ah;   // start anomaly: minimum of the partial window, hash of entry T0
     __shared__ int s_abest, s_short;  // its rightmost position; the single minimizer of a read shorter than one window
@@ -1231,23 +1240,22 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
                 const uint32_t shifted = (word >> 2) | (nextb << 30);
                 uint32_t d = word ^ shifted;
                 d = (d | (d >> 1)) & 0x55555555u; // field j non-zero <=> base j != base j+1
-                for (int j = 0; j < nb; j++) {
-                    const bool last = (wi * 16 + j == len - 1);
-                    if (last || ((d >> (2 * j)) & 1u) || (j == 15 && nextb == 4u)) flags |= 1u << j;
-                }
+                // even bits -> 16-bit mask; the read's last base always ends a run
+                d = (d | (d >> 1)) & 0x33333333u; d = (d | (d >> 2)) & 0x0f0f0f0fu; d = (d | (d >> 4)) & 0x00ff00ffu; d = (d | (d >> 8)) & 0xffffu;
+                flags = nb >= 16 ? d : (d & ((1u << nb) - 1u));
+                if (len - 1 - wi * 16 < 16) flags |= 1u << (len - 1 - wi * 16);
             } else flags = nb >= 16 ? 0xffffu : ((1u << nb) - 1u);
         }
         const uint32_t cnt = __popc(flags);
-        s_scan[tid] = cnt;
+        // exclusive scan over the 256 threads: shuffle scan inside each wave, the four wave totals through LDS
+        uint32_t incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o2 = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += o2; }
+        if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
         __syncthreads();
-        // exclusive scan over the 256 threads (Hillis-Steele in LDS)
-        for (int off = 1; off < 256; off <<= 1) {
-            uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t incl = s_scan[tid], base = s_carry + incl - cnt;
+        uint32_t wave_before = 0, tile_total = 0;
+#pragma unroll
+        for (int wv = 0; wv < 4; wv++) { const uint32_t v = s_scan[wv]; if (wv < (tid >> 6)) wave_before += v; tile_total += v; }
+        const uint32_t base = s_carry + wave_before + incl - cnt;
         if (cnt) {
             uint32_t lo = 0, hi = 0, rank = 0;
             for (int j = 0; j < nb; j++)
@@ -1262,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
             if (sh + cnt > 32) { atomicOr(&low[wd + 1], lo >> (32 - sh)); atomicOr(&high[wd + 1], hi >> (32 - sh)); }
         }
         __syncthreads();
-        if (tid == 255) s_carry += incl;
+        if (tid == 0) s_carry += tile_total;
         __syncthreads();
     }
     const int M = (int)s_carry; // entries
@@ -1301,11 +1309,31 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
         const int e0 = t0 - (w - 1); // entry held by s_h[0]
         for (int idx = tid; idx < SKF_T + 2 * (w - 1); idx += 256) s_h[idx] = entry_hash(e0 + idx, nullptr);
         __syncthreads();
-        // window minima: s_wmin[i] = min over entries (t0+i)-(w-1) .. (t0+i)
-        for (int i = tid; i < SKF_T + (w - 1); i += 256) {
-            uint64_t m = NONE;
-            for (int j = 0; j < w; j++) m = min(m, s_h[i + j]);
-            s_wmin[i] = m;
+        // window minima: s_wmin[i] = min over entries (t0+i)-(w-1) .. (t0+i) = min(s_h[i .. i+w-1]), by doubling: after the
+        // pass with distance d an element covers 2d entries; two overlapping power-of-two ranges make the window of w
+        const int NW = SKF_T + 2 * (w - 1);
+        int p2 = 1;
+        while (p2 * 2 <= w) p2 <<= 1;
+        auto pass = [&](const uint64_t *src, int d, bool is_max) {   // s_wmin[i] = op(src[i], src[i+d]) for every i < NW
+            uint64_t v[SKF_V];
+#pragma unroll
+            for (int c = 0; c < SKF_V; c++) {
+                const int i = tid + 256 * c;
+                if (i < NW) {
+                    const uint64_t a = src[i], b = i + d < NW ? src[i + d] : (is_max ? 0ull : NONE);
+                    v[c] = is_max ? max(a, b) : min(a, b);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < SKF_V; c++) { const int i = tid + 256 * c; if (i < NW) s_wmin[i] = v[c]; }
+            __syncthreads();
+        };
+        if (w == 1) pass(s_h, 0, false);
+        else {
+            pass(s_h, 1, false);
+            for (int d = 2; d < p2; d <<= 1) pass(s_wmin, d, false);
+            if (w > p2) pass(s_wmin, w - p2, false);
         }
         if (t0 == 0 && tid == 0) {
             s_short = -1; s_abest = -1; s_am = NONE; s_ah = NONE;
@@ -1320,6 +1348,23 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
             }
         }
         __syncthreads();
+        // an entry is reported iff it equals the minimum of one of the windows that contain it and end in [T0, M-1]; every such
+        // minimum is <= the entry's hash, so the test is "sliding maximum of the (masked) window minima == hash", doubled the same way
+        if (M > T0) {
+            {
+                // in place: every thread rewrites its own elements
+#pragma unroll
+                for (int c = 0; c < SKF_V; c++) {
+                    const int i = tid + 256 * c, t = t0 + i;
+                    if (i < NW && !(t >= T0 && t <= M - 1 && i < SKF_T + w - 1)) s_wmin[i] = 0ull;
+                }
+                __syncthreads();
+            }
+            if (w > 1) {
+                for (int d = 1; d < p2; d <<= 1) pass(s_wmin, d, true);
+                if (w > p2) pass(s_wmin, w - p2, true);
+            }
+        }
         for (int pi = tid; pi < SKF_T; pi += 256) {
             const int p = t0 + pi;
             if (p >= M) break;
@@ -1328,9 +1373,7 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
             bool e;
             if (M <= T0) e = (p == s_short);
             else {
-                e = false;
-                const int lo = max(p, T0), hi = min(p + w - 1, M - 1);
-                for (int t = lo; t <= hi && !e; t++) e = (s_wmin[t - t0] == hp);
+                e = (p + w - 1 >= T0) && s_wmin[pi] == hp;
                 if (p >= T0 - w + 1 && p <= T0 - 1 && s_am != NONE && hp == s_am) e = (p != s_abest) ? true : (s_ah > s_am);
             }
             if (e) emit(p);
