@@ -39,7 +39,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
 
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
-        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, upair_base, upair_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, upair_base, upair_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -48,11 +48,10 @@ struct AsmWs {
     fsv_asm_stats stats;
     KTimes kt;
     void *h_pin = nullptr; size_t h_pin_cap = 0; // pinned host staging (exact hits)
-    std::vector<uint32_t> hit_idx;
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &upair_base, &upair_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &upair_base, &upair_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -182,9 +181,20 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
         FSV_HIP(ctx, hipGetLastError());
     }
     W.kt.end(ctx);
+    // the sort in k_uniq holds a read's minimizers in LDS: size it to the longest list of the batch (16 B per entry), so that
+    // short-read batches keep many reads per CU
+    std::vector<uint32_t> cnt(B.n_reads);
+    FSV_HIP(ctx, hipMemcpyAsync(cnt.data(), W.mz_cnt.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t max_raw = 0;
+    for (uint32_t r = 0; r < B.n_reads; r++) max_raw = std::max(max_raw, cnt[r]);
     W.kt.begin(ctx, KN_UNIQ, (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz) * 2);
-    hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
-                       (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p);
+    if (max_raw <= 1024)
+        hipLaunchKernelGGL(k_uniq<1024>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
+                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p);
+    else
+        hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
+                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
     W.stats.ms_sketch += ts.stop();
@@ -202,7 +212,6 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     uint64_t chain_bytes = (uint64_t)B.n_pairs * sizeof(fsv_ovl);
     uint32_t max_cnt = 0;
     {
-        std::vector<uint32_t> cnt(B.n_reads);
         FSV_HIP(ctx, hipMemcpyAsync(cnt.data(), W.mz_cnt.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (uint32_t s2 = 0; s2 < B.n_sets; s2++) {
@@ -228,22 +237,21 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
 // arc (q,+) -> (t,rev); its complement is (t,!rev) -> (q,-).  Mirrors ma_hit_contained / ma_hit2arc / asg_arc_del_trans
 // on error-free linear data (Overlaps.cpp:1198, 2152, 4531; Overlaps.h:178-246) and ma_ug_seq for the sequence.
 struct Piece { uint32_t read, rev, len; };
-void layout_set(const int32_t *len, uint32_t n, const fsv_ovl *hits, const uint32_t *idx, uint32_t n_hit, int min_reads,
+void layout_set(const int32_t *len, uint32_t n, const fsv_hit *hits, uint32_t n_hit, int min_reads,
                 std::vector<std::vector<Piece>> &contigs, bool &fallback)
 {
     std::vector<uint8_t> contained(n, 0), used(n, 0);
     std::vector<int32_t> succ(2 * n, -1), sovl(2 * n, 0), pred(2 * n, -1);
     fallback = false;
     for (uint32_t i = 0; i < n_hit; i++) {
-        const fsv_ovl &h = hits[idx[i]];
-        if (!h.valid || !h.exact) continue;
+        const fsv_hit &h = hits[i];
         bool qfull = h.x_s == 0 && h.x_e == len[h.q] - 1, tfull = h.y_s == 0 && h.y_e == len[h.t] - 1;
         if (qfull && tfull) { if (h.q > h.t) contained[h.q] = 1; }
         else if (qfull) contained[h.q] = 1;
     }
     for (uint32_t i = 0; i < n_hit; i++) {
-        const fsv_ovl &h = hits[idx[i]];
-        if (!h.valid || !h.exact || contained[h.q] || contained[h.t]) continue;
+        const fsv_hit &h = hits[i];
+        if (contained[h.q] || contained[h.t]) continue;
         const int L = h.x_e - h.x_s + 1;
         int a, b;
         if (h.x_e == len[h.q] - 1 && h.y_s == 0 && h.x_s > 0) { a = 2 * (int)h.q; b = 2 * (int)h.t + h.rev; }
@@ -491,37 +499,41 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     TRY(ensure(ctx, W.tasks, 64));
     TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0));
     trace("overlaps");
-    const fsv_ovl *hraw = nullptr;
+    const fsv_hit *hraw = nullptr;
     std::vector<uint32_t> hit_first(B.n_sets + 1, 0);
     if (B.n_pairs) {
-        TRY(ensure(ctx, W.hits, (size_t)B.n_pairs * sizeof(fsv_ovl)));
-        FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.counters.p + 3, 0, 4, ctx->stream));
+        TRY(ensure(ctx, W.hits, (size_t)B.n_pairs * sizeof(fsv_hit)));
+        TRY(ensure(ctx, W.set_hits, (size_t)(2 * B.n_sets + 2) * 4));
+        FSV_HIP(ctx, hipMemsetAsync(W.set_hits.p, 0, (size_t)B.n_sets * 4, ctx->stream));
         W.kt.begin(ctx, KN_EXACT, (uint64_t)B.n_pairs * sizeof(fsv_ovl) + W.stats.n_pairs * 0);
         hipLaunchKernelGGL(k_exact, dim3(B.n_upairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
-                           (const uint32_t *)W.read_set.p, (const uint4 *)W.upair_tab.p, (const fsv_ovl *)W.ovl.p, (fsv_ovl *)W.hits.p,
-                           (uint32_t *)W.counters.p + 3);
+                           (const uint32_t *)W.read_set.p, (const uint32_t *)W.pair_base.p, (const uint4 *)W.upair_tab.p, (const fsv_ovl *)W.ovl.p,
+                           (fsv_hit *)W.hits.p, (uint32_t *)W.set_hits.p);
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);
-        uint32_t nh = 0;
-        FSV_HIP(ctx, hipMemcpyAsync(&nh, (uint32_t *)W.counters.p + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
+        // per-set counts -> offsets; the segments are packed on the device and come back in one copy, already grouped by set.
+        // The order inside a set depends on atomics and does not matter: the layout's containment marks and "longest arc,
+        // smallest target on ties" choices are order-independent.
+        FSV_HIP(ctx, hipMemcpyAsync(hit_first.data() + 1, W.set_hits.p, (size_t)B.n_sets * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if ((size_t)nh * sizeof(fsv_ovl) > W.h_pin_cap) {
+        for (uint32_t s2 = 0; s2 < B.n_sets; s2++) hit_first[s2 + 1] += hit_first[s2];
+        const uint32_t nh = hit_first[B.n_sets];
+        if ((size_t)nh * sizeof(fsv_hit) > W.h_pin_cap) {
             if (W.h_pin) FSV_HIP(ctx, hipHostFree(W.h_pin));
-            W.h_pin = nullptr; W.h_pin_cap = (size_t)nh * sizeof(fsv_ovl) * 5 / 4 + 4096;
+            W.h_pin = nullptr; W.h_pin_cap = (size_t)nh * sizeof(fsv_hit) * 5 / 4 + 4096;
             FSV_HIP(ctx, hipHostMalloc(&W.h_pin, W.h_pin_cap, hipHostMallocDefault));
         }
-        hraw = (const fsv_ovl *)W.h_pin;
+        hraw = (const fsv_hit *)W.h_pin;
         if (nh) {
-            FSV_HIP(ctx, hipMemcpyAsync(W.h_pin, W.hits.p, (size_t)nh * sizeof(fsv_ovl), hipMemcpyDeviceToHost, ctx->stream));
+            uint32_t *first_dev = (uint32_t *)W.set_hits.p + B.n_sets;
+            TRY(ensure(ctx, W.hits_packed, (size_t)nh * sizeof(fsv_hit)));
+            FSV_HIP(ctx, hipMemcpyAsync(first_dev, hit_first.data(), (size_t)(B.n_sets + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_hits_compact, dim3(B.n_sets), dim3(256), 0, ctx->stream, (const fsv_hit *)W.hits.p, (const uint32_t *)W.pair_base.p,
+                               (const uint32_t *)first_dev, (fsv_hit *)W.hits_packed.p);
+            FSV_HIP(ctx, hipGetLastError());
+            FSV_HIP(ctx, hipMemcpyAsync(W.h_pin, W.hits_packed.p, (size_t)nh * sizeof(fsv_hit), hipMemcpyDeviceToHost, ctx->stream));
             FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        // the gather order depends on atomics; bucket by set (counting sort over indices).  The order inside a set does not
-        // matter: the layout's containment marks and "longest arc, smallest target on ties" choices are order-independent.
-        for (uint32_t i = 0; i < nh; i++) hit_first[(uint32_t)hraw[i].first_win + 1]++;
-        for (uint32_t s2 = 0; s2 < B.n_sets; s2++) hit_first[s2 + 1] += hit_first[s2];
-        W.hit_idx.resize(nh);
-        std::vector<uint32_t> fill(hit_first.begin(), hit_first.end() - 1);
-        for (uint32_t i = 0; i < nh; i++) W.hit_idx[fill[(uint32_t)hraw[i].first_win]++] = i;
         W.stats.n_exact_overlaps = nh;
     }
     trace("exact+gather");
@@ -545,7 +557,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
                 const uint32_t r0 = B.set_start[s], ns = B.set_start[s + 1] - r0;
                 if (ns == 0) continue;
                 const uint32_t nh_s = hit_first[s + 1] - hit_first[s];
-                layout_set(len.data() + r0, ns, hraw, nh_s ? W.hit_idx.data() + hit_first[s] : nullptr, nh_s, P.min_contig_reads, lay[s].contigs, lay[s].fallback);
+                layout_set(len.data() + r0, ns, hraw + hit_first[s], nh_s, P.min_contig_reads, lay[s].contigs, lay[s].fallback);
             }
         };
         std::vector<std::thread> thr;

@@ -233,14 +233,12 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
     __syncthreads();
     for (uint32_t sz = 2; sz <= np; sz <<= 1)
         for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
-            for (uint32_t i = tid; i < np; i += 256) {
-                uint32_t j = i ^ st;
-                if (j > i) {
-                    bool up = (i & sz) == 0;
-                    uint64_t hi = s_hash[i], hj = s_hash[j], pi = s_pay[i], pj = s_pay[j];
-                    bool gt = hi > hj || (hi == hj && (uint32_t)pi > (uint32_t)pj);
-                    if (gt == up) { s_hash[i] = hj; s_hash[j] = hi; s_pay[i] = pj; s_pay[j] = pi; }
-                }
+            for (uint32_t t = tid; t < np / 2; t += 256) { // one compare-exchange per thread and trip: pair t = (i, i | st)
+                const uint32_t i = ((t & ~(st - 1)) << 1) | (t & (st - 1)), j = i | st;
+                const bool up = (i & sz) == 0;
+                const uint64_t hi = s_hash[i], hj = s_hash[j], pi = s_pay[i], pj = s_pay[j];
+                const bool gt = hi > hj || (hi == hj && (uint32_t)pi > (uint32_t)pj);
+                if (gt == up) { s_hash[i] = hj; s_hash[j] = hi; s_pay[i] = pj; s_pay[j] = pi; }
             }
             __syncthreads();
         }
@@ -281,15 +279,13 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
         __syncthreads();
         for (uint32_t sz = 2; sz <= mp; sz <<= 1)
             for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
-                for (uint32_t i = tid; i < mp; i += 256) {
-                    uint32_t j = i ^ st;
-                    if (j > i) {
-                        bool up = (i & sz) == 0;
-                        uint64_t pi = s_pay[i], pj = s_pay[j];
-                        bool gt = (uint32_t)pi > (uint32_t)pj || ((uint32_t)pi == (uint32_t)pj && pi > pj);
-                        if (pi == ~0ull && pj != ~0ull) gt = true; else if (pj == ~0ull) gt = false;
-                        if (gt == up) { uint64_t hi2 = s_hash[i], hj = s_hash[j]; s_hash[i] = hj; s_hash[j] = hi2; s_pay[i] = pj; s_pay[j] = pi; }
-                    }
+                for (uint32_t t = tid; t < mp / 2; t += 256) {
+                    const uint32_t i = ((t & ~(st - 1)) << 1) | (t & (st - 1)), j = i | st;
+                    const bool up = (i & sz) == 0;
+                    const uint64_t pi = s_pay[i], pj = s_pay[j];
+                    bool gt = (uint32_t)pi > (uint32_t)pj || ((uint32_t)pi == (uint32_t)pj && pi > pj);
+                    if (pi == ~0ull && pj != ~0ull) gt = true; else if (pj == ~0ull) gt = false;
+                    if (gt == up) { const uint64_t hi2 = s_hash[i], hj = s_hash[j]; s_hash[i] = hj; s_hash[j] = hi2; s_pay[i] = pj; s_pay[j] = pi; }
                 }
                 __syncthreads();
             }
@@ -1119,10 +1115,13 @@ __global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwi
 // pair: the overlap of t on q covers the same bases as the overlap of q on t, so one comparison decides both slots.
 // The comparison issues four 16-base fetches per lane before it looks at any of them (the early exit costs a memory
 // round trip per test, and most valid overlaps of the final pass are exact).
+// An exact overlap as the host layout reads it (32 B; q, t are read indices inside the set).
+struct fsv_hit { uint32_t q, t; int32_t x_s, x_e, y_s, y_e; uint32_t rev, slot; };
+
 __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                               const int32_t *__restrict__ read_len, const uint32_t *__restrict__ read_set,
-                                              const uint4 *__restrict__ upair_tab, const fsv_ovl *__restrict__ ovl,
-                                              fsv_ovl *__restrict__ hits, uint32_t *__restrict__ n_hits)
+                                              const uint32_t *__restrict__ pair_base, const uint4 *__restrict__ upair_tab,
+                                              const fsv_ovl *__restrict__ ovl, fsv_hit *__restrict__ hits, uint32_t *__restrict__ set_hits)
 {
     const uint4 pt = upair_tab[blockIdx.x];
     const int lane = threadIdx.x;
@@ -1152,13 +1151,30 @@ __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store
         }
         same = !__any(acc != 0u);
     }
-    if (lane < 2 && same) {
-        // exact hits are gathered for the host layout (a few per cent of the slots); the record carries its set and slot
+    if (!same) return;
+    // exact hits are gathered per set for the host layout (a few per cent of the slots): the set's hit segment starts at its
+    // first ordered-pair slot and a per-set counter hands out places -- one atomic per pair, spread over the sets' addresses
+    const uint32_t s = read_set[pt.x];
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&set_hits[s], 2u);
+    at = __shfl(at, 0, 64);
+    if (lane < 2) {
         const uint32_t slot = lane ? pt.w : pt.z;
         if (lane) o = ovl[slot];
-        o.exact = 1; o.first_win = (int32_t)read_set[pt.x]; o.chain_off = (int32_t)slot;
-        hits[atomicAdd(n_hits, 1u)] = o;
+        fsv_hit h; h.q = o.q; h.t = o.t; h.x_s = o.x_s; h.x_e = o.x_e; h.y_s = o.y_s; h.y_e = o.y_e; h.rev = o.rev; h.slot = slot;
+        hits[pair_base[s] + at + lane] = h;
     }
+}
+
+// the per-set hit segments, packed back to back for one D2H copy: one block per set, 8 words per record
+__global__ __launch_bounds__(256) void k_hits_compact(const fsv_hit *__restrict__ hits, const uint32_t *__restrict__ pair_base,
+                                                      const uint32_t *__restrict__ hit_first, fsv_hit *__restrict__ out)
+{
+    const uint32_t s = blockIdx.x;
+    const uint32_t n = (hit_first[s + 1] - hit_first[s]) * 8u;
+    const uint32_t *src = (const uint32_t *)(hits + pair_base[s]);
+    uint32_t *dst = (uint32_t *)(out + hit_first[s]);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------ k_stitch
