@@ -428,21 +428,22 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             for (int wide = 0; wide < 2; wide++) {
                 const uint32_t n_here = wide ? n_dp_wide : n_dp, list0 = wide ? n_tasks - n_dp_wide : 0u;
                 if (!n_here) continue;
-                const uint32_t chunk = std::min<uint32_t>(n_here, 1u << 18);
-                const uint32_t stride = (chunk + 63) / 64 * 64;
-                TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * (wide ? 8 : 4)));
-                for (uint32_t b = 0; b < n_here; b += chunk) {
-                    const uint32_t e = std::min(n_here, b + chunk);
-                    W.kt.begin(ctx, KN_PATH_DP, (uint64_t)(e - b) * (32 + 196 + 128));
-                    if (wide)
-                        hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(fsv_grid_for(e - b, 64)), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                                           (const uint32_t *)W.dp_list.p, list0 + b, list0 + e, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p, stride);
-                    else
-                        hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(fsv_grid_for(e - b, 64)), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                                           (const uint32_t *)W.dp_list.p, list0 + b, list0 + e, (fsv_wpath *)W.paths.p, (uint32_t *)W.cols.p, stride);
-                    FSV_HIP(ctx, hipGetLastError());
-                    W.kt.end(ctx);
-                }
+                // persistent grid: as many blocks as the device holds at once (LDS- and wave-limited), each striding through the list
+                int per_cu = 0;
+                auto launch = [&](auto kern, auto *colp) -> int {
+                    FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0));
+                    const uint32_t grid = std::min<uint32_t>(fsv_grid_for(n_here, 64), (uint32_t)std::max(1, per_cu) * (uint32_t)ctx->n_cu);
+                    const uint32_t stride = grid * 64;
+                    TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * sizeof(*colp)));
+                    W.kt.begin(ctx, KN_PATH_DP, (uint64_t)n_here * (32 + 196 + 128));
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                                       (const uint32_t *)W.dp_list.p, list0, list0 + n_here, (fsv_wpath *)W.paths.p, (decltype(colp))W.cols.p, stride);
+                    return FSV_OK;
+                };
+                if (wide) TRY(launch(k_path_dp<uint64_t>, (uint64_t *)nullptr));
+                else TRY(launch(k_path_dp<uint32_t>, (uint32_t *)nullptr));
+                FSV_HIP(ctx, hipGetLastError());
+                W.kt.end(ctx);
             }
             W.stats.ms_path += tp.stop();
         }

@@ -759,12 +759,13 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     for (int i = 0; i < 13; i++) dst[i] = make_uint2(ops32[2 * i], ops32[2 * i + 1]);
 }
 
-// Full K6: forward pass keeping {D0, VP, VN} of every column in a per-lane slice of an HBM scratch ([column][word][lane],
-// coalesced 512-byte stores), the reference's walk back, generate_cigar's end trimming and greedy gap left-shift; the
+// Full K6: forward pass keeping {D0, VP, VN} of every column in a per-lane slice of an HBM scratch ([block][column][word][lane]:
+// a wave streams through its own contiguous 290 KB, 256-byte stores), the reference's walk back, generate_cigar's end trimming and greedy gap left-shift; the
 // path under construction lives in LDS (2 bits per op) and is packed start-to-end at the end.
-// (A variant that checkpoints the DP state every 16 columns and recomputes blocks into an LDS tile during the walk back
-//  cut the scratch traffic 8x but ran 1.4x slower: the tile costs occupancy and the lanes cross block boundaries at
-//  different steps, so the wave replays each block several times.  Measured round 1, kept out.)
+// (Measured and kept out, round 1: checkpointing the DP state every 16 columns and recomputing blocks during the walk back
+//  cut the scratch traffic 8x but ran 1.4x slower; staging 9 columns per lane in LDS ahead of the walk ran 1.2x slower.
+//  SQ counters show why: with 4-5 waves per SIMD the issue slots are full -- the kernel is instruction-bound, not
+//  latency- or HBM-bound, so only fewer instructions help.)
 // WordT = uint32_t for bands of at most 31 diagonals (k <= 15): the walk back only looks at bits below the band width, so the
 // low halves of D0 / VP / VN are all it needs and the scratch traffic halves; uint64_t for the doubled thresholds (k <= 31).
 template <class WordT> struct PathSink {
@@ -774,7 +775,6 @@ template <class WordT> struct PathSink {
         WordT *c = cols + (size_t)(i + 1) * 3 * stride + lane;
         c[0] = (WordT)d0; c[stride] = (WordT)vp; c[2 * (size_t)stride] = (WordT)vn;
     }
-    __device__ __forceinline__ void block(int, const BpmState &) const {}
 };
 
 template <class WordT>
@@ -784,40 +784,54 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
 {
     __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
     const int lane64 = threadIdx.x;
-    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t li = list_begin + slot;
-    if (li >= list_end) return;
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;   // this lane's slice of the scratch, reused for every task it takes
+    // persistent blocks: the grid is sized to what the device holds at once and every block strides through the list, so the
+    // scratch is a few hundred MB whatever the number of windows, and the whole list is one launch
+    for (uint32_t li = list_begin + slot; li < list_end; li += gridDim.x * 64) {
     const uint32_t tid = dp_list[li];
     const fsv_wtask t = tasks[tid];
     fsv_wpath *P = paths + tid;
     const int n = t.x_len, k = t.k, band = 2 * k + 1;
     fsv_wres r;
-    PathSink<WordT> sink{cols, stride, slot};
+    PathSink<WordT> sink{cols + (size_t)blockIdx.x * (FSV_WINDOW + 2) * 3 * 64, 64u, (uint32_t)lane64};
     bpm_run(store, t, r, sink);
-    if (r.err < 0) { P->state = 0; return; } // cannot happen: K5 matched this window
-#define COL(c, w) ((uint64_t)cols[((size_t)(c) * 3 + (w)) * stride + slot])
+    if (r.err < 0) { P->state = 0; continue; } // cannot happen: K5 matched this window
+#define COL(c, w) (sink.cols[((c) * 3 + (w)) * 64 + lane64])
 #define TMP(i) ((s_ops[(i) >> 4][lane64] >> (((i) & 15) << 1)) & 3u)
 #define TMP_SET(i, v) do { const int w_ = (i) >> 4, sh_ = ((i) & 15) << 1; s_ops[w_][lane64] = (s_ops[w_][lane64] & ~(3u << sh_)) | ((uint32_t)(v) << sh_); } while (0)
     for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
     int end = r.end_site, err = r.err;
     int cur = err, col = n, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
+    // The walk needs columns col and col-1 at every step and moves to col-1 or stays: a step-by-step walk is a chain of
+    // ~n dependent scratch reads.  Instead each lane keeps TC+1 columns around its position in LDS; when any lane of the wave
+    // runs out, every walking lane re-centres its tile -- 3(TC+1) independent loads in flight, one memory latency per ~TC steps.
+    {
+    // the kernel is instruction-bound (4-5 waves per SIMD keep the issue slots full), so the walk is written for few
+    // instructions: WordT-wide bit tests (only band bits are read), the column it leaves behind handed to the next step
+    // instead of re-read, and the ops gathered in a register that goes to LDS once per 16 steps
+    WordT vp = COL(col, 1), vn = COL(col, 2);
+    uint32_t acc = 0;
     while (col > 0 && cur != 0) {
-        const uint64_t d0 = COL(col, 0), vp = COL(col, 1), vn = COL(col, 2);
-        const uint64_t vpi = col > 1 ? COL(col - 1, 1) : 0ull, vni = col > 1 ? COL(col - 1, 2) : 0ull;
-        const uint64_t hn = vpi & d0, hp = vni | ~(vpi | d0);
-        const int diag = cur - (int)((~(d0 >> row)) & 1ull);
+        const WordT d0 = COL(col, 0);
+        const WordT vpi = col > 1 ? COL(col - 1, 1) : (WordT)0, vni = col > 1 ? COL(col - 1, 2) : (WordT)0;
+        const WordT hn = vpi & d0, hp = vni | ~(vpi | d0);
+        const int diag = cur - (int)((~(d0 >> row)) & 1u);
         const bool can_up = row != 0, can_left = row == 0 || row != band - 1;
         int left = cur, up = cur;
-        if (can_left) left = cur - (int)((hp >> row) & 1ull) + (int)((hn >> row) & 1ull);
-        if (can_up) up = cur - (int)((vp >> (row - 1)) & 1ull) + (int)((vn >> (row - 1)) & 1ull);
+        if (can_left) left = cur - (int)((hp >> row) & 1u) + (int)((hn >> row) & 1u);
+        if (can_up) up = cur - (int)((vp >> (row - 1)) & 1u) + (int)((vn >> (row - 1)) & 1u);
         int best = diag; dir = 0;
         if (can_up && up < best) { best = up; dir = 2; }
         if (can_left && left < best) { best = left; dir = 3; }
-        if (dir == 0) { if (diag != cur) dir = 1; col--; start--; }
+        if (dir == 0) { if (diag != cur) dir = 1; col--; start--; vp = vpi; vn = vni; }
         else if (dir == 2) { row--; start--; }
-        else { col--; row++; }
-        TMP_SET(plen, dir); plen++;
+        else { col--; row++; vp = vpi; vn = vni; }
+        acc |= (uint32_t)dir << ((plen & 15) << 1);
+        if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
+        plen++;
         cur = best;
+    }
+    if (plen & 15) s_ops[plen >> 4][lane64] = acc;
     }
     if (col > 0) { start -= col; plen += col; dir = 0; } // the rest of the path is matches: the fields are already 0
     if (dir != 3) start++;
@@ -827,9 +841,14 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
         for (int i = 0; i < plen && TMP(i) == 1; i++) { TMP_SET(i, 3); end--; stop = i; }
         for (int i = plen - 1; i >= 0 && TMP(i) == 1; i--) { TMP_SET(i, 3); start++; }
         int xi = 0, yi = 0;
-        for (int i = plen - 1; i > stop; i--) {
-            const uint32_t op = TMP(i);
-            if (op < 2) { xi++; yi++; continue; }
+        for (int i = plen - 1; i > stop;) {
+            // runs of match / mismatch ops are skipped a path word at a time: a gap op is a field with its high bit set
+            const int f = i & 15;
+            const uint32_t wv = s_ops[i >> 4][lane64];
+            const uint32_t m = wv & 0xAAAAAAAAu & (f == 15 ? 0xffffffffu : ((1u << (2 * f + 2)) - 1u));
+            const int skip = min(m == 0u ? f + 1 : f - ((31 - __clz(m)) >> 1), i - stop);
+            if (skip > 0) { xi += skip; yi += skip; i -= skip; continue; }
+            const uint32_t op = (wv >> (2 * f)) & 3u;
             // shift this gap towards the alignment start while the bases it passes still pair up (move_gap_greedy)
             int pi = i + 1, x2 = xi, y2 = yi;
             if (op == 3) y2--; else x2--;
@@ -842,18 +861,26 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
                 TMP_SET(pi, op);
             }
             if (op == 2) yi++; else xi++;
+            i--;
         }
     }
+    // pack start-to-end: output word wd holds the source fields plen-16-16wd .. plen-1-16wd in reverse order
     const int pl = min(plen, FSV_PATH_CAP);
     uint32_t *dst = reinterpret_cast<uint32_t *>(P->ops);
     for (int wd = 0; wd < 26; wd++) {
+        const int a = plen - 16 - 16 * wd;
         uint32_t v = 0;
-        for (int f = 0; f < 16; f++) { const int i = wd * 16 + f; if (i < pl) v |= (uint32_t)TMP(plen - 1 - i) << (2 * f); }
-        dst[wd] = v;
+        if (a >= 0) {
+            const int wi = a >> 4, sh = (a & 15) << 1;
+            const uint32_t w0 = s_ops[wi][lane64], w1 = (sh && wi + 1 < 28) ? s_ops[wi + 1][lane64] : 0u;
+            v = sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
+        } else if (a > -16) v = s_ops[0][lane64] << ((-a) << 1);
+        dst[wd] = rev_fields2(v);
     }
     P->ry_start = t.y_start - t.k + start;
     P->ry_end = t.y_start - t.k + end;
     P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
+    } // next task of this lane
 #undef COL
 #undef TMP
 #undef TMP_SET

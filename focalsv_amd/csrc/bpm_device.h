@@ -111,12 +111,32 @@ __device__ __forceinline__ uint32_t fetch16_x(const uint32_t *__restrict__ store
     return sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
 }
 
-// Hooks for K6: `sink` sees every DP column (D0 and the post-update VP/VN); `block` sees the whole state in front of
-// every 16-column block (K6 checkpoints it so that the walk back can recompute one block at a time).
+// Hooks for K6: `sink` sees every DP column (D0 and the post-update VP/VN).
 struct BpmNoSink {
     __device__ __forceinline__ void operator()(int, uint64_t, uint64_t, uint64_t) const {}
-    __device__ __forceinline__ void block(int, const BpmState &) const {}
 };
+
+// even bit positions of a 32-bit word -> 16-bit mask (bit j = bit 2j of the input)
+__device__ __forceinline__ uint32_t compress_even16(uint32_t d)
+{
+    d &= 0x55555555u;
+    d = (d | (d >> 1)) & 0x33333333u; d = (d | (d >> 2)) & 0x0f0f0f0fu; d = (d | (d >> 4)) & 0x00ff00ffu; d = (d | (d >> 8)) & 0xffffu;
+    return d;
+}
+
+// One column of the recurrence (Levenshtein_distance.h:330-366); false when the column's diagonal cell is a mismatch.
+__device__ __forceinline__ bool bpm_column(uint64_t eq, uint64_t &vp, uint64_t &vn, uint64_t &d0_out)
+{
+    const uint64_t x = eq | vn;
+    const uint64_t d0 = ((vp + (x & vp)) ^ vp) | x;
+    const uint64_t hn = vp & d0;
+    const uint64_t hp = vn | ~(vp | d0);
+    const uint64_t sh = d0 >> 1;
+    vn = sh & hp;
+    vp = hn | ~(sh | hp);
+    d0_out = d0;
+    return (d0 & 1ull) != 0ull;
+}
 
 template <class Sink>
 __device__ __forceinline__ void bpm_run(const uint32_t *__restrict__ store, const fsv_wtask &t, fsv_wres &r, Sink sink)
@@ -131,66 +151,65 @@ __device__ __forceinline__ void bpm_run(const uint32_t *__restrict__ store, cons
         for (int j = 0; j < 16 && b16 + j <= 2 * k; j++)
             if ((y.valid >> j) & 1u) bpm_eq_set(s, (y.bits >> (2 * j)) & 3u, 1ull << (b16 + j));
     }
-    const uint64_t top = 1ull << (2 * k);
     int err = 0;
     uint32_t xb = fetch16_x(store, t.x_word, t.x_start);
     Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1);
-    for (int blk = 0; blk < n; blk += 16) {
-        // next block's operands are requested before this block's 16 columns are computed
-        const uint32_t xn = fetch16_x(store, t.x_word, t.x_start + blk + 16);
-        const Bases16 yn = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1 + blk + 16);
-        const int lim = min(16, n - blk);
-        sink.block(blk >> 4, s);
-        for (int j = 0; j < lim; j++) {
-            const int i = blk + j;
-            const uint32_t c = (xb >> (2 * j)) & 3u;
-            uint64_t x = bpm_pick_eq(s, c) | s.vn;
-            uint64_t d0 = ((s.vp + (x & s.vp)) ^ s.vp) | x;
-            uint64_t hn = s.vp & d0;
-            uint64_t hp = s.vn | ~(s.vp | d0);
-            uint64_t sh = d0 >> 1;
-            s.vn = sh & hp;
-            s.vp = hn | ~(sh | hp);
-            if (!(d0 & 1ull)) {
-                ++err;
-                if (err - 2 * k > k) return; // Levenshtein_distance.h:367-375
+    if (2 * k + 17 <= 64) {
+        // The reference slides its four match masks one row per column (shift, then set the new top row).  Here the masks
+        // of a 16-column block cover all 2k+17 y rows the block touches (bit b = row win0 + blk + b), so a column's masks are
+        // a shift by j and a band mask, and the slide costs one shift per 16 columns: the same bits, a third fewer instructions.
+        const uint64_t band = (2ull << (2 * k)) - 1ull;
+        for (int blk = 0; blk < n; blk += 16) {
+            // next block's operands are requested before this block's 16 columns are computed
+            const uint32_t xn = fetch16_x(store, t.x_word, t.x_start + blk + 16);
+            const Bases16 yn = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1 + blk + 16);
+            {
+                const uint32_t lo = compress_even16(yb.bits), hi = compress_even16(yb.bits >> 1), v = yb.valid & 0xffffu;
+                s.eq0 |= (uint64_t)(~lo & ~hi & v) << (2 * k + 1);
+                s.eq1 |= (uint64_t)(lo & ~hi & v) << (2 * k + 1);
+                s.eq2 |= (uint64_t)(~lo & hi & v) << (2 * k + 1);
+                s.eq3 |= (uint64_t)(lo & hi & v) << (2 * k + 1);
             }
-            sink(i, d0, s.vp, s.vn);
-            if (i + 1 < n) {
-                s.eq0 >>= 1; s.eq1 >>= 1; s.eq2 >>= 1; s.eq3 >>= 1;
-                if ((yb.valid >> j) & 1u) bpm_eq_set(s, (yb.bits >> (2 * j)) & 3u, top);
+            const int lim = min(16, n - blk);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (j < lim) {
+                    const uint64_t eq = (bpm_pick_eq(s, (xb >> (2 * j)) & 3u) >> j) & band;
+                    uint64_t d0;
+                    if (!bpm_column(eq, s.vp, s.vn, d0)) {
+                        ++err;
+                        if (err - 2 * k > k) return; // Levenshtein_distance.h:367-375
+                    }
+                    sink(blk + j, d0, s.vp, s.vn);
+                }
             }
+            s.eq0 >>= 16; s.eq1 >>= 16; s.eq2 >>= 16; s.eq3 >>= 16;
+            xb = xn; yb = yn;
         }
-        xb = xn; yb = yn;
+    } else {
+        // bands wider than 47 rows (the doubled thresholds of the rescue pass): the reference's column-by-column slide
+        const uint64_t top = 1ull << (2 * k);
+        for (int blk = 0; blk < n; blk += 16) {
+            const uint32_t xn = fetch16_x(store, t.x_word, t.x_start + blk + 16);
+            const Bases16 yn = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1 + blk + 16);
+            const int lim = min(16, n - blk);
+            for (int j = 0; j < lim; j++) {
+                const int i = blk + j;
+                uint64_t d0;
+                if (!bpm_column(bpm_pick_eq(s, (xb >> (2 * j)) & 3u), s.vp, s.vn, d0)) {
+                    ++err;
+                    if (err - 2 * k > k) return;
+                }
+                sink(i, d0, s.vp, s.vn);
+                if (i + 1 < n) {
+                    s.eq0 >>= 1; s.eq1 >>= 1; s.eq2 >>= 1; s.eq3 >>= 1;
+                    if ((yb.valid >> j) & 1u) bpm_eq_set(s, (yb.bits >> (2 * j)) & 3u, top);
+                }
+            }
+            xb = xn; yb = yn;
+        }
     }
     int best;
     r.end_site = bpm_pick_end(s, err, n, k, best);
     r.err = best;
-}
-
-// Recompute the columns of block b (x indices 16b .. 16b+15) from the state in front of it; out(j, d0, vp, vn) for column 16b+j.
-template <class Out>
-__device__ __forceinline__ void bpm_replay_block(const uint32_t *__restrict__ store, const fsv_wtask &t, int b, BpmState s, Out out)
-{
-    const int n = t.x_len, k = t.k, blk = b << 4;
-    const uint64_t top = 1ull << (2 * k);
-    const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + blk);
-    const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, t.y_start - k + 2 * k + 1 + blk);
-    const int lim = min(16, n - blk);
-    for (int j = 0; j < lim; j++) {
-        const int i = blk + j;
-        const uint32_t c = (xb >> (2 * j)) & 3u;
-        uint64_t x = bpm_pick_eq(s, c) | s.vn;
-        uint64_t d0 = ((s.vp + (x & s.vp)) ^ s.vp) | x;
-        uint64_t hn = s.vp & d0;
-        uint64_t hp = s.vn | ~(s.vp | d0);
-        uint64_t sh = d0 >> 1;
-        s.vn = sh & hp;
-        s.vp = hn | ~(sh | hp);
-        out(j, d0, s.vp, s.vn);
-        if (i + 1 < n) {
-            s.eq0 >>= 1; s.eq1 >>= 1; s.eq2 >>= 1; s.eq3 >>= 1;
-            if ((yb.valid >> j) & 1u) bpm_eq_set(s, (yb.bits >> (2 * j)) & 3u, top);
-        }
-    }
 }
