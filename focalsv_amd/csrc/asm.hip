@@ -39,7 +39,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
 
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
-        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, upair_base, upair_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -51,7 +51,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &upair_base, &upair_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -156,6 +156,7 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     TRY(ensure(ctx, W.mz, (size_t)G.mz_off[B.n_reads] * sizeof(fsv_mz)));
     TRY(ensure(ctx, W.mz_cnt, (size_t)B.n_reads * 4));
     TRY(ensure(ctx, W.ovl, (size_t)std::max(1u, B.n_pairs) * sizeof(fsv_ovl)));
+    TRY(ensure(ctx, W.ovl_c, (size_t)std::max(1u, B.n_pairs) * sizeof(uint4)));
     TRY(ensure(ctx, W.counters, 64));
     FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, 64, ctx->stream));
     W.kt.begin(ctx, KN_SKETCH, (uint64_t)G.word_off[B.n_reads] * 4 + (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz));
@@ -406,7 +407,8 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             W.kt.end(ctx);
             W.kt.begin(ctx, KN_RESCUE, (uint64_t)n_tasks * 48 + (uint64_t)B.n_pairs * sizeof(fsv_ovl) * 2);
     hipLaunchKernelGGL(k_rescue_accept, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
-                               B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)((uint32_t *)W.counters.p + 4));
+                               B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)((uint32_t *)W.counters.p + 4),
+                               (uint4 *)W.ovl_c.p);
             FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
             W.stats.ms_verify += tv.stop();
@@ -453,11 +455,16 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         TRY(ensure(ctx, W.cwin, (size_t)n_gwin * FSV_CW_STRIDE));
         TRY(ensure(ctx, W.cwin_len, (size_t)n_gwin * 2));
         TRY(ensure(ctx, W.new_len, (size_t)B.n_reads * 4));
-        if (!n_tasks) { TRY(ensure(ctx, W.paths, sizeof(fsv_wpath))); }
+        if (!n_tasks) { TRY(ensure(ctx, W.paths, sizeof(fsv_wpath))); FSV_HIP(ctx, hipMemsetAsync(W.ovl_c.p, 0, (size_t)std::max(1u, B.n_pairs) * sizeof(uint4), ctx->stream)); }
+        TRY(ensure(ctx, W.gwin_tab, (size_t)std::max(1u, n_gwin) * sizeof(uint4)));
+        hipLaunchKernelGGL(k_gwin_tab, dim3(fsv_grid_for(n_gwin, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_read.p, (const uint32_t *)W.gwin_off.p,
+                           (const uint32_t *)W.read_set.p, (const uint32_t *)W.set_start.p, (const uint32_t *)W.pair_base.p, n_gwin, (uint4 *)W.gwin_tab.p);
+        FSV_HIP(ctx, hipGetLastError());
         ConsArgs C;
         C.store = store; C.word_off = (const uint32_t *)W.word_off.p; C.read_len = (const int32_t *)W.len.p;
         C.read_set = (const uint32_t *)W.read_set.p; C.set_start = (const uint32_t *)W.set_start.p; C.pair_base = (const uint32_t *)W.pair_base.p;
-        C.gwin_off = (const uint32_t *)W.gwin_off.p; C.gwin_read = (const uint32_t *)W.gwin_read.p; C.ovl = (const fsv_ovl *)W.ovl.p; C.tasks = (const fsv_wtask *)W.tasks.p;
+        C.gwin_off = (const uint32_t *)W.gwin_off.p; C.gwin_read = (const uint32_t *)W.gwin_read.p; C.ovl_c = (const uint4 *)W.ovl_c.p;
+        C.gwin_tab = (const uint4 *)W.gwin_tab.p; C.tasks = (const fsv_wtask *)W.tasks.p;
         C.paths = (const fsv_wpath *)W.paths.p; C.cwin = (uint8_t *)W.cwin.p; C.cwin_len = (uint16_t *)W.cwin_len.p; C.warn = (uint32_t *)W.warn.p;
         C.n_reads = B.n_reads;
         W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_tasks * 128 + (uint64_t)n_gwin * (96 + 448));

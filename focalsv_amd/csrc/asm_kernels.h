@@ -646,12 +646,13 @@ __device__ __forceinline__ int double_thr(int pre, int x_len)
 
 __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict__ store, fsv_ovl *__restrict__ ovl, uint32_t n_pairs,
                                                       fsv_wtask *__restrict__ tasks, fsv_wres *__restrict__ res,
-                                                      unsigned long long *__restrict__ stat_cols)
+                                                      unsigned long long *__restrict__ stat_cols, uint4 *__restrict__ ovl_c)
 {
     const uint32_t p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n_pairs) return;
     fsv_ovl o = ovl[p];
-    if (!o.valid) return;
+    // ovl_c: what the consensus needs of an overlap, 16 B instead of 56: {x_s, first window task, n_win | accepted << 31, -}
+    if (!o.valid) { ovl_c[p] = make_uint4(0u, 0u, 0u, 0u); return; }
     fsv_wtask *T = tasks + o.first_win;
     fsv_wres *R = res + o.first_win;
     int align = 0;
@@ -681,6 +682,7 @@ __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict
     o.align_len = align; o.err_sum = (int32_t)terr;
     o.is_match = ((long long)(o.x_e - o.x_s + 1) * 9 <= (long long)align * 10 && terr * 100 <= tlen * 3) ? 1 : 0;
     ovl[p] = o;
+    ovl_c[p] = make_uint4((uint32_t)o.x_s, (uint32_t)o.first_win, (uint32_t)o.n_win | (o.is_match ? 0x80000000u : 0u), 0u);
     if (cols) atomicAdd(stat_cols, cols);
 }
 
@@ -899,7 +901,8 @@ struct ConsArgs {
     const uint32_t *pair_base;
     const uint32_t *gwin_off;    // n_reads + 1: first grid window of every read
     const uint32_t *gwin_read;   // n_gwin: read of every grid window
-    const fsv_ovl *ovl;
+    const uint4 *ovl_c;          // per ordered pair: {x_s, first window task, n_win | accepted << 31, -}  (k_rescue_accept)
+    const uint4 *gwin_tab;       // per grid window: {read, first pair slot of the read, overlaps of the read, window index}  (k_gwin_tab)
     const fsv_wtask *tasks;
     const fsv_wpath *paths;
     uint8_t *cwin;               // FSV_CW_STRIDE bytes per grid window (2-bit codes, one per byte)
@@ -914,13 +917,23 @@ __device__ __forceinline__ bool vote_wins(int cnt, int total, bool homo)
     return homo && cnt * 1000 >= total * 515;
 }
 
+// per grid window, once per round: everything k_consensus would otherwise look up through three levels of tables
+__global__ void k_gwin_tab(const uint32_t *__restrict__ gwin_read, const uint32_t *__restrict__ gwin_off, const uint32_t *__restrict__ read_set,
+                           const uint32_t *__restrict__ set_start, const uint32_t *__restrict__ pair_base, uint32_t n_gwin, uint4 *__restrict__ tab)
+{
+    const uint32_t gw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw >= n_gwin) return;
+    const uint32_t r = gwin_read[gw], s = read_set[r], r0 = set_start[s], ns = set_start[s + 1] - r0;
+    tab[gw] = make_uint4(r, pair_base[s] + (r - r0) * (ns - 1), ns - 1, gw - gwin_off[r]);
+}
+
 __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
 {
     // Per-column votes of one 375-bp grid window.  A match op votes for the backbone's own base, so a lane (= one
     // overlap) only contributes (a) its coverage interval, through a difference array, and (b) its deviations --
     // mismatches, deleted columns, insertions -- which it finds by skipping the all-match words of its 2-bit path.
     // Deviations are sparse (HiFi: ~1.5 per window), so their LDS atomics do not collide the way per-step votes would.
-    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][6];  // per column: votes for A C G T that differ from the backbone, deleted, arrived-after-insertion
+    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][3];  // per column, 16 bits each: votes for A C | G T that differ from the backbone | deleted, arrived-after-insertion
     __shared__ int32_t s_cov[FSV_WINDOW + 2];      // coverage difference array -> arrived
     __shared__ uint32_t s_path[64][27];            // per lane: the 26 op words of its window path (odd stride); reused as s_out
     __shared__ uint16_t s_evcol[FSV_EV_CAP];
@@ -931,25 +944,27 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     const int lane = threadIdx.x;
     const uint32_t gw = blockIdx.x;
     if (gw >= n_gwin) return;
-    const uint32_t r = A.gwin_read[gw];
-    const int g = (int)(gw - A.gwin_off[r]);
+    const uint4 gt = A.gwin_tab[gw];
+    const uint32_t r = gt.x, pbase = gt.y, n_ovl = gt.z;
+    const int g = (int)gt.w;
     const int xlen = A.read_len[r];
     const int gs = g * FSV_WINDOW, glen = min(FSV_WINDOW, xlen - gs);
     const uint32_t xw = A.word_off[r];
-    const uint32_t s = A.read_set[r], r0 = A.set_start[s], ns = A.set_start[s + 1] - r0, q = r - r0;
-    const uint32_t pbase = A.pair_base[s] + q * (ns - 1);
     const int xw0 = (gs >> 4) - 1; // first staged word (may be -1 at the read start: reads as 0, never used)
     if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((xlen + 15) >> 4)) ? A.store[xw + wi] : 0u; }
-    for (int i = lane; i < (FSV_WINDOW + 1) * 6; i += 64) (&s_cnt[0][0])[i] = 0;
+    for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
     if (lane == 0) { s_evn = 0; s_cover = 0; }
     __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
-    for (uint32_t oi = lane; oi < ns - 1; oi += 64) {
-        const fsv_ovl o = A.ovl[pbase + oi];
-        const int j = g - o.x_s / FSV_WINDOW;
-        if (!o.valid || !o.is_match || j < 0 || j >= o.n_win) continue;
-        const uint32_t ti = (uint32_t)o.first_win + (uint32_t)j;
+#define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
+#define CNT_GET(c, b) ((s_cnt[(c)][(b) >> 1] >> (((b) & 1u) << 4)) & 0xffffu)
+    for (uint32_t oi = lane; oi < n_ovl; oi += 64) {
+        const uint4 oc = A.ovl_c[pbase + oi];
+        const int o_x_s = (int)oc.x, o_n_win = (int)(oc.z & 0x7fffffffu);
+        const int j = g - o_x_s / FSV_WINDOW;
+        if (!(oc.z >> 31) || j < 0 || j >= o_n_win) continue;
+        const uint32_t ti = oc.y + (uint32_t)j;
         const fsv_wpath *P = A.paths + ti;
         const uint4 h0 = *reinterpret_cast<const uint4 *>(P);                      // ry_start, ry_end, path_len|err, state|rev|pad
         if ((h0.w & 0xffu) != 1u) continue;
@@ -963,7 +978,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
         const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
 #define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))
-        const int xs = max(gs, o.x_s) - gs;
+        const int xs = max(gs, o_x_s) - gs;
         bool pend = false;
         if (j > 0) {
             const uint4 hp = *reinterpret_cast<const uint4 *>(A.paths + ti - 1);
@@ -1004,9 +1019,9 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                 n2 += L; p += L;
                 continue;
             }
-            if (pend) { atomicAdd(&s_cnt[xp][5], 1u); pend = false; }
-            if (op == 3u) { atomicAdd(&s_cnt[xp][4], 1u); n3++; }
-            else if (op == 1u) atomicAdd(&s_cnt[xp][YB(ry_start + p - n3)], 1u);
+            if (pend) { CNT_ADD(xp, 5u); pend = false; }
+            if (op == 3u) { CNT_ADD(xp, 4u); n3++; }
+            else if (op == 1u) CNT_ADD(xp, YB(ry_start + p - n3));
             p++;
         }
 #undef OP
@@ -1040,7 +1055,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         else {
             const int p = gs + c;
             bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < xlen && XB(p + 1) == own);
-            const int instot = (int)s_cnt[c][5];
+            const int instot = (int)CNT_GET(c, 5u);
             if (instot) {
                 int bc = 0; uint32_t bk = 0;
                 for (uint32_t i = 0; i < evn; i++) {
@@ -1059,7 +1074,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
             int v[5];
             int dev = 0;
 #pragma unroll
-            for (int b = 0; b < 5; b++) { v[b] = (int)s_cnt[c][b]; dev += v[b]; }
+            for (int b = 0; b < 5; b++) { v[b] = (int)CNT_GET(c, (uint32_t)b); dev += v[b]; }
             // matches vote for the backbone base; + the backbone's own weight of 1 (POA.cpp:269-307)
 #pragma unroll
             for (int b = 0; b < 4; b++) if ((int)own == b) v[b] += arrived - dev + 1;
@@ -1089,6 +1104,8 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     for (int c = c0; c < c1; c++) for (int b = 0; b < s_out[c][0]; b++) dst[off++] = s_out[c][1 + b];
     if (lane == 0) A.cwin_len[gw] = (uint16_t)tot;
 #undef XB
+#undef CNT_ADD
+#undef CNT_GET
 }
 
 // ------------------------------------------------------------------------------------------------ k_newlen / k_repack
