@@ -24,7 +24,29 @@ __global__ __launch_bounds__(256) void k5_bpm_kernel(const uint32_t *__restrict_
     if (tid >= n_tasks) return;
     const fsv_wtask t = tasks[tid];
     fsv_wres r;
-    bpm_run(store, t, r, BpmNoSink());
+    // Shortcut for a window that matches exactly on its predicted diagonal (nearly every window from the second correction
+    // round on): the DP then reports distance 0, and its end-site rule (Levenshtein_distance.h:418-457: the last site with the
+    // minimum, overridden by the ungapped site when that attains it) picks the diagonal's end n-1+k.  A 24-word XOR compare
+    // instead of 375 DP columns; lanes that differ anywhere run the DP as before.
+    bool exact = bpm_window_geometry(t, r);
+    if (exact) {
+        const int n = t.x_len;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int wd = 0; wd < (FSV_WINDOW + 15) / 16; wd++) {
+            const int i = wd * 16;
+            if (i < n) {
+                const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + i);
+                const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, t.y_start + i);
+                const int lim = min(16, n - i);
+                const uint32_t fm = lim < 16 ? (1u << (2 * lim)) - 1u : 0xffffffffu, vm = (1u << lim) - 1u;
+                acc |= ((xb ^ yb.bits) & fm) | ((yb.valid & vm) ^ vm);
+            }
+        }
+        exact = acc == 0u;
+        if (exact) { r.end_site = n - 1 + t.k; r.err = 0; }
+    }
+    if (!exact) bpm_run(store, t, r, BpmNoSink());
     res[tid] = r;
 }
 
