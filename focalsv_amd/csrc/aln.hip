@@ -214,100 +214,183 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
 // ------------------------------------------------------------------------------------------------ NW
 // One workgroup per event, cells of one anti-diagonal in parallel.  Rolling rows indexed by the query position:
 //   H on diagonals d-1 and d-2, and the E/F/E2/F2 values *leaving* each cell of diagonal d-1.
-// Per cell one traceback byte with ksw2's layout (ksw2.h:115-118).
-template <int QCAP> // queries up to QCAP bases keep their rolling rows in LDS (11 x QCAP x 4 B); small events get many blocks per CU
-__global__ __launch_bounds__(256) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
-                                            const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
-                                            const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
-                                            const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all, int32_t *__restrict__ rows_all,
-                                            uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
+// Per cell one traceback byte with ksw2's layout (ksw2.h:115-118), stored diagonal-major (byte (i+j)*ql + j: the cells of
+// a diagonal are adjacent, so a wave's stores coalesce).
+struct NwRows {
+    int32_t *rows; int stride;
+    __device__ __forceinline__ int32_t *H(int d) const { return rows + (size_t)(((d) % 3 + 3) % 3) * stride; }
+    __device__ __forceinline__ int32_t *E(int d) const { return rows + (size_t)(3 + (d & 1)) * stride; }
+    __device__ __forceinline__ int32_t *F(int d) const { return rows + (size_t)(5 + (d & 1)) * stride; }
+    __device__ __forceinline__ int32_t *E2(int d) const { return rows + (size_t)(7 + (d & 1)) * stride; }
+    __device__ __forceinline__ int32_t *F2(int d) const { return rows + (size_t)(9 + (d & 1)) * stride; }
+};
+
+// cell (i, j) of diagonal d = i + j (ksw_extz2's recurrence, ksw2_extz2_sse.c; boundary: a gap of length l before the
+// first cell costs min(q + e*l, q2 + e2*l))
+__device__ __forceinline__ void nw_cell(const NwRows &R, int d, int i, int j, uint32_t tb, uint32_t qb, bool two, const fsv_aln_params &P,
+                                        uint8_t *__restrict__ bt, int ql)
 {
-    __shared__ int32_t s_rows[11 * QCAP];
-    const NwTask T = tasks[blockIdx.x];
-    const uint32_t qw = word_off[pair_q[T.pair]], tw = word_off[pair_t[T.pair]];
-    const int lenq = read_len[pair_q[T.pair]], rev = hdr[T.pair].rev;
-    const int ql = T.ql, tl = T.tl;
-    const bool two = P.q2 >= 0;
-    int32_t *rows = ql <= QCAP ? s_rows : rows_all + T.row_off;
-    const int stride = ql <= QCAP ? QCAP : ql;
-    uint8_t *bt = bt_all + T.bt_off;
-    // rows: H[3], Eo[2], Fo[2], E2o[2], F2o[2]
-#define HROW(d) (rows + (size_t)(((d) % 3 + 3) % 3) * stride)
-#define EROW(d) (rows + (size_t)(3 + ((d) & 1)) * stride)
-#define FROW(d) (rows + (size_t)(5 + ((d) & 1)) * stride)
-#define E2ROW(d) (rows + (size_t)(7 + ((d) & 1)) * stride)
-#define F2ROW(d) (rows + (size_t)(9 + ((d) & 1)) * stride)
-    for (int d = 0; d <= ql + tl - 2; d++) {
-        const int jlo = max(0, d - (tl - 1)), jhi = min(ql - 1, d);
-        int32_t *Hc = HROW(d), *H1 = HROW(d - 1), *H2 = HROW(d - 2);
-        for (int j = jlo + (int)threadIdx.x; j <= jhi; j += blockDim.x) {
-            const int i = d - j;
-            // boundary values (ksw2: a gap of length l before the first cell costs min(q + e*l, q2 + e2*l))
-            int32_t hdiag, a, b, a2 = NW_NEG, b2 = NW_NEG;
-            if (i == 0 && j == 0) hdiag = 0;
-            else if (i == 0) { int g1 = -(P.q + P.e * j), g2 = two ? -(P.q2 + P.e2 * j) : NW_NEG; hdiag = max(g1, g2); }
-            else if (j == 0) { int g1 = -(P.q + P.e * i), g2 = two ? -(P.q2 + P.e2 * i) : NW_NEG; hdiag = max(g1, g2); }
-            else hdiag = H2[j - 1];
-            if (i == 0) {
-                int g1 = -(P.q + P.e * (j + 1)), g2 = two ? -(P.q2 + P.e2 * (j + 1)) : NW_NEG;
-                const int hup = max(g1, g2); // H(-1, j)
-                a = hup - P.q - P.e; if (two) a2 = hup - P.q2 - P.e2;
-            } else { a = EROW(d - 1)[j]; if (two) a2 = E2ROW(d - 1)[j]; }
-            if (j == 0) {
-                int g1 = -(P.q + P.e * (i + 1)), g2 = two ? -(P.q2 + P.e2 * (i + 1)) : NW_NEG;
-                const int hleft = max(g1, g2); // H(i, -1)
-                b = hleft - P.q - P.e; if (two) b2 = hleft - P.q2 - P.e2;
-            } else { b = FROW(d - 1)[j - 1]; if (two) b2 = F2ROW(d - 1)[j - 1]; }
-            const uint32_t tb = fsv_base_fwd(store, tw, T.ts + i), qb = qbase(store, qw, lenq, rev, T.qs + j);
-            int32_t h = hdiag + (tb == qb ? P.a : -P.b);
-            uint8_t dd = 0;
-            if (a > h) { h = a; dd = 1; }
-            if (b > h) { h = b; dd = 2; }
-            if (two && a2 > h) { h = a2; dd = 3; }
-            if (two && b2 > h) { h = b2; dd = 4; }
-            int32_t o = h - P.q;
-            if (a > o) { dd |= 0x08; EROW(d)[j] = a - P.e; } else EROW(d)[j] = o - P.e;
-            if (b > o) { dd |= 0x10; FROW(d)[j] = b - P.e; } else FROW(d)[j] = o - P.e;
-            if (two) {
-                o = h - P.q2;
-                if (a2 > o) { dd |= 0x20; E2ROW(d)[j] = a2 - P.e2; } else E2ROW(d)[j] = o - P.e2;
-                if (b2 > o) { dd |= 0x40; F2ROW(d)[j] = b2 - P.e2; } else F2ROW(d)[j] = o - P.e2;
-            }
-            Hc[j] = h;
-            bt[(size_t)i * ql + j] = dd;
+    int32_t hdiag, a, b, a2 = NW_NEG, b2 = NW_NEG;
+    if (i == 0 && j == 0) hdiag = 0;
+    else if (i == 0) { int g1 = -(P.q + P.e * j), g2 = two ? -(P.q2 + P.e2 * j) : NW_NEG; hdiag = max(g1, g2); }
+    else if (j == 0) { int g1 = -(P.q + P.e * i), g2 = two ? -(P.q2 + P.e2 * i) : NW_NEG; hdiag = max(g1, g2); }
+    else hdiag = R.H(d - 2)[j - 1];
+    if (i == 0) {
+        int g1 = -(P.q + P.e * (j + 1)), g2 = two ? -(P.q2 + P.e2 * (j + 1)) : NW_NEG;
+        const int hup = max(g1, g2); // H(-1, j)
+        a = hup - P.q - P.e; if (two) a2 = hup - P.q2 - P.e2;
+    } else { a = R.E(d - 1)[j]; if (two) a2 = R.E2(d - 1)[j]; }
+    if (j == 0) {
+        int g1 = -(P.q + P.e * (i + 1)), g2 = two ? -(P.q2 + P.e2 * (i + 1)) : NW_NEG;
+        const int hleft = max(g1, g2); // H(i, -1)
+        b = hleft - P.q - P.e; if (two) b2 = hleft - P.q2 - P.e2;
+    } else { b = R.F(d - 1)[j - 1]; if (two) b2 = R.F2(d - 1)[j - 1]; }
+    int32_t h = hdiag + (tb == qb ? P.a : -P.b);
+    uint8_t dd = 0;
+    if (a > h) { h = a; dd = 1; }
+    if (b > h) { h = b; dd = 2; }
+    if (two && a2 > h) { h = a2; dd = 3; }
+    if (two && b2 > h) { h = b2; dd = 4; }
+    int32_t o = h - P.q;
+    if (a > o) { dd |= 0x08; R.E(d)[j] = a - P.e; } else R.E(d)[j] = o - P.e;
+    if (b > o) { dd |= 0x10; R.F(d)[j] = b - P.e; } else R.F(d)[j] = o - P.e;
+    if (two) {
+        o = h - P.q2;
+        if (a2 > o) { dd |= 0x20; R.E2(d)[j] = a2 - P.e2; } else R.E2(d)[j] = o - P.e2;
+        if (b2 > o) { dd |= 0x40; R.F2(d)[j] = b2 - P.e2; } else R.F2(d)[j] = o - P.e2;
+    }
+    R.H(d)[j] = h;
+    bt[(size_t)d * ql + j] = dd;
+}
+
+// ksw_backtrack (ksw2.h:120-150) by thread 0, emitted end-to-start then reversed in place.  The traceback bytes come through
+// an LDS tile of NW_TD diagonals x NW_TC columns that the whole workgroup loads around the current cell: one memory latency
+// per >= 16 steps instead of one per step.
+#define NW_TD 32
+#define NW_TC 32
+__device__ __forceinline__ void nw_backtrack(const uint8_t *__restrict__ bt, int ql, int tl, uint32_t *__restrict__ cg, uint32_t *__restrict__ cg_n_out,
+                                             uint8_t (*s_bt)[NW_TC], int *s_walk)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) { s_walk[0] = tl - 1; s_walk[1] = ql - 1; s_walk[2] = 0; s_walk[3] = 0; s_walk[4] = 0; }
+    __syncthreads();
+    for (;;) {
+        const int i0 = s_walk[0], j0 = s_walk[1];
+        if (i0 < 0 || j0 < 0) break;
+        const int dtop = i0 + j0, jtop = j0;    // tile: diagonals dtop-NW_TD+1 .. dtop, columns jtop-NW_TC+1 .. jtop
+        for (int idx = tid; idx < NW_TD * NW_TC; idx += nt) {
+            const int rd = idx / NW_TC, rc = idx % NW_TC;
+            const int d = dtop - rd, j = jtop - rc, i = d - j;
+            s_bt[rd][rc] = (d >= 0 && j >= 0 && i >= 0 && i < tl) ? bt[(size_t)d * ql + j] : (uint8_t)0;
         }
         __syncthreads();
-        (void)H1;
+        if (tid == 0) {
+            int i = i0, j = j0, state = s_walk[2], n = s_walk[3];
+            bool over = s_walk[4] != 0;
+            while (i >= 0 && j >= 0) {
+                const int rd = dtop - (i + j), rc = jtop - j;
+                if (rd >= NW_TD || rc >= NW_TC) break;   // left the tile
+                const uint8_t dd = s_bt[rd][rc];
+                if (state == 0) state = dd & 7;
+                else if (!((dd >> (state + 2)) & 1)) state = 0;
+                if (state == 0) state = dd & 7;
+                uint32_t op;
+                if (state == 0) { op = 0; i--; j--; }
+                else if (state == 1 || state == 3) { op = 2; i--; }
+                else { op = 1; j--; }
+                if (n && (cg[n - 1] & 0xf) == op) cg[n - 1] += 1u << 4;
+                else if (n < ALN_CG_CAP) cg[n++] = 1u << 4 | op;
+                else over = true;
+            }
+            s_walk[0] = i; s_walk[1] = j; s_walk[2] = state; s_walk[3] = n; s_walk[4] = over ? 1 : 0;
+        }
+        __syncthreads();
     }
-    if (threadIdx.x != 0) return;
-    scores[T.out_idx] = HROW(ql + tl - 2)[ql - 1];
-    // ksw_backtrack, emitted end-to-start then reversed in place
-    uint32_t *cg = cg_all + T.cg_off;
-    int n = 0, i = tl - 1, j = ql - 1, state = 0;
-    bool over = false;
+    if (tid != 0) return;
+    int i = s_walk[0], j = s_walk[1], n = s_walk[3];
+    bool over = s_walk[4] != 0;
     auto put = [&](uint32_t op, uint32_t len) {
         if (n && (cg[n - 1] & 0xf) == op) cg[n - 1] += len << 4;
         else if (n < ALN_CG_CAP) cg[n++] = len << 4 | op;
         else over = true;
     };
-    while (i >= 0 && j >= 0) {
-        const uint8_t dd = bt[(size_t)i * ql + j];
-        if (state == 0) state = dd & 7;
-        else if (!((dd >> (state + 2)) & 1)) state = 0;
-        if (state == 0) state = dd & 7;
-        if (state == 0) { put(0, 1); i--; j--; }
-        else if (state == 1 || state == 3) { put(2, 1); i--; }
-        else { put(1, 1); j--; }
-    }
     if (i >= 0) put(2, (uint32_t)(i + 1));
     if (j >= 0) put(1, (uint32_t)(j + 1));
     for (int k2 = 0; k2 < n / 2; k2++) { uint32_t t = cg[k2]; cg[k2] = cg[n - 1 - k2]; cg[n - 1 - k2] = t; }
-    cg_n[T.out_idx] = over ? 0xffffffffu : (uint32_t)n;
-#undef HROW
-#undef EROW
-#undef FROW
-#undef E2ROW
-#undef F2ROW
+    *cg_n_out = over ? 0xffffffffu : (uint32_t)n;
+}
+
+// Queries up to QCAP bases: rolling rows in LDS (11 x QCAP x 4 B), thread t owns the query columns t, t+NT, ... for the whole
+// sweep, so its query bases sit in registers; the target bases of the rows the sweep is crossing sit in an LDS ring that the
+// workgroup refills every CH diagonals.  No global load on the per-diagonal critical path.
+template <int QCAP, int NT>
+__global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                           const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
+                                           const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
+                                           const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all,
+                                           uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
+{
+    constexpr int C = QCAP / NT;
+    constexpr int CH = QCAP >= 1024 ? 256 : 64;
+    constexpr int TB = 2 * QCAP;   // ring of target bases (power of two >= QCAP + CH)
+    __shared__ int32_t s_rows[11 * QCAP];
+    __shared__ uint8_t s_t[TB];
+    __shared__ uint8_t s_bt[NW_TD][NW_TC];
+    __shared__ int s_walk[8];
+    const NwTask T = tasks[blockIdx.x];
+    const uint32_t qw = word_off[pair_q[T.pair]], tw = word_off[pair_t[T.pair]];
+    const int lenq = read_len[pair_q[T.pair]], rev = hdr[T.pair].rev;
+    const int ql = T.ql, tl = T.tl, tid = threadIdx.x;
+    const bool two = P.q2 >= 0;
+    const NwRows R{s_rows, QCAP};
+    uint8_t *bt = bt_all + T.bt_off;
+    uint32_t qb[C];
+#pragma unroll
+    for (int m = 0; m < C; m++) { const int j = tid + m * NT; qb[m] = j < ql ? qbase(store, qw, lenq, rev, T.qs + j) : 0u; }
+    for (int d = 0; d <= ql + tl - 2; d++) {
+        if (d % CH == 0) {
+            // rows d .. d+CH-1 enter the sweep during the next CH diagonals; rows below d-ql+1 have left it
+            for (int i = d + tid; i < min(d + CH, tl); i += NT) s_t[i & (TB - 1)] = (uint8_t)fsv_base_fwd(store, tw, T.ts + i);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < C; m++) {
+            const int j = tid + m * NT, i = d - j;
+            if (j < ql && i >= 0 && i < tl) nw_cell(R, d, i, j, s_t[i & (TB - 1)], qb[m], two, P, bt, ql);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) scores[T.out_idx] = R.H(ql + tl - 2)[ql - 1];
+    nw_backtrack(bt, ql, tl, cg_all + T.cg_off, cg_n + T.out_idx, s_bt, s_walk);
+}
+
+// Any query length: rolling rows in HBM, bases fetched per cell (events with queries above NW_LDS_Q bases: rare, slow path)
+__global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                                const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
+                                                const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
+                                                const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all, int32_t *__restrict__ rows_all,
+                                                uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
+{
+    __shared__ uint8_t s_bt[NW_TD][NW_TC];
+    __shared__ int s_walk[8];
+    const NwTask T = tasks[blockIdx.x];
+    const uint32_t qw = word_off[pair_q[T.pair]], tw = word_off[pair_t[T.pair]];
+    const int lenq = read_len[pair_q[T.pair]], rev = hdr[T.pair].rev;
+    const int ql = T.ql, tl = T.tl;
+    const bool two = P.q2 >= 0;
+    const NwRows R{rows_all + T.row_off, ql};
+    uint8_t *bt = bt_all + T.bt_off;
+    for (int d = 0; d <= ql + tl - 2; d++) {
+        const int jlo = max(0, d - (tl - 1)), jhi = min(ql - 1, d);
+        for (int j = jlo + (int)threadIdx.x; j <= jhi; j += blockDim.x) {
+            const int i = d - j;
+            nw_cell(R, d, i, j, fsv_base_fwd(store, tw, T.ts + i), qbase(store, qw, lenq, rev, T.qs + j), two, P, bt, ql);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scores[T.out_idx] = R.H(ql + tl - 2)[ql - 1];
+    nw_backtrack(bt, ql, tl, cg_all + T.cg_off, cg_n + T.out_idx, s_bt, s_walk);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -420,13 +503,18 @@ int pack_pairs(fsv_ctx *ctx, AlnWs &W, const std::vector<const char *> &seq, con
 
 int run_nw(fsv_ctx *ctx, AlnWs &W, const std::vector<NwTask> &tasks, uint64_t bt_bytes, uint64_t row_words, const fsv_aln_params &P)
 {
-    // small events first in the array (stable), so that each launch covers a contiguous range and outputs keep their task index
+    // three size classes by query length, each a contiguous range of the (stably) reordered task array; outputs keep their task index
     const size_t n = tasks.size();
-    std::vector<uint32_t> order(n);
-    size_t ns = 0;
-    for (size_t i = 0; i < n; i++) if (tasks[i].ql <= 256) order[ns++] = (uint32_t)i;
-    size_t nl = ns;
-    for (size_t i = 0; i < n; i++) if (tasks[i].ql > 256) order[nl++] = (uint32_t)i;
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    size_t cls_end[3];
+    for (int c = 0; c < 3; c++) {
+        for (size_t i = 0; i < n; i++) {
+            const int cl = tasks[i].ql <= 256 ? 0 : tasks[i].ql <= NW_LDS_Q ? 1 : 2;
+            if (cl == c) order.push_back((uint32_t)i);
+        }
+        cls_end[c] = order.size();
+    }
     std::vector<NwTask> sorted(n);
     for (size_t i = 0; i < n; i++) { sorted[i] = tasks[order[i]]; sorted[i].cg_off = order[i] * (uint32_t)ALN_CG_CAP; sorted[i].out_idx = order[i]; }
     TRY(upload(ctx, W.tasks, sorted));
@@ -435,16 +523,21 @@ int run_nw(fsv_ctx *ctx, AlnWs &W, const std::vector<NwTask> &tasks, uint64_t bt
     TRY(ensure(ctx, W.cg, n * (size_t)ALN_CG_CAP * 4));
     TRY(ensure(ctx, W.cg_n, n * 4));
     TRY(ensure(ctx, W.scores, n * 4));
-    if (ns)
-        hipLaunchKernelGGL(k_nw<256>, dim3((uint32_t)ns), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+    if (cls_end[0])
+        hipLaunchKernelGGL((k_nw<256, 64>), dim3((uint32_t)cls_end[0]), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
-                           (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (int32_t *)W.rows.p, (uint32_t *)W.cg.p, (uint32_t *)W.cg_n.p,
-                           (int32_t *)W.scores.p, P);
+                           (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (uint32_t *)W.cg.p, (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
-    if (n > ns)
-        hipLaunchKernelGGL(k_nw<NW_LDS_Q>, dim3((uint32_t)(n - ns)), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p,
+    if (cls_end[1] > cls_end[0])
+        hipLaunchKernelGGL((k_nw<NW_LDS_Q, 1024>), dim3((uint32_t)(cls_end[1] - cls_end[0])), dim3(1024), 0, ctx->stream, (const uint32_t *)W.store.p,
                            (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
-                           (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + ns, (uint8_t *)W.bt.p, (int32_t *)W.rows.p, (uint32_t *)W.cg.p,
+                           (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + cls_end[0], (uint8_t *)W.bt.p, (uint32_t *)W.cg.p,
+                           (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
+    FSV_HIP(ctx, hipGetLastError());
+    if (cls_end[2] > cls_end[1])
+        hipLaunchKernelGGL(k_nw_any, dim3((uint32_t)(cls_end[2] - cls_end[1])), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p,
+                           (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
+                           (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + cls_end[1], (uint8_t *)W.bt.p, (int32_t *)W.rows.p, (uint32_t *)W.cg.p,
                            (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
     return FSV_OK;
@@ -499,7 +592,7 @@ extern "C" int fsv_nw(fsv_ctx *ctx, const char *target, int32_t tl, const char *
     TRY(upload(ctx, W.pair_t, std::vector<uint32_t>{1u}));
     std::vector<NwTask> tasks(1);
     tasks[0] = NwTask{0u, 0, ql, 0, tl, 0u, 0ull, 0ull, 0u, 0u};
-    TRY(run_nw(ctx, W, tasks, (uint64_t)tl * ql, ql > NW_LDS_Q ? 11ull * ql : 0, P));
+    TRY(run_nw(ctx, W, tasks, (uint64_t)(tl + ql) * ql, ql > NW_LDS_Q ? 11ull * ql : 0, P));
     uint32_t n = 0; int32_t sc = 0;
     FSV_HIP(ctx, hipMemcpyAsync(&n, W.cg_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     FSV_HIP(ctx, hipMemcpyAsync(&sc, W.scores.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -648,7 +741,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
             t.out_idx = 0; t.pad = 0;
             t.pair = p; t.qs = ev.qs; t.ql = ev.qe - ev.qs + 1; t.ts = ev.ts; t.tl = ev.te - ev.ts + 1;
             t.cg_off = (uint32_t)(tasks.size() * ALN_CG_CAP); t.bt_off = bt; t.row_off = rows;
-            bt += (uint64_t)t.ql * t.tl;
+            bt += (uint64_t)(t.ql + t.tl) * t.ql;   // diagonal-major traceback bytes
             if (t.ql > NW_LDS_Q) rows += 11ull * t.ql;
             W.stats.dp_cells += (uint64_t)t.ql * t.tl;
             W.stats.algo_bytes += (uint64_t)(t.ql + t.tl + 3) / 4;

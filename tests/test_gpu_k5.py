@@ -92,3 +92,27 @@ def test_k5_reverse_strand(ctx):
     ypad = y_fwd[15: 15 + 405]
     assert (int(r["end_site"]), int(r["err"])) == O.bpm(x, ypad, 15)
     assert int(r["err"]) == 1
+
+
+def test_k5_exact_diagonal_shortcut_in_repeats(ctx):
+    """windows that match exactly on the predicted diagonal take a shortcut in the kernel; in a tandem repeat other end
+    sites reach distance 0 too, and the reference's end-site rule must still come out (oracle = reference restatement)"""
+    rng = random.Random(11)
+    cases = []
+    for i in range(400):
+        unit = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 7)))
+        n = rng.choice([375, 375, 200, 16, 17, 33])
+        k = rng.choice([0, 1, 8, 15]) if n >= 33 else rng.choice([0, 1])
+        core = (unit * (2 * (n + 2 * k) // len(unit) + 4))
+        x = core[k: k + n]
+        y = core[: n + 2 * k]
+        if i % 5 == 0:   # one substitution somewhere: must not take the shortcut
+            p = rng.randrange(n)
+            x = x[:p] + "ACGT"[("ACGT".index(x[p]) + 1) % 4] + x[p + 1:]
+        cases.append({"k": k, "x": x, "y": y})
+    cases = [c for c in cases if usable(c)]
+    words, tasks = tasks_from_cases(cases)
+    res = ctx.bpm_windows(words, tasks)
+    for c, r in zip(cases, res):
+        site, err = O.bpm(c["x"], c["y"], c["k"])
+        assert (int(r["err"]), int(r["end_site"]) if err >= 0 else -1) == (err, site if err >= 0 else -1), c
