@@ -23,7 +23,7 @@ namespace {
 #define NW_LDS_Q 2048        // query length up to which the rolling DP rows live in LDS
 #define NW_NEG (-(1 << 29))
 
-struct AlnHeader { int32_t qbeg, tbeg, qend, tend, n_events, n_chain, rev, status; };
+struct AlnHeader { int32_t qbeg, tbeg, qend, tend, n_events, n_chain, rev, status; uint32_t ev_off, pad; };   // ev_off: first event in the packed list
 struct AlnEvent { int32_t qs, qe, ts, te; };   // inclusive
 struct NwTask { uint32_t pair; int32_t qs, ql, ts, tl; uint32_t cg_off; uint64_t bt_off; uint64_t row_off; uint32_t out_idx, pad; };
 
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
     const int lenq = read_len[rq];
     const int nq = (int)mz_cnt[rq], nt = (int)mz_cnt[rt];
     const fsv_mz *mq = mz + mz_off[rq] + nq, *mt = mz + mz_off[rt]; // contig: position-sorted copy, reference: hash-sorted
-    AlnHeader h; h.qbeg = h.tbeg = h.qend = h.tend = 0; h.n_events = 0; h.n_chain = 0; h.rev = 0; h.status = 1;
+    AlnHeader h; h.qbeg = h.tbeg = h.qend = h.tend = 0; h.n_events = 0; h.n_chain = 0; h.rev = 0; h.status = 1; h.ev_off = 0; h.pad = 0;
     int n = 0, nrev = 0, nfwd = 0;
     for (int base = 0; base < nq; base += 64) {
         int i = base + lane;
@@ -144,7 +144,8 @@ __device__ __forceinline__ uint32_t qbase(const uint32_t *__restrict__ store, ui
 __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                                     const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                     const uint32_t *__restrict__ pair_t, const uint64_t *__restrict__ chain,
-                                                    AlnHeader *__restrict__ hdr, AlnEvent *__restrict__ events, fsv_aln_params P)
+                                                    AlnHeader *__restrict__ hdr, AlnEvent *__restrict__ events, AlnEvent *__restrict__ packed,
+                                                    uint32_t *__restrict__ n_packed, fsv_aln_params P)
 {
     __shared__ uint8_t s_cls[ALN_AMAX];
     const uint32_t p = blockIdx.x;
@@ -208,6 +209,11 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
 #undef CQ
 #undef CT
     h.qbeg = qbeg; h.tbeg = tbeg; h.qend = qend; h.tend = tend; h.n_events = ne; h.status = status;
+    // the pair's events also go to a list packed over all pairs (any order; the header says where): one D2H copy for the batch
+    if (status == 0 && ne > 0) {
+        h.ev_off = atomicAdd(n_packed, (uint32_t)ne);
+        for (int e = 0; e < ne; e++) packed[h.ev_off + e] = ev[e];
+    }
     hdr[p] = h;
 }
 
@@ -397,9 +403,9 @@ __global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ sto
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 struct AlnWs {
-    DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, tasks, bt, rows, cg, cg_n, scores;
+    DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, ev_packed, ev_count, tasks, bt, rows, cg, cg_n, scores;
     fsv_aln_stats stats;
-    std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
+    std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
 };
 
 void aln_ws_free(fsv_ctx *ctx)
@@ -712,19 +718,23 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     trace("chain");
     W.stats.ms_chain = tchain.stop();
     Timer tev(ctx);
+    TRY(ensure(ctx, W.ev_packed, (size_t)np * ALN_EV_CAP * sizeof(AlnEvent)));
+    TRY(ensure(ctx, W.ev_count, 16));
+    FSV_HIP(ctx, hipMemsetAsync(W.ev_count.p, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_aln_events, dim3(np), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
                        (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const uint64_t *)W.chain.p,
-                       (AlnHeader *)W.hdr.p, (AlnEvent *)W.events.p, P);
+                       (AlnHeader *)W.hdr.p, (AlnEvent *)W.events.p, (AlnEvent *)W.ev_packed.p, (uint32_t *)W.ev_count.p, P);
     FSV_HIP(ctx, hipGetLastError());
     std::vector<AlnHeader> hdr(np);
-    std::vector<AlnEvent> events((size_t)np * ALN_EV_CAP);
+    uint32_t n_ev = 0;
     FSV_HIP(ctx, hipMemcpyAsync(hdr.data(), W.hdr.p, (size_t)np * sizeof(AlnHeader), hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipMemcpyAsync(&n_ev, W.ev_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint32_t p = 0; p < np; p++)
-        if (hdr[p].status == 0 && hdr[p].n_events > 0)
-            FSV_HIP(ctx, hipMemcpyAsync(events.data() + (size_t)p * ALN_EV_CAP, (const AlnEvent *)W.events.p + (size_t)p * ALN_EV_CAP,
-                                        (size_t)hdr[p].n_events * sizeof(AlnEvent), hipMemcpyDeviceToHost, ctx->stream));
-    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<AlnEvent> events(n_ev);
+    if (n_ev) {
+        FSV_HIP(ctx, hipMemcpyAsync(events.data(), W.ev_packed.p, (size_t)n_ev * sizeof(AlnEvent), hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     trace("events");
     W.stats.ms_events = tev.stop();
     // DP tasks
@@ -736,7 +746,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
         first_task[p] = (uint32_t)tasks.size();
         if (pre_status[p] != 0 || hdr[p].status != 0) continue;
         for (int e = 0; e < hdr[p].n_events; e++) {
-            const AlnEvent &ev = events[(size_t)p * ALN_EV_CAP + e];
+            const AlnEvent &ev = events[(size_t)hdr[p].ev_off + e];
             NwTask t;
             t.out_idx = 0; t.pad = 0;
             t.pair = p; t.qs = ev.qs; t.ql = ev.qe - ev.qs + 1; t.ts = ev.ts; t.tl = ev.te - ev.ts + 1;
@@ -749,13 +759,25 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
         }
     }
     first_task[np] = (uint32_t)tasks.size();
-    std::vector<uint32_t> cg_n(tasks.size()), cg(tasks.size() * (size_t)ALN_CG_CAP);
+    // CIGAR runs of the events: nearly all have a handful; the first CG_HEAD runs of every task come back in one strided copy,
+    // longer ones are fetched individually
+    constexpr uint32_t CG_HEAD = 8;
+    std::vector<uint32_t> cg_n(tasks.size()), cg_head(tasks.size() * (size_t)CG_HEAD);
+    std::vector<std::vector<uint32_t>> cg_long(tasks.size());
     if (!tasks.empty()) {
         if (tasks.size() * (uint64_t)ALN_CG_CAP >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "too many DP events in one batch");
         TRY(run_nw(ctx, W, tasks, bt, rows, P));
         FSV_HIP(ctx, hipMemcpyAsync(cg_n.data(), W.cg_n.p, tasks.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        FSV_HIP(ctx, hipMemcpyAsync(cg.data(), W.cg.p, cg.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipMemcpy2DAsync(cg_head.data(), CG_HEAD * 4, W.cg.p, (size_t)ALN_CG_CAP * 4, CG_HEAD * 4, tasks.size(), hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool any = false;
+        for (size_t t = 0; t < tasks.size(); t++)
+            if (cg_n[t] != 0xffffffffu && cg_n[t] > CG_HEAD) {
+                cg_long[t].resize(cg_n[t]);
+                FSV_HIP(ctx, hipMemcpyAsync(cg_long[t].data(), (const uint32_t *)W.cg.p + t * (size_t)ALN_CG_CAP, (size_t)cg_n[t] * 4, hipMemcpyDeviceToHost, ctx->stream));
+                any = true;
+            }
+        if (any) FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     trace("dp");
     W.stats.ms_dp = tdp.stop();
@@ -773,7 +795,8 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
                 const NwTask &T = tasks[t];
                 push_cg(c, 0, (uint32_t)(T.qs - mstart));
                 if (cg_n[t] == 0xffffffffu) { st = FSV_ECAP; break; }
-                for (uint32_t i = 0; i < cg_n[t]; i++) { uint32_t v = cg[(size_t)t * ALN_CG_CAP + i]; push_cg(c, v & 0xf, v >> 4); }
+                const uint32_t *runs = cg_n[t] > CG_HEAD ? cg_long[t].data() : cg_head.data() + (size_t)t * CG_HEAD;
+                for (uint32_t i = 0; i < cg_n[t]; i++) { uint32_t v = runs[i]; push_cg(c, v & 0xf, v >> 4); }
                 mstart = T.qs + T.ql;
             }
             if (st == 0) {
