@@ -150,10 +150,11 @@ def main():
         try:
             pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json"))
             pk = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))["kernels"]
-            alias = {"k_sketch": "k_sketch_fast", "k5_bpm": "k5_bpm_kernel", "k_uniq": "k_uniq<4096>"}
-            e = pk.get(alias.get(dom[0], dom[0])) if dom[0] else None
-            if e:
-                traffic = int((e["fetch_bytes_x2"] + e["write_bytes"]) / max(1, e["launches"]))
+            alias = {"k_sketch": "k_sketch_fast", "k5_bpm": "k5_bpm_kernel"}
+            name = alias.get(dom[0], dom[0]) if dom[0] else None
+            es = [v for k2, v in pk.items() if k2 == name or k2.startswith(name + "<")] if name else []   # template instances together
+            if es:
+                traffic = int(sum(e["fetch_bytes_x2"] + e["write_bytes"] for e in es) / max(1, sum(e["launches"] for e in es)))
         except Exception:
             traffic = None
         if dom[0]:

@@ -20,7 +20,7 @@ namespace {
 #define ALN_AMAX 8192
 #define ALN_EV_CAP 2048      // events per pair
 #define ALN_CG_CAP 1024      // CIGAR runs per event
-#define NW_LDS_Q 2048        // query length up to which the rolling DP rows live in LDS
+#define NW_LDS_Q 3072        // query length up to which the rolling DP rows live in LDS (11 x 4 B x 3072 = 132 KB of the CU's 160)
 #define NW_NEG (-(1 << 29))
 
 struct AlnHeader { int32_t qbeg, tbeg, qend, tend, n_events, n_chain, rev, status; uint32_t ev_off, pad; };   // ev_off: first event in the packed list
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, c
 {
     constexpr int C = QCAP / NT;
     constexpr int CH = QCAP >= 1024 ? 256 : 64;
-    constexpr int TB = 2 * QCAP;   // ring of target bases (power of two >= QCAP + CH)
+    constexpr int TB = QCAP >= 2048 ? 4096 : 2 * QCAP;   // ring of target bases (power of two >= QCAP + CH)
     __shared__ int32_t s_rows[11 * QCAP];
     __shared__ uint8_t s_t[TB];
     __shared__ uint8_t s_bt[NW_TD][NW_TC];
@@ -364,8 +364,11 @@ __global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, c
             const int j = tid + m * NT, i = d - j;
             if (j < ql && i >= 0 && i < tl) nw_cell(R, d, i, j, s_t[i & (TB - 1)], qb[m], two, P, bt, ql);
         }
-        __syncthreads();
+        // the next diagonal needs this one's LDS rows, not its traceback bytes: __syncthreads() would also drain the global
+        // stores (vmcnt), a memory round trip per diagonal; they are drained once, by the barrier in front of the backtrack
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    __syncthreads();
     if (tid == 0) scores[T.out_idx] = R.H(ql + tl - 2)[ql - 1];
     nw_backtrack(bt, ql, tl, cg_all + T.cg_off, cg_n + T.out_idx, s_bt, s_walk);
 }
