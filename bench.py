@@ -176,6 +176,10 @@ def main():
             "kernel_ms": {k: [round(v["ms"], 2), v["launches"]] for k, v in kern.items()},
             "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},
             "host_ms": res.host_ms,
+            # companion compute figure: banded DP column-steps of K5 + K6 (windows x their x_len, 31-row bands)
+            "dp": {"column_steps_per_step": int(a.get("dp_columns", 0)), "windows_per_step": int(a.get("n_windows", 0)),
+                   "G_column_steps_per_s": round(a.get("dp_columns", 0) * args.steps / dt / 1e9, 2),
+                   "GCUPS_band31": round(a.get("dp_columns", 0) * 31 * args.steps / dt / 1e9, 1)},
             "algo_bytes_per_region": int((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) / n),
             "hbm_roofline_whole_path": {"GBps": round((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) * args.steps / dt / 1e9 * 1.0, 3), "frac": round((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) * args.steps / dt / 8e12, 6)},
             "roofline": roof,

@@ -192,6 +192,47 @@ def shard_regions(work: Sequence[int], world_size: int) -> List[List[int]]:
     return out
 
 
+class RegionQueue:
+    """Region -> rank scheduling for uneven region sets (real BEDs span 14 kb - 1.1 Mb): regions sorted by
+    work, the heavy head dealt statically (shard_regions), the tail handed out in batches from one shared cursor -- a
+    counter in the process group's key-value store (`Store.add` is atomic), not a data-path collective.  Every rank
+    iterates `batches()`; a batch is a list of region indices.  Without an initialised process group it degrades to one
+    rank that takes everything."""
+
+    def __init__(self, work: Sequence[int], batch: int = 64, static_fraction: float = 0.75, store=None, rank: Optional[int] = None,
+                 world_size: Optional[int] = None, key: str = "fsv_region_cursor"):
+        import torch.distributed as dist
+        if rank is None:
+            live = dist.is_available() and dist.is_initialized()
+            rank, world_size = (dist.get_rank(), dist.get_world_size()) if live else (0, 1)
+            if live and store is None and world_size > 1:
+                store = dist.distributed_c10d._get_default_store()
+        self.rank, self.world, self.store, self.key, self.batch = rank, world_size, store, key, max(1, batch)
+        order = sorted(range(len(work)), key=lambda i: (-work[i], i))
+        n_static = len(order) if self.world == 1 else int(len(order) * static_fraction)
+        head = order[:n_static]
+        mine = shard_regions([work[i] for i in head], self.world)[self.rank]
+        self.static = [head[i] for i in mine]
+        self.tail = order[n_static:]
+
+    def batches(self):
+        for b in range(0, len(self.static), self.batch):
+            yield self.static[b:b + self.batch]
+        if not self.tail:
+            return
+        n_batches = (len(self.tail) + self.batch - 1) // self.batch
+        while True:
+            # Store.add returns the value after the addition: ticket k (0-based) = returned - 1
+            k = (self.store.add(self.key, 1) - 1) if self.store is not None else self._local_next()
+            if k >= n_batches:
+                return
+            yield self.tail[k * self.batch:(k + 1) * self.batch]
+
+    def _local_next(self):
+        self._cur = getattr(self, "_cur", -1) + 1
+        return self._cur
+
+
 def _vcf_key(line: str):
     d = line.split('\t', 2)
     c = d[0]

@@ -51,3 +51,44 @@ def test_gather_vcf_gloo_world2():
 def test_gather_vcf_single_process_sorts():
     lines = ["chr21\t9\tx\tA\tAT\t20\tPASS\tSVLEN=1;SVTYPE=INS\tGT\t0/1\n", "chr21\t3\ty\tA\tAT\t20\tPASS\tSVLEN=1;SVTYPE=INS\tGT\t0/1\n"]
     assert [l.split('\t')[2] for l in pipeline.gather_vcf(lines)] == ["y", "x"]
+
+
+def _queue_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
+    rng = random.Random(4)
+    work = [rng.choice([14_000, 26_000, 50_000, 1_100_000]) for _ in range(1000)]   # widths like the whole-genome BED (config 4)
+    rq = pipeline.RegionQueue(work, batch=16)
+    got = []
+    for b in rq.batches():
+        got += b
+        if rank == 1:
+            import time
+            time.sleep(0.002)          # a slow rank: the other one should drain most of the tail
+    q.put((rank, got, len(rq.static)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_region_queue_gloo_world2_covers_every_region_once():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_queue_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    allr = sorted(i for _, got, _ in res for i in got)
+    assert allr == list(range(1000))                       # every region exactly once
+    by = {r: (len(got), ns) for r, got, ns in res}
+    assert by[0][0] - by[0][1] > by[1][0] - by[1][1]      # the fast rank took more of the shared tail
+
+
+def test_region_queue_single_process():
+    rq = pipeline.RegionQueue([3, 1, 2, 9, 9], batch=2)
+    assert sorted(i for b in rq.batches() for i in b) == [0, 1, 2, 3, 4]
