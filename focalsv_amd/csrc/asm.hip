@@ -39,7 +39,8 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
 
 struct AsmWs {
     DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
-        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+    ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -51,7 +52,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -223,12 +224,13 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
         }
     }
     // LDS per pair = 24 B x the longest minimizer list of the batch (rounded up to 64, at most FSV_AMAX): more pairs per CU
-    A.upair_tab = (const uint4 *)W.upair_tab.p;
+    A.upair_tab = (const uint4 *)W.upair_tab.p; A.pair_list = nullptr;
     A.amax = (int32_t)std::min<uint32_t>(FSV_AMAX, std::max<uint32_t>(64u, (max_cnt + 63u) / 64u * 64u));
     W.kt.begin(ctx, KN_CHAIN, chain_bytes);
     hipLaunchKernelGGL(k_chain, dim3(B.n_upairs), dim3(64), (size_t)A.amax * 24, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
+    W.last_chain = A;
     W.stats.ms_chain += tc.stop();
     return FSV_OK;
 }
@@ -244,24 +246,37 @@ void layout_set(const int32_t *len, uint32_t n, const fsv_hit *hits, uint32_t n_
     std::vector<uint8_t> contained(n, 0), used(n, 0);
     std::vector<int32_t> succ(2 * n, -1), sovl(2 * n, 0), pred(2 * n, -1);
     fallback = false;
+    // ma_hit2arc (Overlaps.h:178-246) from the query's side of every hit; the mirrored hit supplies the other side.
+    // tl5 / tl3 = overhang of the target in front of / behind the overlap on the query's strand (y is strand-corrected).
+    struct Geom { int ql, tl, qs, qe, tl5, tl3, ext5, ext3, tspan; bool internal; };
+    auto geom = [&](const fsv_hit &h) {
+        Geom g;
+        g.ql = len[h.q]; g.tl = len[h.t]; g.qs = h.x_s; g.qe = h.x_e + 1; g.tl5 = h.y_s; g.tl3 = g.tl - (h.y_e + 1);
+        g.ext5 = std::min(g.qs, g.tl5); g.ext3 = std::min(g.ql - g.qe, g.tl3); g.tspan = h.y_e + 1 - h.y_s;
+        g.internal = g.ext5 > 1000 || g.ext3 > 1000 || (g.qe - g.qs) < (g.qe - g.qs + g.ext5 + g.ext3) * 0.8f || g.tspan < (g.tspan + g.ext5 + g.ext3) * 0.8f;
+        return g;
+    };
     for (uint32_t i = 0; i < n_hit; i++) {
         const fsv_hit &h = hits[i];
-        bool qfull = h.x_s == 0 && h.x_e == len[h.q] - 1, tfull = h.y_s == 0 && h.y_e == len[h.t] - 1;
-        if (qfull && tfull) { if (h.q > h.t) contained[h.q] = 1; }
-        else if (qfull) contained[h.q] = 1;
-    }
-    for (uint32_t i = 0; i < n_hit; i++) {
-        const fsv_hit &h = hits[i];
-        if (contained[h.q] || contained[h.t]) continue;
-        const int L = h.x_e - h.x_s + 1;
-        int a, b;
-        if (h.x_e == len[h.q] - 1 && h.y_s == 0 && h.x_s > 0) { a = 2 * (int)h.q; b = 2 * (int)h.t + h.rev; }
-        else if (h.x_s == 0 && h.y_e == len[h.t] - 1 && h.x_e < len[h.q] - 1) { a = 2 * (int)h.t + h.rev; b = 2 * (int)h.q; }
-        else continue;
-        for (int pass = 0; pass < 2; pass++) {
-            const int from = pass ? (b ^ 1) : a, to = pass ? (a ^ 1) : b;
-            if (L > sovl[from] || (L == sovl[from] && succ[from] >= 0 && to < succ[from])) { succ[from] = to; sovl[from] = L; }
+        const Geom g = geom(h);
+        if (g.internal) continue;
+        if (g.qs <= g.tl5 && g.ql - g.qe <= g.tl3) {                       // MA_HT_QCONT
+            if (g.qs >= g.tl5 && g.ql - g.qe >= g.tl3) { if (h.q > h.t) contained[h.q] = 1; } // mutual: keep the lower index
+            else contained[h.q] = 1;
         }
+    }
+    for (uint32_t v = 0; v < 2 * n; v++) sovl[v] = 0x7fffffff;
+    for (uint32_t i = 0; i < n_hit; i++) {
+        const fsv_hit &h = hits[i];
+        const Geom g = geom(h);
+        if (g.internal || contained[h.q] || contained[h.t]) continue;
+        if ((g.qs <= g.tl5 && g.ql - g.qe <= g.tl3) || (g.qs >= g.tl5 && g.ql - g.qe >= g.tl3)) continue; // containments
+        if (g.qe - g.qs + g.ext5 + g.ext3 < 50 || g.tspan + g.ext5 + g.ext3 < 50) continue;                 // MA_HT_SHORT_OVLP
+        int from, to, l;
+        if (g.qs > g.tl5) { from = 2 * (int)h.q; to = 2 * (int)h.t + (int)h.rev; l = g.qs - g.tl5; }          // (q,+) -> (t,rev)
+        else { from = 2 * (int)h.q + 1; to = 2 * (int)h.t + (h.rev ? 0 : 1); l = (g.ql - g.qe) - g.tl3; }      // (q,-) -> (t,!rev)
+        // every node keeps its nearest successor: the smallest node length = the longest overlap
+        if (l < sovl[from] || (l == sovl[from] && succ[from] >= 0 && to < succ[from])) { succ[from] = to; sovl[from] = l; }
     }
     for (uint32_t v = 0; v < 2 * n; v++) { int w = succ[v]; if (w >= 0 && succ[w ^ 1] != (int)(v ^ 1)) succ[v] = -1; }
     for (uint32_t v = 0; v < 2 * n; v++) if (succ[v] >= 0) pred[succ[v]] = (int)v;
@@ -277,15 +292,13 @@ void layout_set(const int32_t *len, uint32_t n, const fsv_hit *hits, uint32_t n_
             for (int w = (int)v; w >= 0 && !used[w >> 1]; w = succ[w]) {
                 used[w >> 1] = 1;
                 const bool more = succ[w] >= 0 && !used[succ[w] >> 1];
-                c.push_back(Piece{(uint32_t)(w >> 1), (uint32_t)(w & 1), (uint32_t)(more ? len[w >> 1] - sovl[w] : len[w >> 1])});
+                c.push_back(Piece{(uint32_t)(w >> 1), (uint32_t)(w & 1), (uint32_t)(more ? sovl[w] : len[w >> 1])});
             }
             contigs.push_back(std::move(c));
         }
-    if (contigs.empty()) {
-        int best = -1;
-        for (uint32_t i = 0; i < n; i++) if (!contained[i] && (best < 0 || len[i] > len[best])) best = (int)i;
-        if (best >= 0) { contigs.push_back({Piece{(uint32_t)best, 0u, (uint32_t)len[best]}}); fallback = true; }
-    }
+    // no fall-back to a single read: hifiasm's asg_cut_tip (Overlaps.cpp:4666-4709) removes dead-end chains of fewer than four
+    // reads, a lone read included, and writes no contig for such a set
+    fallback = contigs.empty();
 }
 
 } // namespace
@@ -294,7 +307,7 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
 {
     if (!p) return;
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
-    p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 2;
+    p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
 }
 
 extern "C" int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap)
@@ -505,6 +518,13 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     TRY(upload(ctx, W.len, len));
     TRY(upload(ctx, W.mz_off, G.mz_off));
     TRY(ensure(ctx, W.tasks, 64));
+    // what the last correction round verified (coordinates on the reads as they were before that round) -- the final pass
+    // accepts inexact overlaps against it; the slots are about to be overwritten
+    const bool have_prev = P.n_rounds > 0 && B.n_pairs > 0;
+    if (have_prev) {
+        TRY(ensure(ctx, W.ovl_prev, (size_t)B.n_pairs * sizeof(fsv_ovl)));
+        FSV_HIP(ctx, hipMemcpyAsync(W.ovl_prev.p, W.ovl.p, (size_t)B.n_pairs * sizeof(fsv_ovl), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0));
     trace("overlaps");
     const fsv_hit *hraw = nullptr;
@@ -514,11 +534,35 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         TRY(ensure(ctx, W.set_hits, (size_t)(2 * B.n_sets + 2) * 4));
         FSV_HIP(ctx, hipMemsetAsync(W.set_hits.p, 0, (size_t)B.n_sets * 4, ctx->stream));
         W.kt.begin(ctx, KN_EXACT, (uint64_t)B.n_pairs * sizeof(fsv_ovl) + W.stats.n_pairs * 0);
+        TRY(ensure(ctx, W.exact_flag, (size_t)B.n_upairs + 16));
         hipLaunchKernelGGL(k_exact, dim3(B.n_upairs), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
                            (const uint32_t *)W.read_set.p, (const uint32_t *)W.pair_base.p, (const uint4 *)W.upair_tab.p, (const fsv_ovl *)W.ovl.p,
-                           (fsv_hit *)W.hits.p, (uint32_t *)W.set_hits.p);
+                           (fsv_hit *)W.hits.p, (uint32_t *)W.set_hits.p, (uint8_t *)W.exact_flag.p);
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);
+        if (have_prev) {
+            // pairs without an exact overlap that the last correction round had verified: gapped re-chain, accept per direction
+            TRY(ensure(ctx, W.inexact_list, (size_t)B.n_upairs * 4 + 16));
+            uint32_t *n_list_dev = (uint32_t *)W.counters.p + 3;
+            FSV_HIP(ctx, hipMemsetAsync(n_list_dev, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_inexact_list, dim3(fsv_grid_for(B.n_upairs, 256)), dim3(256), 0, ctx->stream, (const uint4 *)W.upair_tab.p,
+                               (const uint8_t *)W.exact_flag.p, (const fsv_ovl *)W.ovl_prev.p, B.n_upairs, (uint32_t *)W.inexact_list.p, n_list_dev);
+            FSV_HIP(ctx, hipGetLastError());
+            uint32_t n_list = 0;
+            FSV_HIP(ctx, hipMemcpyAsync(&n_list, n_list_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (n_list) {
+                ChainArgs A2 = W.last_chain;
+                A2.bw = 1; A2.emit_tasks = 0; A2.pair_list = (const uint32_t *)W.inexact_list.p;
+                hipLaunchKernelGGL(k_chain, dim3(n_list), dim3(64), (size_t)A2.amax * 24, ctx->stream, A2);
+                FSV_HIP(ctx, hipGetLastError());
+                hipLaunchKernelGGL(k_accept_inexact, dim3(fsv_grid_for(2 * n_list, 256)), dim3(256), 0, ctx->stream, (const uint4 *)W.upair_tab.p,
+                                   (const uint32_t *)W.inexact_list.p, n_list, (const fsv_ovl *)W.ovl.p, (const fsv_ovl *)W.ovl_prev.p,
+                                   (const uint32_t *)W.read_set.p, (const uint32_t *)W.pair_base.p, (fsv_hit *)W.hits.p, (uint32_t *)W.set_hits.p);
+                FSV_HIP(ctx, hipGetLastError());
+            }
+            W.stats.n_inexact_candidates = n_list;
+        }
         // per-set counts -> offsets; the segments are packed on the device and come back in one copy, already grouped by set.
         // The order inside a set depends on atomics and does not matter: the layout's containment marks and "longest arc,
         // smallest target on ties" choices are order-independent.

@@ -322,6 +322,7 @@ struct ChainArgs {
     const uint32_t *set_start;   // n_sets + 1
     const uint32_t *pair_base;   // n_sets + 1: ordered-pair slots
     const uint32_t *upair_base;  // n_sets + 1: unordered pairs (one block each)
+    const uint32_t *pair_list;   // optional: block b works on unordered pair pair_list[b] (nullptr: pair b)
     const uint4 *upair_tab;      // per unordered pair: {first read of the set, q | t << 16, slot (q,t), slot (t,q)}  (k_pair_tab)
     int32_t amax;                // anchors per pair held in LDS (multiple of 64, <= FSV_AMAX): sizes the dynamic LDS
     const fsv_mz *mz;
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     uint16_t *const s_chain = (uint16_t *)(s_raw + 22 * (size_t)AMAX);
     int32_t *const s_f = s_dp, *const s_ind = s_dp + AMAX, *const s_sl = s_dp + 2 * AMAX;
     const int lane = threadIdx.x;
-    const uint4 pt = A.upair_tab[blockIdx.x];
+    const uint4 pt = A.upair_tab[A.pair_list ? A.pair_list[blockIdx.x] : blockIdx.x];
     const uint32_t q = pt.y & 0xffffu, t = pt.y >> 16;
     const uint32_t p = pt.z, pm = pt.w;     // ordered slots (q, t) and (t, q)
     const uint32_t rq = pt.x + q, rt = pt.x + t;
@@ -1165,11 +1166,13 @@ struct fsv_hit { uint32_t q, t; int32_t x_s, x_e, y_s, y_e; uint32_t rev, slot; 
 __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                               const int32_t *__restrict__ read_len, const uint32_t *__restrict__ read_set,
                                               const uint32_t *__restrict__ pair_base, const uint4 *__restrict__ upair_tab,
-                                              const fsv_ovl *__restrict__ ovl, fsv_hit *__restrict__ hits, uint32_t *__restrict__ set_hits)
+                                              const fsv_ovl *__restrict__ ovl, fsv_hit *__restrict__ hits, uint32_t *__restrict__ set_hits,
+                                              uint8_t *__restrict__ exact_flag)
 {
     const uint4 pt = upair_tab[blockIdx.x];
     const int lane = threadIdx.x;
     fsv_ovl o = ovl[pt.z];
+    if (lane == 0) exact_flag[blockIdx.x] = 0;
     if (!o.valid) return;
     const uint32_t rq = pt.x + o.q, rt = pt.x + o.t;
     const int L = o.x_e - o.x_s + 1;
@@ -1196,6 +1199,7 @@ __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store
         same = !__any(acc != 0u);
     }
     if (!same) return;
+    if (lane == 0) exact_flag[blockIdx.x] = 1;
     // exact hits are gathered per set for the host layout (a few per cent of the slots): the set's hit segment starts at its
     // first ordered-pair slot and a per-set counter hands out places -- one atomic per pair, spread over the sets' addresses
     const uint32_t s = read_set[pt.x];
@@ -1219,6 +1223,38 @@ __global__ __launch_bounds__(256) void k_hits_compact(const fsv_hit *__restrict_
     const uint32_t *src = (const uint32_t *)(hits + pair_base[s]);
     uint32_t *dst = (uint32_t *)(out + hit_first[s]);
     for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+// Inexact overlaps for the layout (update_overlaps, Assembly.cpp:975-1083 as called by worker_ov_final :1284-1306): a pair
+// without an exact overlap whose overlap the last correction round verified is chained again with hifiasm's final bandwidth
+// (0.001, gapped coordinates) and accepted per direction when strand and coordinates agree with the verified overlap (both
+// ends of either read within 10 % of the longer span).
+__global__ void k_inexact_list(const uint4 *__restrict__ upair_tab, const uint8_t *__restrict__ exact_flag, const fsv_ovl *__restrict__ prev,
+                               uint32_t n_upairs, uint32_t *__restrict__ list, uint32_t *__restrict__ n_list)
+{
+    const uint32_t up = blockIdx.x * blockDim.x + threadIdx.x;
+    if (up >= n_upairs || exact_flag[up]) return;
+    const uint4 pt = upair_tab[up];
+    const fsv_ovl a = prev[pt.z], b = prev[pt.w];
+    if ((a.valid && a.is_match) || (b.valid && b.is_match)) list[atomicAdd(n_list, 1u)] = up;
+}
+
+__global__ void k_accept_inexact(const uint4 *__restrict__ upair_tab, const uint32_t *__restrict__ list, uint32_t n_list,
+                                 const fsv_ovl *__restrict__ ovl, const fsv_ovl *__restrict__ prev, const uint32_t *__restrict__ read_set,
+                                 const uint32_t *__restrict__ pair_base, fsv_hit *__restrict__ hits, uint32_t *__restrict__ set_hits)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n_list) return;
+    const uint4 pt = upair_tab[list[i >> 1]];
+    const uint32_t slot = (i & 1) ? pt.w : pt.z;
+    const fsv_ovl o = ovl[slot], pv = prev[slot];
+    if (!o.valid || !pv.valid || !pv.is_match || pv.rev != o.rev) return;
+    const int lx = pv.x_e - pv.x_s + 1, ly = pv.y_e - pv.y_s + 1, L = max(lx, ly) / 10;
+    const bool ok = (abs(o.x_s - pv.x_s) < L && abs(o.x_e - pv.x_e) < L) || (abs(o.y_s - pv.y_s) < L && abs(o.y_e - pv.y_e) < L);
+    if (!ok) return;
+    const uint32_t s = read_set[pt.x];
+    fsv_hit h; h.q = o.q; h.t = o.t; h.x_s = o.x_s; h.x_e = o.x_e; h.y_s = o.y_s; h.y_e = o.y_e; h.rev = o.rev; h.slot = slot;
+    hits[pair_base[s] + atomicAdd(&set_hits[s], 1u)] = h;
 }
 
 // ------------------------------------------------------------------------------------------------ k_stitch

@@ -203,14 +203,17 @@ def make_region(i: int, width: int = 50_000, profile: str = "hifi", depth_per_ha
     if homo_del:
         ev2.append((dpos, "DEL", dlen))
     if i % 4 == 0:
-        while True:
-            p2 = int(rng.integers(edge, width - edge))
-            if abs(p2 - dpos) >= 3000 and abs(p2 - dpos - dlen) >= 3000 and abs(p2 - ipos) >= 3000:
+        p2 = None
+        for _ in range(10000):   # narrow windows may have no room 3 kb away from both hap1 events: then hap2 gets no private INS
+            c = int(rng.integers(edge, width - edge))
+            if abs(c - dpos) >= 3000 and abs(c - dpos - dlen) >= 3000 and abs(c - ipos) >= 3000:
+                p2 = c
                 break
-        l2 = _loguniform_int(rng, 50, 2000)
-        s2 = _rand_seq(rng, l2)
-        ev2.append((p2, "INS", s2))
-        truth.append(TruthSV("INS", p2, l2, "0/1", 2, s2.tobytes().decode()))
+        if p2 is not None:
+            l2 = _loguniform_int(rng, 50, 2000)
+            s2 = _rand_seq(rng, l2)
+            ev2.append((p2, "INS", s2))
+            truth.append(TruthSV("INS", p2, l2, "0/1", 2, s2.tobytes().decode()))
     hap2 = apply(ref2, ev2)
 
     if profile == "hifi":

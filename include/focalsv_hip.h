@@ -133,7 +133,7 @@ typedef struct fsv_asm_params {
     int32_t lookback;         /* chain DP predecessors examined, 64 (= one wavefront) */
     int32_t bw_ec;            /* chain indel budget per mille in correction rounds, 20 (hifiasm 0.02) */
     int32_t bw_final;         /* ... in the final overlap pass, 0 = co-linear anchors only */
-    int32_t min_contig_reads; /* contigs built from fewer reads are dropped unless none is left, 2 */
+    int32_t min_contig_reads; /* chains of fewer reads are dropped, as hifiasm's asg_cut_tip(max_short_tip = 3) does (Overlaps.cpp:4666): 4 */
 } fsv_asm_params;
 void fsv_asm_default_params(fsv_asm_params *p);
 
@@ -176,7 +176,7 @@ typedef struct fsv_contigs {
 
 #define FSV_W_MZ_TRUNC     1  /* a read had more minimizers than the per-read cap; the rest were ignored */
 #define FSV_W_ANCHOR_TRUNC 2  /* a read pair had more anchors than the chaining tile holds */
-#define FSV_W_NO_LAYOUT    4  /* no overlap graph: the longest read was emitted as the contig */
+#define FSV_W_NO_LAYOUT    4  /* no chain of min_contig_reads reads: the set has no contig (hifiasm writes an empty GFA for it too) */
 
 /* capacity needed for fsv_contigs.seq / contig count for these read sets */
 int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap);
@@ -196,7 +196,8 @@ typedef struct fsv_asm_stats {
     uint64_t n_pairs, n_overlaps, n_windows, n_windows_matched, n_paths, n_path_dp;
     uint64_t dp_columns;       /* K5 + K6 column steps (windows x their x_len) */
     uint64_t algo_bytes;       /* packed operand + result bytes of all DP tasks + reads in + contigs out */
-    uint64_t n_exact_overlaps;
+    uint64_t n_exact_overlaps;  /* overlaps handed to the layout (exact, or inexact ones the last correction round verified) */
+    uint64_t n_inexact_candidates; /* pairs re-chained with the gapped bandwidth in the final pass */
     double   ms_sketch, ms_chain, ms_verify, ms_path, ms_consensus, ms_final, ms_total;
     uint32_t n_kernels, pad;
     fsv_kernel_stat kernels[FSV_MAX_KERNEL_STATS];

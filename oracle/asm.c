@@ -542,7 +542,7 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
 }
 
 /* one correction round: R -> corrected reads (new buffers); returns total windows examined */
-static void correction_round(readset *R, const orc_asm_params *P, int do_rc)
+static void correction_round(readset *R, const orc_asm_params *P, int do_rc, orc_ovl **accepted, int *n_accepted)
 {
     orc_mz **uq; int *nuq, n_ov, n_win, q;
     orc_ovl *ov; int32_t *cq, *ct; orc_win *W;
@@ -557,6 +557,11 @@ static void correction_round(readset *R, const orc_asm_params *P, int do_rc)
         if (do_rc) revcomp_inplace(nseq[q], nlen[q]);
     }
     for (q = 0; q < R->n; q++) { free(R->seq[q]); R->seq[q] = nseq[q]; R->len[q] = nlen[q]; }
+    if (accepted) { /* the overlaps this round verified (coordinates on the reads as they were before the round) */
+        int i, m = 0;
+        for (i = 0; i < n_ov; i++) if (ov[i].is_match) ov[m++] = ov[i];
+        *accepted = ov; *n_accepted = m; ov = NULL;
+    }
     free(nseq); free(nlen); free(W); free(ov); free(cq); free(ct);
     free_sketch(R, uq, nuq);
 }
@@ -567,11 +572,14 @@ typedef struct { int to, to_rev, ovl; } arc_t; /* best successor of an oriented 
 void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
-    P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 2;
+    P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4;
 }
 
-/* Exact overlaps of the corrected reads; returns the accepted hits (exact == 1) in ov[] */
-static int final_overlaps(const readset *R, const orc_asm_params *P, orc_ovl **out)
+/* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),
+ * and inexact ones that the last correction round had verified for the same ordered pair and strand with about the same
+ * coordinates (update_overlaps: both ends of either read within 10 % of the longer span).  Pairs without an exact overlap are
+ * re-chained with hifiasm's final bandwidth (0.001) to get gapped coordinates.  Returns the hits in ov[]. */
+static int final_overlaps(const readset *R, const orc_asm_params *P, const orc_ovl *prev, int n_prev, orc_ovl **out)
 {
     orc_mz **uq; int *nuq, n_ov, i, m = 0;
     orc_ovl *ov; int32_t *cq, *ct;
@@ -584,6 +592,31 @@ static int final_overlaps(const readset *R, const orc_asm_params *P, orc_ovl **o
         for (p = 0; same && p < L; p++) if (x[o->x_s + p] != ybase(y, ylen, o->rev, o->y_s + p)) same = 0;
         o->exact = (uint8_t)same;
         if (same) ov[m++] = *o;
+    }
+    if (n_prev > 0) {
+        orc_ovl *ov2; int32_t *cq2, *ct2; int n2, j;
+        int32_t *slot = (int32_t *)malloc(sizeof(int32_t) * (size_t)R->n * R->n);
+        uint8_t *has = (uint8_t *)calloc((size_t)R->n * R->n, 1);
+        for (i = 0; i < R->n * R->n; i++) slot[i] = -1;
+        for (i = 0; i < n_prev; i++) slot[(size_t)prev[i].q * R->n + prev[i].t] = i;
+        for (i = 0; i < m; i++) has[(size_t)ov[i].q * R->n + ov[i].t] = 1;
+        collect_overlaps(R, P, 1, uq, nuq, &ov2, &cq2, &ct2, &n2);
+        ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)(m + n2 + 1));
+        for (j = 0; j < n2; j++) {
+            const orc_ovl *o = &ov2[j];
+            const size_t key = (size_t)o->q * R->n + o->t;
+            const orc_ovl *pv;
+            int lx, ly, L;
+            if (has[key] || slot[key] < 0) continue;
+            pv = &prev[slot[key]];
+            if (pv->rev != o->rev) continue;
+            lx = pv->x_e - pv->x_s + 1; ly = pv->y_e - pv->y_s + 1;
+            L = (lx > ly ? lx : ly) / 10;
+            if ((abs(o->x_s - pv->x_s) < L && abs(o->x_e - pv->x_e) < L) || (abs(o->y_s - pv->y_s) < L && abs(o->y_e - pv->y_e) < L)) {
+                ov[m] = *o; ov[m].exact = 0; m++;
+            }
+        }
+        free(ov2); free(cq2); free(ct2); free(has); free(slot);
     }
     free(cq); free(ct);
     free_sketch(R, uq, nuq);
@@ -602,26 +635,34 @@ int orc_layout(const int *len, int n, const orc_ovl *hit, int n_hit, int min_rea
     int32_t *succ = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 2), *sovl = (int32_t *)calloc((size_t)n * 2, sizeof(int32_t));
     int32_t *pred = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 2);
     int i, v, n_piece = 0, n_contig = 0, pass;
+    /* ma_hit2arc (Overlaps.h:178-246) from the query's side of every hit; the mirrored hit supplies the other side.
+     * tl5 / tl3 = overhang of the target in front of / behind the overlap, on the query's strand (y is strand-corrected). */
+#define HIT_GEOM(h) const int ql = len[(h)->q], tl = len[(h)->t], qs = (h)->x_s, qe = (h)->x_e + 1, tl5 = (h)->y_s, tl3 = tl - ((h)->y_e + 1); \
+                    const int ext5 = qs < tl5 ? qs : tl5, ext3 = ql - qe < tl3 ? ql - qe : tl3, tspan = (h)->y_e + 1 - (h)->y_s; \
+                    const int internal = ext5 > 1000 || ext3 > 1000 || (qe - qs) < (qe - qs + ext5 + ext3) * 0.8f || tspan < (tspan + ext5 + ext3) * 0.8f
     for (i = 0; i < n_hit; i++) {
         const orc_ovl *h = &hit[i];
-        int qfull = h->x_s == 0 && h->x_e == len[h->q] - 1, tfull = h->y_s == 0 && h->y_e == len[h->t] - 1;
-        if (qfull && tfull) { if (h->q > h->t) contained[h->q] = 1; } /* identical reads: keep the lower index */
-        else if (qfull) contained[h->q] = 1;
-    }
-    for (v = 0; v < 2 * n; v++) { succ[v] = -1; pred[v] = -1; }
-    for (i = 0; i < n_hit; i++) {
-        const orc_ovl *h = &hit[i];
-        int L = h->x_e - h->x_s + 1, a, b;
-        if (contained[h->q] || contained[h->t]) continue;
-        if (h->x_e == len[h->q] - 1 && h->y_s == 0 && h->x_s > 0) { a = 2 * (int)h->q; b = 2 * (int)h->t + h->rev; }       /* (q,+) -> (t,rev) */
-        else if (h->x_s == 0 && h->y_e == len[h->t] - 1 && h->x_e < len[h->q] - 1) { a = 2 * (int)h->t + h->rev; b = 2 * (int)h->q; } /* (t,rev) -> (q,+) */
-        else continue;
-        /* the arc and its complement */
-        for (pass = 0; pass < 2; pass++) {
-            int from = pass ? (b ^ 1) : a, to = pass ? (a ^ 1) : b;
-            if (L > sovl[from] || (L == sovl[from] && succ[from] >= 0 && to < succ[from])) { succ[from] = to; sovl[from] = L; }
+        HIT_GEOM(h);
+        if (internal) continue;
+        if (qs <= tl5 && ql - qe <= tl3) {                 /* MA_HT_QCONT */
+            if (qs >= tl5 && ql - qe >= tl3) { if (h->q > h->t) contained[h->q] = 1; } /* mutual: keep the lower index */
+            else contained[h->q] = 1;
         }
     }
+    for (v = 0; v < 2 * n; v++) { succ[v] = -1; pred[v] = -1; sovl[v] = 0x7fffffff; }
+    for (i = 0; i < n_hit; i++) {
+        const orc_ovl *h = &hit[i];
+        int from, to, l;
+        HIT_GEOM(h);
+        if (internal || contained[h->q] || contained[h->t]) continue;
+        if ((qs <= tl5 && ql - qe <= tl3) || (qs >= tl5 && ql - qe >= tl3)) continue; /* containments */
+        if (qe - qs + ext5 + ext3 < 50 || tspan + ext5 + ext3 < 50) continue;         /* MA_HT_SHORT_OVLP */
+        if (qs > tl5) { from = 2 * (int)h->q; to = 2 * (int)h->t + h->rev; l = qs - tl5; }              /* (q,+) -> (t,rev) */
+        else { from = 2 * (int)h->q + 1; to = 2 * (int)h->t + !h->rev; l = (ql - qe) - tl3; }           /* (q,-) -> (t,!rev) */
+        /* every node keeps its nearest successor: the smallest node length = the longest overlap */
+        if (l < sovl[from] || (l == sovl[from] && succ[from] >= 0 && to < succ[from])) { succ[from] = to; sovl[from] = l; }
+    }
+#undef HIT_GEOM
     /* keep mutually-best arcs only: v -> w is kept when the best out-arc of ~w is ~v */
     for (v = 0; v < 2 * n; v++) {
         int w = succ[v];
@@ -642,19 +683,14 @@ int orc_layout(const int *len, int n, const orc_ovl *hit, int n_hit, int min_rea
             for (w = v; w >= 0 && !used[w >> 1]; w = succ[w]) {
                 used[w >> 1] = 1;
                 piece_read[n_piece] = w >> 1; piece_rev[n_piece] = (uint8_t)(w & 1);
-                piece_len[n_piece] = (succ[w] >= 0 && !used[succ[w] >> 1]) ? len[w >> 1] - sovl[w] : len[w >> 1];
+                piece_len[n_piece] = (succ[w] >= 0 && !used[succ[w] >> 1]) ? sovl[w] : len[w >> 1];
                 n_piece++;
             }
             contig_first[n_contig++] = first;
         }
     }
-    if (n_contig == 0) { /* nothing chained: fall back to the longest uncontained read so the region is not silently empty */
-        int bestr = -1;
-        for (i = 0; i < n; i++) if (!contained[i] && (bestr < 0 || len[i] > len[bestr])) bestr = i;
-        if (bestr >= 0 && piece_cap > 0 && contig_cap > 0) {
-            piece_read[0] = bestr; piece_rev[0] = 0; piece_len[0] = len[bestr]; contig_first[0] = 0; n_piece = 1; n_contig = 1;
-        }
-    }
+    /* no fall-back: hifiasm's asg_cut_tip (Overlaps.cpp:4666-4709, max_short_tip = 3) deletes every dead-end chain of
+     * fewer than four reads, a lone uncontained read included, and then writes no contig at all for the set */
     contig_first[n_contig] = n_piece;
     free(contained); free(used); free(succ); free(sovl); free(pred);
     return n_contig;
@@ -665,7 +701,7 @@ int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const o
                  char *corrected, uint64_t corrected_cap, uint64_t *corrected_off)
 {
     readset R;
-    orc_ovl *hits; int n_hit, r, i, c, nc;
+    orc_ovl *hits, *prev = NULL; int n_hit, n_prev = 0, r, i, c, nc;
     int32_t *piece_read, *piece_len, *contig_first; uint8_t *piece_rev;
     uint64_t used = 0;
     R.n = n_reads;
@@ -676,7 +712,10 @@ int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const o
         R.seq[r] = (char *)malloc((size_t)R.len[r] + 1);
         for (i = 0; i < R.len[r]; i++) { char ch = seqs[seq_off[r] + i]; R.seq[r][i] = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? ch : 'A'; }
     }
-    for (i = 0; i < P->n_rounds; i++) correction_round(&R, P, i + 1 < P->n_rounds);
+    for (i = 0; i < P->n_rounds; i++) {
+        const int last = i + 1 == P->n_rounds;
+        correction_round(&R, P, !last, last ? &prev : NULL, last ? &n_prev : NULL);
+    }
     if (corrected && corrected_off) {
         uint64_t u = 0;
         for (r = 0; r < n_reads; r++) {
@@ -686,7 +725,8 @@ int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const o
         }
         corrected_off[n_reads] = u;
     }
-    n_hit = final_overlaps(&R, P, &hits);
+    n_hit = final_overlaps(&R, P, prev, n_prev, &hits);
+    free(prev);
     piece_read = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 1));
     piece_len = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 1));
     piece_rev = (uint8_t *)malloc((size_t)n_reads + 1);

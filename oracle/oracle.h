@@ -26,7 +26,7 @@ typedef struct {
     int32_t bw_final;         /* ... in the final overlap pass: 0 = co-linear anchors only (hifiasm: 0.001; a read that ends inside a
                                  homopolymer run yields an HPC k-mer whose end is off by the truncated bases, which a non-zero
                                  budget lets into the chain and shifts the exact-overlap interval by one) */
-    int32_t min_contig_reads; /* contigs built from fewer reads are dropped unless none is left: 2 */
+    int32_t min_contig_reads; /* chains of fewer reads are dropped (asg_cut_tip with max_short_tip = 3, Overlaps.cpp:4666): 4 */
 } orc_asm_params;
 
 typedef struct {

@@ -90,3 +90,24 @@ def test_degenerate_sets(ctx):
         oc, _ = O.assemble(s) if s else ([], [])
         mine = [c for c, cs in zip(contigs, cset) if cs == si]
         assert mine == oc
+
+
+def test_low_coverage_and_narrow_regions_match_oracle(ctx):
+    """8x per haplotype: some reads keep errors, so the layout runs through inexact overlaps that the last correction round
+    verified; 14 kb windows: chains of fewer than four reads give no contig (as hifiasm's tip cutting)."""
+    cases = [(560, 50000, 8.0), (531, 26000, 8.0), (591, 100000, 8.0), (500, 14000, 8.0), (510, 14000, 15.0)]
+    regions = [synth.make_region(i, width=w, depth_per_hap=d) for i, w, d in cases]
+    sets = [rd for r in regions for rd in r.reads]
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets)
+    k = 0
+    n_inexact_needed = 0
+    for si, s in enumerate(sets):
+        oc, ocorr = O.assemble(s)
+        for j in range(len(s)):
+            assert reads[k + j] == ocorr[j], (si, j)
+        k += len(s)
+        mine = [c for c, cs in zip(contigs, cset) if cs == si]
+        assert mine == oc, (si, [len(c) for c in mine], [len(c) for c in oc])
+        if not oc:
+            assert status[si] & 4   # FSV_W_NO_LAYOUT
+    assert ctx.asm_stats()["n_inexact_candidates"] > 0

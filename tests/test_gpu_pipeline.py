@@ -62,7 +62,9 @@ def test_real_bed_geometry_config3(ctx, golden_dir):
     bed = json.load(open(os.path.join(golden_dir, "bed_chr21_regions.json")))["chr21"]
     picks = sorted(bed, key=lambda r: r[1] - r[0])
     chosen = [picks[0], picks[len(picks) // 2], picks[-8], picks[len(picks) // 3]]  # smallest, median, a wide one (> 60 kb)
-    rs = [synth.make_region(300 + i, width=b - a, start=a) for i, (a, b) in enumerate(chosen)]
+    # `samtools view bam chr:start-end` (1_crop_bam.py:74) returns whole reads that touch the region, so a read set spans about a
+    # read length beyond either end of its BED line: the synthetic haplotype is the region +- 15 kb
+    rs = [synth.make_region(300 + i, width=b - a + 30000, start=max(0, a - 15000)) for i, (a, b) in enumerate(chosen)]
     batch = pipeline.upload_regions(ctx, [pipeline.region_from_synth(r) for r in rs])
     try:
         res = pipeline.run_hot_path(ctx, batch)

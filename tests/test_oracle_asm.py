@@ -18,17 +18,40 @@ def _sets(golden_dir):
     return json.load(open(os.path.join(golden_dir, "hifiasm_contigs.json")))["sets"]
 
 
-@pytest.mark.parametrize("region", [0, 7, 38, 39])
-def test_oracle_contigs_equal_hifiasm_contigs(golden_dir, region):
-    """byte-identical (up to strand) to the reference assembler, including the two sets (38/hp2, 39/hp1)
-    where hifiasm itself keeps an uncorrectable 1-base insertion at the very end of the contig"""
-    r = synth.make_region(region)
-    for g in [s for s in _sets(golden_dir) if s["region"] == region]:
-        reads = r.reads[g["hap"] - 1]
-        assert hashlib.md5(b"\n".join(reads)).hexdigest() == g["reads_md5"], "synthetic generator drifted"
-        contigs, corrected = O.assemble(reads)
-        got = sorted((len(c), hashlib.md5(canon(c)).hexdigest()) for c in contigs)
-        exp = sorted((c["len"], c["md5"]) for c in g["contigs"])
+def _gold_ids(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
+    sets = _sets(golden_dir)
+    # the grid of other widths / depths completely; of the 19 bench-geometry regions the four with special cases
+    return [i for i, g in enumerate(sets) if g["region"] >= 500 or g["region"] in (0, 7, 38, 39)]
+
+
+# 8x per haplotype: some reads keep errors, hifiasm's graph cleaning prefers exact edges around them
+# (asg_arc_del_short_diploid_by_exact and friends, Overlaps.cpp:7179) and this restatement does not: the contig is whole but
+# differs from hifiasm's by a few bases at a junction (561/1: hifiasm drops 10 kb that we keep).  Corrected reads are identical.
+KNOWN_LAYOUT_DEVIATIONS = {(530, 1), (531, 1), (560, 1), (561, 1), (591, 1), (591, 2)}
+
+
+# 580/2: one of 96 corrected reads ends one base earlier than hifiasm's (a deletion among the last bases of a read at the window
+# edge; hifiasm re-aligns read ends in fix_boundary / calculate_boundary_cigars, Correct.cpp:1676-1795, 2310, not restated)
+KNOWN_READ_END_DEVIATIONS = {(580, 2)}
+
+
+@pytest.mark.parametrize("idx", _gold_ids())
+def test_oracle_equals_hifiasm(golden_dir, idx):
+    """corrected reads identical to `hifiasm --write-ec` and contigs byte-identical (up to strand) to the reference assembler,
+    including the two sets (38/hp2, 39/hp1) where hifiasm itself keeps an uncorrectable 1-base insertion at the very end of
+    the contig, and the 14 kb windows where it writes no contig at all"""
+    g = _sets(golden_dir)[idx]
+    r = synth.make_region(g["region"], width=g["width"], depth_per_hap=g["depth"])
+    reads = r.reads[g["hap"] - 1]
+    assert hashlib.md5(b"\n".join(reads)).hexdigest() == g["reads_md5"], "synthetic generator drifted"
+    contigs, corrected = O.assemble(reads)
+    same_reads = hashlib.md5(b"\n".join(canon(c) for c in corrected)).hexdigest() == g["corrected_reads_md5"]
+    assert same_reads != ((g["region"], g["hap"]) in KNOWN_READ_END_DEVIATIONS)
+    got = sorted((len(c), hashlib.md5(canon(c)).hexdigest()) for c in contigs)
+    exp = sorted((c["len"], c["md5"]) for c in g["contigs"])
+    if (g["region"], g["hap"]) in KNOWN_LAYOUT_DEVIATIONS:
+        assert len(got) == 1 and got != exp, "a documented low-coverage deviation disappeared: drop it from the list"
+    else:
         assert got == exp
 
 
