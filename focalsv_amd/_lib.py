@@ -20,6 +20,9 @@ MZ_DTYPE = np.dtype([("hash", "<u8"), ("pos", "<u4"), ("rev", "u1"), ("span", "u
 WRES_DTYPE = np.dtype(
     [("end_site", "<i4"), ("err", "<i4"), ("y_beg", "<i4"), ("extra_begin", "<i2"), ("extra_end", "<i2")], align=False)
 assert WTASK_DTYPE.itemsize == 32 and WRES_DTYPE.itemsize == 16
+WPATH_DTYPE = np.dtype([("ry_start", "<i4"), ("ry_end", "<i4"), ("path_len", "<i2"), ("err", "<i2"), ("state", "u1"), ("y_rev", "u1"),
+                        ("pad", "<u2"), ("y_word", "<u4"), ("y_len", "<i4"), ("ops", "u1", (104,))], align=False)
+assert WPATH_DTYPE.itemsize == 128
 
 
 class AsmParams(C.Structure):
@@ -156,6 +159,13 @@ def join_refs(refs):
     return np.frombuffer(b"".join(refs) + b"\0", dtype=np.uint8), roff
 
 
+def path_ops(p) -> bytes:
+    """fsv_wpath record -> its ops start-to-end, one per byte (0 match 1 mismatch 2 y-only 3 x-only)"""
+    b = np.asarray(p["ops"], dtype=np.uint8)
+    fields = np.stack([(b >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(-1)
+    return bytes(fields[: int(p["path_len"])])
+
+
 class ContigBatch:
     """The contigs of one fsv_assemble_batch call: a read-only sequence of `bytes`, cut out of the library's output buffer
     on access (a batch is tens of MB; most callers touch a few contigs or none -- the aligner takes them from the device)."""
@@ -232,6 +242,15 @@ class Context:
         res = np.empty(len(tasks), dtype=WRES_DTYPE)
         self.check(self._lib.fsv_bpm_windows(self._h, _ptr(words), words.size, _ptr(tasks), len(tasks), _ptr(res)), "fsv_bpm_windows")
         return res
+
+    def bpm_paths(self, words, tasks):
+        """K5 + K6 on host tasks (fsv_bpm_paths) -> (results, paths); `path_ops(paths[i])` unpacks the 2-bit ops"""
+        tasks = np.ascontiguousarray(tasks, dtype=WTASK_DTYPE)
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        res = np.empty(len(tasks), dtype=WRES_DTYPE)
+        paths = np.zeros(len(tasks), dtype=WPATH_DTYPE)
+        self.check(self._lib.fsv_bpm_paths(self._h, _ptr(words), words.size, _ptr(tasks), len(tasks), _ptr(res), _ptr(paths)), "fsv_bpm_paths")
+        return res, paths
 
     def bpm_windows_dev(self, store_ptr, tasks_ptr, n_tasks, res_ptr):
         self.check(self._lib.fsv_bpm_windows_dev(self._h, C.c_void_p(store_ptr), C.c_void_p(tasks_ptr), n_tasks, C.c_void_p(res_ptr)),

@@ -321,6 +321,65 @@ extern "C" int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_
     return FSV_OK;
 }
 
+// K5 + K6 on caller-supplied tasks: the same kernels fsv_assemble_batch drives, with every task treated as belonging to an
+// accepted overlap
+extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_words, const fsv_wtask *tasks, uint32_t n_tasks,
+                             fsv_wres *res, fsv_wpath *paths)
+{
+    if (!ctx || !store || (!tasks && n_tasks) || (!res && n_tasks) || (!paths && n_tasks)) return FSV_EINVAL;
+    if (n_tasks == 0) return FSV_OK;
+    for (uint32_t i = 0; i < n_tasks; i++)
+        if (tasks[i].k > FSV_K_MAX || tasks[i].x_len == 0 || tasks[i].x_len > FSV_WINDOW) return fsv_fail(ctx, FSV_EINVAL, "task k/x_len out of range");
+    FSV_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_cnt, d_cols;
+    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_cnt, &d_cols}) if (b->p) (void)hipFree(b->p); };
+    int rc = FSV_OK;
+    auto run = [&]() -> int {
+        std::vector<fsv_wtask> t(tasks, tasks + n_tasks);
+        for (auto &x : t) x.ovl = 0;
+        fsv_ovl o; memset(&o, 0, sizeof(o)); o.valid = 1; o.is_match = 1;
+        TRY(ensure(ctx, d_store, store_words * 4 + 64));
+        FSV_HIP(ctx, hipMemsetAsync(d_store.p, 0, store_words * 4 + 64, ctx->stream));
+        FSV_HIP(ctx, hipMemcpyAsync(d_store.p, store, store_words * 4, hipMemcpyHostToDevice, ctx->stream));
+        TRY(upload(ctx, d_tasks, t));
+        TRY(upload(ctx, d_ovl, std::vector<fsv_ovl>{o}));
+        TRY(ensure(ctx, d_res, (size_t)n_tasks * sizeof(fsv_wres)));
+        TRY(ensure(ctx, d_paths, (size_t)n_tasks * sizeof(fsv_wpath)));
+        TRY(ensure(ctx, d_list, (size_t)n_tasks * 4));
+        TRY(ensure(ctx, d_cnt, 64));
+        FSV_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, 64, ctx->stream));
+        FSV_HIP(ctx, hipMemsetAsync(d_paths.p, 0, (size_t)n_tasks * sizeof(fsv_wpath), ctx->stream));
+        TRY(fsv_bpm_windows_dev(ctx, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, n_tasks, (fsv_wres *)d_res.p));
+        hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_ovl *)d_ovl.p,
+                           (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p, n_tasks, (fsv_wpath *)d_paths.p, (uint32_t *)d_list.p,
+                           (uint32_t *)d_cnt.p + 2, (uint32_t *)d_cnt.p + 6);
+        FSV_HIP(ctx, hipGetLastError());
+        uint32_t cnt[8];
+        FSV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int wide = 0; wide < 2; wide++) {
+            const uint32_t n_here = wide ? cnt[6] : cnt[2], list0 = wide ? n_tasks - cnt[6] : 0u;
+            if (!n_here) continue;
+            const uint32_t grid = std::min<uint32_t>(fsv_grid_for(n_here, 64), 8u * (uint32_t)ctx->n_cu);
+            TRY(ensure(ctx, d_cols, (size_t)grid * 64 * (FSV_WINDOW + 2) * 3 * (wide ? 8 : 4)));
+            if (wide)
+                hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
+                                   (const uint32_t *)d_list.p, list0, list0 + n_here, (fsv_wpath *)d_paths.p, (uint64_t *)d_cols.p, grid * 64);
+            else
+                hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
+                                   (const uint32_t *)d_list.p, list0, list0 + n_here, (fsv_wpath *)d_paths.p, (uint32_t *)d_cols.p, grid * 64);
+            FSV_HIP(ctx, hipGetLastError());
+        }
+        FSV_HIP(ctx, hipMemcpyAsync(res, d_res.p, (size_t)n_tasks * sizeof(fsv_wres), hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipMemcpyAsync(paths, d_paths.p, (size_t)n_tasks * sizeof(fsv_wpath), hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FSV_OK;
+    };
+    rc = run();
+    cleanup();
+    return rc;
+}
+
 extern "C" int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out)
 {
     if (!ctx || !out || !ctx->asm_ws) return FSV_EINVAL;

@@ -22,16 +22,7 @@
 #define FSV_INS_MAXLEN   12
 #define FSV_EV_CAP     1024  // insertion events per grid window
 
-struct fsv_wpath {           // 128 bytes per window task
-    int32_t ry_start, ry_end;   // absolute strand coordinates of the aligned y interval
-    int16_t path_len, err;
-    uint8_t state;              // 0 none, 1 path present, 2 queued for DP
-    uint8_t y_rev;
-    uint16_t pad;
-    uint32_t y_word;            // where to find read y (the consensus fetches y bases only at mismatches / insertions)
-    int32_t y_len;
-    uint8_t ops[104];           // 2-bit ops start-to-end: 0 match 1 mismatch 2 y-only 3 x-only
-};
+// fsv_wpath (include/focalsv_hip.h): 128 bytes per window task; state 2 = queued for the DP kernel (internal)
 static_assert(sizeof(fsv_wpath) == 128, "fsv_wpath layout");
 
 namespace { // every translation unit that includes this header gets its own copy of the kernels

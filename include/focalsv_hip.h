@@ -107,6 +107,24 @@ typedef struct fsv_wres {
     int16_t extra_end;   /* 'N' columns padded behind */
 } fsv_wres;              /* 16 bytes */
 
+/* K6 result of one window task: the alignment path after generate_cigar's end trimming and gap left-shift
+ * (Reserve_Banded_BPM_PATH + generate_cigar, Levenshtein_distance.h:511-888, Correct.cpp:1387-1536). */
+typedef struct fsv_wpath {
+    int32_t ry_start, ry_end;   /* aligned y interval in y's strand coordinates (inclusive) */
+    int16_t path_len, err;      /* ops in the path; edit distance after trimming */
+    uint8_t state;              /* 0 no alignment within k, 1 path present */
+    uint8_t y_rev;
+    uint16_t pad;
+    uint32_t y_word;
+    int32_t y_len;
+    uint8_t ops[104];           /* 2 bits per op, start-to-end: 0 match 1 mismatch 2 y-only 3 x-only; at most 416 ops */
+} fsv_wpath;                    /* 128 bytes */
+
+/* K5 + K6 over host tasks (test / integration entry point; fsv_assemble_batch runs the same kernels on its own task list):
+ * res[i] as fsv_bpm_windows, paths[i] for every task with res[i].err >= 0. */
+int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_words, const fsv_wtask *tasks,
+                  uint32_t n_tasks, fsv_wres *res, fsv_wpath *paths);
+
 int fsv_bpm_windows_dev(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wtask *tasks_dev,
                         uint32_t n_tasks, fsv_wres *res_dev);
 /* host convenience wrapper (copies in, runs, copies out) */

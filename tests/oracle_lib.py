@@ -37,6 +37,15 @@ def bpm_path(x: str, y: str, k: int):
     return site, err.value, start.value, bytes(path[: plen.value])
 
 
+def try_cigar(x: str, y: str, end_site: int, error: int):
+    """gap-free fast path of Reserve_Banded_BPM_PATH -> (start_site, path end-to-start) or None"""
+    n = len(x)
+    path = (C.c_uint8 * (n + 16))()
+    start, plen = C.c_int(-1), C.c_int(0)
+    ok = lib().orc_try_cigar(y.encode(), x.encode(), n, end_site, error, path, C.byref(start), C.byref(plen))
+    return (start.value, bytes(path[: plen.value])) if ok else None
+
+
 def generate_cigar(path: bytes, x: str, y: str, start: int, end: int, err: int):
     """-> (start, end, err, 'nMnXnInD') after trimming + gap left-shift"""
     n = len(x)
