@@ -38,7 +38,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
                                         "k_repack", "k_exact", "k_stitch"};
 
 struct AsmWs {
-    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list,
+    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     // state of the last run (for fsv_asm_fetch_reads / stats)
@@ -52,7 +52,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -331,8 +331,8 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
     for (uint32_t i = 0; i < n_tasks; i++)
         if (tasks[i].k > FSV_K_MAX || tasks[i].x_len == 0 || tasks[i].x_len > FSV_WINDOW) return fsv_fail(ctx, FSV_EINVAL, "task k/x_len out of range");
     FSV_HIP(ctx, hipSetDevice(ctx->device));
-    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_cnt, d_cols;
-    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_cnt, &d_cols}) if (b->p) (void)hipFree(b->p); };
+    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_cnt, d_cols, d_cols2;
+    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_cnt, &d_cols, &d_cols2}) if (b->p) (void)hipFree(b->p); };
     int rc = FSV_OK;
     auto run = [&]() -> int {
         std::vector<fsv_wtask> t(tasks, tasks + n_tasks);
@@ -357,6 +357,17 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         uint32_t cnt[8];
         FSV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DevBuf &d_list2 = d_cols2;
+        const uint32_t *narrow = (const uint32_t *)d_list.p;
+        if (cnt[2]) {
+            TRY(ensure(ctx, d_list2, (size_t)cnt[2] * 4));
+            hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(cnt[2], 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
+                               (const fsv_wres *)d_res.p, (const uint32_t *)d_list.p, cnt[2], (fsv_wpath *)d_paths.p, (uint32_t *)d_list2.p, (uint32_t *)d_cnt.p + 7);
+            FSV_HIP(ctx, hipGetLastError());
+            FSV_HIP(ctx, hipMemcpyAsync(&cnt[2], (uint32_t *)d_cnt.p + 7, 4, hipMemcpyDeviceToHost, ctx->stream));
+            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            narrow = (const uint32_t *)d_list2.p;
+        }
         for (int wide = 0; wide < 2; wide++) {
             const uint32_t n_here = wide ? cnt[6] : cnt[2], list0 = wide ? n_tasks - cnt[6] : 0u;
             if (!n_here) continue;
@@ -367,7 +378,7 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
                                    (const uint32_t *)d_list.p, list0, list0 + n_here, (fsv_wpath *)d_paths.p, (uint64_t *)d_cols.p, grid * 64);
             else
                 hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
-                                   (const uint32_t *)d_list.p, list0, list0 + n_here, (fsv_wpath *)d_paths.p, (uint32_t *)d_cols.p, grid * 64);
+                                   narrow, list0, list0 + n_here, (fsv_wpath *)d_paths.p, (uint32_t *)d_cols.p, grid * 64);
             FSV_HIP(ctx, hipGetLastError());
         }
         FSV_HIP(ctx, hipMemcpyAsync(res, d_res.p, (size_t)n_tasks * sizeof(fsv_wres), hipMemcpyDeviceToHost, ctx->stream));
@@ -496,7 +507,23 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             uint32_t cnt2[8];
             FSV_HIP(ctx, hipMemcpyAsync(cnt2, W.counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
             FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            const uint32_t n_dp = cnt2[2], n_dp_wide = cnt2[6];
+            uint32_t n_dp = cnt2[2];
+            const uint32_t n_dp_wide = cnt2[6];
+            const uint32_t *narrow_list = (const uint32_t *)W.dp_list.p;
+            if (n_dp) {
+                // single-indel windows are settled without the DP (k_path_indel1); the rest is compacted into a second list
+                TRY(ensure(ctx, W.dp_list2, (size_t)n_dp * 4));
+                uint32_t *n2_dev = (uint32_t *)W.counters.p + 7;
+                hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(n_dp, 256)), dim3(256), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                                   (const fsv_wres *)W.res.p, (const uint32_t *)W.dp_list.p, n_dp, (fsv_wpath *)W.paths.p, (uint32_t *)W.dp_list2.p, n2_dev);
+                FSV_HIP(ctx, hipGetLastError());
+                uint32_t n2 = 0;
+                FSV_HIP(ctx, hipMemcpyAsync(&n2, n2_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+                FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                W.stats.n_path_indel1 += n_dp - n2;
+                n_dp = n2;
+                narrow_list = (const uint32_t *)W.dp_list2.p;
+            }
             W.stats.n_path_dp += n_dp + n_dp_wide;
             // narrow bands: [0, n_dp) of the list with 32-bit column words; wide bands: the last n_dp_wide entries with 64-bit words
             for (int wide = 0; wide < 2; wide++) {
@@ -511,7 +538,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
                     TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * sizeof(*colp)));
                     W.kt.begin(ctx, KN_PATH_DP, (uint64_t)n_here * (32 + 196 + 128));
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                                       (const uint32_t *)W.dp_list.p, list0, list0 + n_here, (fsv_wpath *)W.paths.p, (decltype(colp))W.cols.p, stride);
+                                       wide ? (const uint32_t *)W.dp_list.p : narrow_list, list0, list0 + n_here, (fsv_wpath *)W.paths.p, (decltype(colp))W.cols.p, stride);
                     return FSV_OK;
                 };
                 if (wide) TRY(launch(k_path_dp<uint64_t>, (uint64_t *)nullptr));

@@ -753,6 +753,101 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     for (int i = 0; i < 13; i++) dst[i] = make_uint2(ops32[2 * i], ops32[2 * i + 1]);
 }
 
+// Windows at distance 1 that are not a single mismatch are a single inserted or deleted base: about a third of the windows that
+// reach the DP in the first correction round.  For them the reference's walk back (Levenshtein_distance.h:757-888) can be
+// predicted without the DP matrix.  It climbs the end diagonal over matches (distance stays 1) and leaves it at the first cell,
+// coming from the end, whose upper or left neighbour has distance 0 -- "up" is tested first.  A cell has distance 0 exactly
+// when the x prefix in front of it matches on its diagonal, so with pmU / pmL = the number of leading x bases that match on the
+// diagonal above / below the end diagonal, "up" is open at columns c <= pmU and "left" at c <= pmL + 1 (band edges permitting),
+// and the walk takes the larger of the two, "up" on a tie.  generate_cigar then left-shifts that one gap while the bases it
+// passes pair up.  Anything unexpected (no admissible column, a mismatch behind the gap) is left to the DP kernel.
+__device__ __forceinline__ int path_prefix_match(const uint32_t *__restrict__ store, const fsv_wtask &t, int win0, int off, int n)
+{
+    // number of leading i with x[i] == ywin[off + i]; columns outside read y never match
+    for (int b = 0; b * 16 < n; b++) {
+        const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + b * 16);
+        const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + off + b * 16);
+        uint32_t d = xb ^ yb.bits;
+        d = (d | (d >> 1)) & 0x55555555u;
+        uint32_t inval = ~yb.valid & 0xffffu;
+        inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
+        inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
+        d |= inval;
+        const int lim = min(16, n - b * 16);
+        if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+        if (d) return b * 16 + (__ffs((int)d) - 1) / 2;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_path_indel1(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
+                                                     const fsv_wres *__restrict__ res, const uint32_t *__restrict__ dp_list, uint32_t n_list,
+                                                     fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list2, uint32_t *__restrict__ n_list2)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_list) return;
+    const uint32_t tid = dp_list[idx];
+    const fsv_wtask t = tasks[tid];
+    const fsv_wres r = res[tid];
+    bool done = false;
+    if (r.err == 1 && t.k >= 1) {
+        const int n = t.x_len, k = t.k, band = 2 * k + 1, E = r.end_site, win0 = t.y_start - k;
+        const int row = band - (n + 2 * k - E);
+        const bool can_up = row != 0, can_left = row != band - 1;
+        const int c_up = can_up ? min(n, path_prefix_match(store, t, win0, E - n, n)) : 0;
+        const int c_left = can_left ? min(n, path_prefix_match(store, t, win0, E - n + 2, n) + 1) : 0;
+        const int c = max(c_up, c_left);
+        const uint32_t gap = c_up >= c_left ? 2u : 3u;
+        // behind the gap the end diagonal must be all matches: x[c .. n) against ywin[E - n + 1 + i]
+        bool clean = c >= 1;
+        if (clean) {
+            for (int b = c >> 4; b * 16 < n && clean; b++) {
+                const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + b * 16);
+                const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + E - n + 1 + b * 16);
+                uint32_t d = xb ^ yb.bits;
+                d = (d | (d >> 1)) & 0x55555555u;
+                uint32_t inval = ~yb.valid & 0xffffu;
+                inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
+                inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
+                d |= inval;
+                const int lo = max(c - b * 16, 0), lim = min(16, n - b * 16);
+                if (lo > 0) d &= ~((1u << (2 * lo)) - 1u);
+                if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+                if (d) clean = false;
+            }
+        }
+        if (clean) {
+            // the walk: n - c matches, the gap, then c (up) or c - 1 (left) matches; start site as the reference computes it
+            const int g = n - c, rest = gap == 2u ? c : c - 1, plen = n + (gap == 2u ? 1 : 0);
+            int start = E - g - (gap == 2u ? 1 : 0);
+            if (rest > 0) start -= rest;
+            if (rest > 0 || gap != 3u) start++;
+            // generate_cigar: no mismatches to trim; the gap (index g counted from the end) moves towards the start while the bases pair up
+            const int before = plen - 1 - g;     // ops in front of the gap, all matches: x and y consumed there
+            int x2 = before, y2 = before, s = 0;
+            if (gap == 3u) y2--; else x2--;
+            for (int pi = g + 1; pi < plen && x2 >= 0 && y2 >= 0; pi++, x2--, y2--) {
+                if (fsv_base_fwd(store, t.x_word, t.x_start + x2) != task_ybase(store, t, start + y2)) break;
+                s++;
+            }
+            const int f = before - s;            // field of the gap in start-to-end order
+            fsv_wpath *P = paths + tid;
+            uint2 *dst = reinterpret_cast<uint2 *>(P->ops);
+#pragma unroll
+            for (int i = 0; i < 13; i++) {
+                uint2 v = make_uint2(0u, 0u);
+                if ((f >> 5) == i) { if ((f >> 4) & 1) v.y = gap << ((f & 15) << 1); else v.x = gap << ((f & 15) << 1); }
+                dst[i] = v;
+            }
+            P->ry_start = t.y_start - t.k + start;
+            P->ry_end = t.y_start - t.k + E;
+            P->path_len = (int16_t)plen; P->err = 1; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
+            done = true;
+        }
+    }
+    if (!done) dp_list2[atomicAdd(n_list2, 1u)] = tid;
+}
+
 // Full K6: forward pass keeping {D0, VP, VN} of every column in a per-lane slice of an HBM scratch ([block][column][word][lane]:
 // a wave streams through its own contiguous 290 KB, 256-byte stores), the reference's walk back, generate_cigar's end trimming and greedy gap left-shift; the
 // path under construction lives in LDS (2 bits per op) and is packed start-to-end at the end.
