@@ -65,8 +65,8 @@ def cpu_baseline(n_regions, first_index):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=256, help="regions per GPU (BASELINE.json configs[1]: 256)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="regions the CPU baseline runs (0 = skip)")
     args = ap.parse_args()
@@ -138,8 +138,19 @@ def main():
     tp1, _, _, _ = pipeline.match_truth(calls, truth_left, bp_tol=1, len_tol=0.02, left_shift_ok=0)
 
     if rank == 0:
-        a = stats_acc[-1][0]
-        l = stats_acc[-1][1]
+        # library statistics averaged over the timed steps (a single step can catch a clock or host hiccup)
+        def avg(dicts):
+            out = {}
+            for k, v in dicts[-1].items():
+                if isinstance(v, (int, float)):
+                    out[k] = sum(d[k] for d in dicts) / len(dicts)
+                elif isinstance(v, dict):
+                    out[k] = avg([d[k] for d in dicts])
+                else:
+                    out[k] = v
+            return out
+        a = avg([x[0] for x in stats_acc])
+        l = avg([x[1] for x in stats_acc]) if stats_acc[-1][1] else {}
         kern = a.get("kernels", {})
         dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else (None, None)
         peak = 8000.0
@@ -173,7 +184,7 @@ def main():
                                    "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather"},
             "sv_vs_truth": {"truth": len(truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok, "tp_within_1bp_of_left_aligned_truth": tp1},
             "stage_ms": {k: round(v, 2) for k, v in a.items() if k.startswith("ms_")},
-            "kernel_ms": {k: [round(v["ms"], 2), v["launches"]] for k, v in kern.items()},
+            "kernel_ms": {k: [round(v["ms"], 2), int(round(v["launches"]))] for k, v in kern.items()},
             "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},
             "host_ms": res.host_ms,
             # companion compute figure: banded DP column-steps of K5 + K6 (windows x their x_len, 31-row bands)

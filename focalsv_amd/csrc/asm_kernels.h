@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     int32_t *const s_dp = (int32_t *)(s_raw + 8 * (size_t)AMAX);    // s_f | s_ind | s_sl ; doubles as the staged t records
     uint16_t *const s_aux = (uint16_t *)(s_raw + 20 * (size_t)AMAX); // t span | strand << 8 ; later: predecessor index
     uint16_t *const s_chain = (uint16_t *)(s_raw + 22 * (size_t)AMAX);
-    int32_t *const s_f = s_dp, *const s_ind = s_dp + AMAX, *const s_sl = s_dp + 2 * AMAX;
+    int32_t *const s_f = s_dp, *const s_ind = s_dp + AMAX;   // the third row only serves the staged t records
     const int lane = threadIdx.x;
     const uint4 pt = A.upair_tab[A.pair_list ? A.pair_list[blockIdx.x] : blockIdx.x];
     const uint32_t q = pt.y & 0xffffu, t = pt.y >> 16;
@@ -475,40 +475,55 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         for (int i = lane; i < n; i += 64) { s_aux[i] = (uint16_t)(i == 0 ? 0xffff : i - 1); s_f[i] = i == n - 1 ? A.k_score + acc : 0; }
         __syncthreads();
-    } else
-    for (int i = 0; i < n; i++) {
-        const uint64_t ki = s_key[i];
-        const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
-        const int j = i - 1 - lane;
-        int cand = -1, ti = 0, tl = 0;
-        if (j >= 0) {
-            const uint64_t kj = s_key[j];
-            const int dq = qe - (int)(kj >> 32), dt = te - (int)(uint32_t)kj;
-            if (dq > 0 && dt > 0) {
-                const int gap = dq > dt ? dq - dt : dt - dq;
-                ti = s_ind[j] + gap; tl = s_sl[j] + dq;
-                // 64-bit divisions cost ~150 VALU ops on gfx950; the operands fit 32 bits for every read below 2^17 bases
-                // (ti <= tl*bw/1000 <= 2621, sc <= 63): same quotient either way
-                if (tl < (1 << 17) && gap < (1 << 17) && A.bw <= 20) {
-                    if ((uint32_t)ti * 1000u <= (uint32_t)tl * (uint32_t)A.bw) {
+    } else {
+        // The 64 predecessors live in registers, lane l = anchor i-1-l: after anchor i is settled every lane hands its anchor to
+        // the next lane (DPP wave_shr, lane 0 takes the new one), so an iteration has no LDS round trip on its critical path --
+        // only the broadcast read of the next anchor, requested one iteration ahead, and the stores of f / predecessor.
+        int rq = 0, rt = 0, rind = 0, rsl = 0, rf = 0;
+        uint64_t knext = s_key[0];
+        for (int i = 0; i < n; i++) {
+            const uint64_t ki = knext;
+            if (i + 1 < n) knext = s_key[i + 1];
+            const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
+            const int j = i - 1 - lane;
+            int cand = -1, ti = 0, tl = 0;
+            if (j >= 0) {
+                const int dq = qe - rq, dt = te - rt;
+                if (dq > 0 && dt > 0) {
+                    const int gap = dq > dt ? dq - dt : dt - dq;
+                    ti = rind + gap; tl = rsl + dq;
+                    // 64-bit divisions cost ~150 VALU ops on gfx950; the operands fit 32 bits for every read below 2^17 bases
+                    // (ti <= tl*bw/1000 <= 2621, sc <= 63): same quotient either way
+                    if (tl < (1 << 17) && gap < (1 << 17) && A.bw <= 20) {
+                        if ((uint32_t)ti * 1000u <= (uint32_t)tl * (uint32_t)A.bw) {
+                            int sc = min(min(dq, dt), A.k_score);
+                            if (ti) sc -= (int)(((uint32_t)ti * (uint32_t)sc * 1000u) / ((uint32_t)tl * (uint32_t)A.bw));
+                            cand = sc + rf;
+                        }
+                    } else if ((long long)ti * 1000 <= (long long)tl * A.bw) {
                         int sc = min(min(dq, dt), A.k_score);
-                        if (ti) sc -= (int)(((uint32_t)ti * (uint32_t)sc * 1000u) / ((uint32_t)tl * (uint32_t)A.bw));
-                        cand = sc + s_f[j];
+                        if (ti) sc -= (int)(((long long)ti * sc * 1000) / ((long long)tl * A.bw));
+                        cand = sc + rf;
                     }
-                } else if ((long long)ti * 1000 <= (long long)tl * A.bw) {
-                    int sc = min(min(dq, dt), A.k_score);
-                    if (ti) sc -= (int)(((long long)ti * sc * 1000) / ((long long)tl * A.bw));
-                    cand = sc + s_f[j];
                 }
             }
+            // pack so that the max prefers the higher score, then the nearer predecessor
+            const int packed = cand < 0 ? -1 : cand * 64 + (63 - lane);
+            const int bestp = wave_max_i32(packed);
+            const int bests = bestp < 0 ? -1 : bestp >> 6;
+            int nf = A.k_score, nind = 0, nsl = 0, npred = 0xffff;
+            if (bests > A.k_score) {
+                const int wl = 63 - (bestp & 63);
+                nf = bests; npred = i - 1 - wl;
+                nind = __builtin_amdgcn_readlane(ti, wl); nsl = __builtin_amdgcn_readlane(tl, wl);
+            }
+            if (lane == 0) { s_f[i] = nf; s_aux[i] = (uint16_t)npred; }
+            rq = __builtin_amdgcn_update_dpp(qe, rq, 0x138, 0xF, 0xF, false);    // wave_shr:1, lane 0 <- the new anchor
+            rt = __builtin_amdgcn_update_dpp(te, rt, 0x138, 0xF, 0xF, false);
+            rind = __builtin_amdgcn_update_dpp(nind, rind, 0x138, 0xF, 0xF, false);
+            rsl = __builtin_amdgcn_update_dpp(nsl, rsl, 0x138, 0xF, 0xF, false);
+            rf = __builtin_amdgcn_update_dpp(nf, rf, 0x138, 0xF, 0xF, false);
         }
-        // pack so that the max prefers the higher score, then the nearer predecessor
-        const int packed = cand < 0 ? -1 : cand * 64 + (63 - lane);
-        const int bestp = wave_max_i32(packed);
-        const int bests = bestp < 0 ? -1 : bestp >> 6;
-        if (bests > A.k_score) {
-            if (packed == bestp) { s_f[i] = bests; s_aux[i] = (uint16_t)j; s_ind[i] = ti; s_sl[i] = tl; }
-        } else if (lane == 0) { s_f[i] = A.k_score; s_aux[i] = 0xffff; s_ind[i] = 0; s_sl[i] = 0; }
         __syncthreads();
     }
     // 5. best chain end: highest score, smallest index on ties
