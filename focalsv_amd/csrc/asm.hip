@@ -507,6 +507,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             uint32_t cnt2[8];
             FSV_HIP(ctx, hipMemcpyAsync(cnt2, W.counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
             FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            W.stats.dp_columns += (uint64_t)cnt2[4] | (uint64_t)cnt2[5] << 32;   // K5 windows (k_chain) + rescue re-runs (k_rescue_accept)
             uint32_t n_dp = cnt2[2];
             const uint32_t n_dp_wide = cnt2[6];
             const uint32_t *narrow_list = (const uint32_t *)W.dp_list.p;

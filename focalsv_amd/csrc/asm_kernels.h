@@ -575,7 +575,11 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     if (!A.emit_tasks) { o.n_win = 0; om.n_win = 0; PUT_BOTH(); return; }
     // 7. window tasks of both directions
     uint32_t first_win = 0;
-    if (lane == 0) first_win = atomicAdd(A.task_counter, (uint32_t)(o.n_win + om.n_win));
+    if (lane == 0) {
+        first_win = atomicAdd(A.task_counter, (uint32_t)(o.n_win + om.n_win));
+        // statistics: DP columns of the windows handed to K5, both directions
+        atomicAdd(reinterpret_cast<unsigned long long *>(A.task_counter + 4), (unsigned long long)(xe - xs + 1) + (unsigned long long)(om.x_e - om.x_s + 1));
+    }
     first_win = __shfl(first_win, 0, 64);
     if ((uint64_t)first_win + (uint32_t)(o.n_win + om.n_win) > A.task_cap) {
         if (lane == 0) { atomicExch(A.overflow, 1u); o.valid = 0; o.n_win = 0; om.valid = 0; om.n_win = 0; A.ovl[p] = o; A.ovl[pm] = om; }
