@@ -38,7 +38,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
                                         "k_repack", "k_exact", "k_stitch"};
 
 struct AsmWs {
-    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2,
+    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, set_cols,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     // state of the last run (for fsv_asm_fetch_reads / stats)
@@ -52,7 +52,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &set_cols, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -207,7 +207,9 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     A.set_start = (const uint32_t *)W.set_start.p; A.pair_base = (const uint32_t *)W.pair_base.p; A.upair_base = (const uint32_t *)W.upair_base.p;
     A.mz = (const fsv_mz *)W.mz.p; A.mz_off = (const uint32_t *)W.mz_off.p; A.mz_cnt = (const uint32_t *)W.mz_cnt.p;
     A.ovl = (fsv_ovl *)W.ovl.p; A.tasks = (fsv_wtask *)W.tasks.p; A.task_counter = (uint32_t *)W.counters.p; A.task_cap = task_cap;
-    A.overflow = (uint32_t *)W.counters.p + 1; A.warn = (uint32_t *)W.warn.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
+    TRY(ensure(ctx, W.set_cols, (size_t)B.n_reads * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.set_cols.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+    A.overflow = (uint32_t *)W.counters.p + 1; A.warn = (uint32_t *)W.warn.p; A.set_cols = (uint32_t *)W.set_cols.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
     A.n_sets = B.n_sets; A.k_score = P.k; A.min_anchors = P.min_anchors; A.min_ovlp = P.min_ovlp; A.bw = bw; A.emit_tasks = emit_tasks ? 1 : 0;
     // algorithmic bytes of the pairwise join: every unordered pair reads both unique-minimizer lists (16 B each) and writes two
     // overlap slots; the window tasks it emits are added once their number is known
@@ -507,7 +509,13 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             uint32_t cnt2[8];
             FSV_HIP(ctx, hipMemcpyAsync(cnt2, W.counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
             FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            W.stats.dp_columns += (uint64_t)cnt2[4] | (uint64_t)cnt2[5] << 32;   // K5 windows (k_chain) + rescue re-runs (k_rescue_accept)
+            W.stats.dp_columns += (uint64_t)cnt2[4] | (uint64_t)cnt2[5] << 32;   // rescue re-runs (k_rescue_accept)
+            {
+                std::vector<uint32_t> sc(B.n_reads);
+                FSV_HIP(ctx, hipMemcpyAsync(sc.data(), W.set_cols.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+                FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                for (uint32_t s2 = 0; s2 < B.n_sets; s2++) if (B.set_start[s2] < B.n_reads) W.stats.dp_columns += sc[B.set_start[s2]]; // K5 windows
+            }
             uint32_t n_dp = cnt2[2];
             const uint32_t n_dp_wide = cnt2[6];
             const uint32_t *narrow_list = (const uint32_t *)W.dp_list.p;

@@ -325,6 +325,7 @@ struct ChainArgs {
     uint32_t task_cap;
     uint32_t *overflow;          // set to 1 when the task array is full
     uint32_t *warn;              // per read
+    uint32_t *set_cols;          // per read, used at the first read of every set: K5 columns emitted for the set (statistics)
     const uint8_t *thr_tab;      // 376 entries: threshold for a window of that length
     uint32_t n_sets;
     int32_t k_score, min_anchors, min_ovlp, bw, emit_tasks;
@@ -577,8 +578,9 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     uint32_t first_win = 0;
     if (lane == 0) {
         first_win = atomicAdd(A.task_counter, (uint32_t)(o.n_win + om.n_win));
-        // statistics: DP columns of the windows handed to K5, both directions
-        atomicAdd(reinterpret_cast<unsigned long long *>(A.task_counter + 4), (unsigned long long)(xe - xs + 1) + (unsigned long long)(om.x_e - om.x_s + 1));
+        // statistics: DP columns of the windows handed to K5, both directions; one counter per set (indexed by the set's first
+        // read) -- a single shared counter costs ~10 ns per pair in same-address atomics
+        atomicAdd(&A.set_cols[pt.x], (uint32_t)(xe - xs + 1) + (uint32_t)(om.x_e - om.x_s + 1));
     }
     first_win = __shfl(first_win, 0, 64);
     if ((uint64_t)first_win + (uint32_t)(o.n_win + om.n_win) > A.task_cap) {
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     __shared__ uint32_t s_path[64][27];            // per lane: the 26 op words of its window path (odd stride); reused as s_out
     __shared__ uint16_t s_evcol[FSV_EV_CAP];
     __shared__ uint32_t s_evkey[FSV_EV_CAP];
-    __shared__ uint32_t s_evn, s_cover;
+    __shared__ uint32_t s_evn, s_cover, s_anydev;   // s_anydev: some overlap deviates from the backbone somewhere in this window
     __shared__ uint32_t s_xraw[28];                // raw store words covering x[gs-16 .. gs+glen+16)
     __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
@@ -1060,7 +1062,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((xlen + 15) >> 4)) ? A.store[xw + wi] : 0u; }
     for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
-    if (lane == 0) { s_evn = 0; s_cover = 0; }
+    if (lane == 0) { s_evn = 0; s_cover = 0; s_anydev = 0; }
     __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
 #define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
@@ -1075,11 +1077,15 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         const uint4 h0 = *reinterpret_cast<const uint4 *>(P);                      // ry_start, ry_end, path_len|err, state|rev|pad
         if ((h0.w & 0xffu) != 1u) continue;
         const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16); // y_word, y_len
-        {
+        // a path at distance 0 is all matches (every window from the second round on, a fifth of them in the first): its 104 op
+        // bytes are not even fetched, it only adds its coverage interval
+        const bool clean_path = (int16_t)(h0.z >> 16) == 0;
+        if (!clean_path) {
             const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
 #pragma unroll
             for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
         }
+        bool dev_here = false;
         atomicAdd(&s_cover, 1u);
         const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
         const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
             if ((hp.w & 0xffu) == 1u) {
                 const int gap = ry_start - (int)hp.y - 1;
                 if (gap > 0 && xs == 0) {
-                    pend = true;
+                    pend = true; dev_here = true;
                     if (gap <= FSV_INS_MAXLEN) {
                         uint32_t key = (uint32_t)gap << 24;
                         for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
@@ -1104,9 +1110,11 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         // deviations: skip the all-match remainder of a path word at a time; n2 / n3 = y-only / x-only ops seen so far
 #define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
         int n2 = 0, n3 = 0;
-        for (int p = 0; p < plen;) {
+        if (clean_path && pend) { CNT_ADD(xs, 5u); pend = false; }   // the first op is a match at column xs
+        for (int p = 0; !clean_path && p < plen;) {
             const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1); // this word from field p on (fields past plen are 0)
             if (rest == 0u && !pend) { p = ((p >> 4) + 1) << 4; continue; }
+            dev_here = true;
             const uint32_t op = rest & 3u;
             const int xp = xs + p - n2;
             if (op == 2u) { // run of y-only ops in front of column xp
@@ -1135,6 +1143,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         const int xcols = plen - n2;
         atomicAdd(&s_cov[xs], 1);
         atomicAdd(&s_cov[xs + xcols], -1);
+        if (dev_here) s_anydev = 1u;
 #undef YB
     }
     __syncthreads();
@@ -1149,7 +1158,8 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     __syncthreads();
     uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]); // 375 x 14 B = 5.2 KB <= 64 x 27 x 4 B; paths are done
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
-    const bool verbatim = s_cover < 3u;
+    // fewer than three overlaps: the reference leaves the window alone; no deviation anywhere: every vote is for the backbone
+    const bool verbatim = s_cover < 3u || s_anydev == 0u;
     const uint32_t evn = min(s_evn, (uint32_t)FSV_EV_CAP);
     if (s_evn > FSV_EV_CAP && lane == 0) atomicOr(&A.warn[r], 8u);
     int arrived = before;
