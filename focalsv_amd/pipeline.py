@@ -8,6 +8,7 @@ collective while computing); `gather_vcf` is the one exchange step -- the analog
 (focalsv/focalsv.py:66-70) -- an all-gather of per-rank VCF bytes (RCCL on GPUs, gloo in the CPU tests).
 """
 import threading
+import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -115,6 +116,8 @@ def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', 
 
     def _read_side():
         try:
+            # let the calling thread reach the library call first: two Python threads hand the GIL over every 5 ms only
+            time.sleep(0.002)
             for chrom in chroms:
                 ref = WindowedRef()
                 ref.wins = sorted((r.start, r.ref.decode()) for r in regions if r.chrom == chrom)
@@ -126,16 +129,19 @@ def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', 
         except BaseException as e:   # re-raised on the calling thread
             side_err.append(e)
 
+    t_enter = time.perf_counter()
     side = threading.Thread(target=_read_side, name="fsv-read-signatures")
     side.start()
     try:
+        res = _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err)
+        res.host_ms["total"] = round((time.perf_counter() - t_enter) * 1e3, 2)
+        return res
         return _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err)
     finally:
         side.join()
 
 
 def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err) -> CallResult:
-    import time
     host_ms, t_prev = {}, [time.perf_counter()]
 
     def lap(name):
