@@ -9,6 +9,7 @@ The reference picks the survivor among equal-length calls through Python set ite
 here the tie goes to the call that comes first in the VCF.
 """
 import os
+from bisect import bisect_left
 
 
 def edit_distance(a: str, b: str) -> int:
@@ -79,11 +80,16 @@ def _sorted_autosomes(recs):
 
 def _links(recs, match, dist):
     links = []
+    by_chrom = {}
+    for r in recs:
+        by_chrom.setdefault(r[0], []).append(r)
     for i in range(1, 23):
-        name = 'chr%d' % i
-        mine = [r for r in recs if r[0] == name]
+        mine = by_chrom.get('chr%d' % i, [])
+        pos = [r[1] for r in mine]
         for x, a in enumerate(mine):
-            for y, b in enumerate(mine):
+            # position-sorted input: records left of a - dist cannot link, start behind them (same links, same order)
+            for y in range(bisect_left(pos, a[1] - dist), len(mine)):
+                b = mine[y]
                 if b[1] > a[1] + dist:
                     break
                 if x != y and a[1] - dist <= b[1] <= a[1] + dist and match(a, b):

@@ -17,6 +17,7 @@ from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
+from bisect import bisect_left
 
 BAM_M, BAM_I, BAM_D, BAM_S, BAM_H = 0, 1, 2, 4, 5
 
@@ -193,15 +194,14 @@ def _seed_cluster(sigs, same, max_shift=None):
                 break
             if label[j] == -1 and same(a, b):
                 label[j] = i
-    out = []
-    for seed in Counter(label):  # first-seen order, as the reference iterates its Counter
-        members = [s for s, l in zip(sigs, label) if l == seed]
-        best = members[0]
-        for m in members:
-            if m[3] > best[3]:
-                best = m
-        out.append(best)
-    return out
+    # one representative per cluster, clusters in first-seen order (the reference iterates a Counter of the labels), the
+    # longest member, first on ties
+    best = {}
+    for s, l in zip(sigs, label):
+        b = best.get(l)
+        if b is None or s[3] > b[3]:
+            best[l] = s
+    return list(best.values())
 
 
 def _del_match(a, b, max_shift, min_overlap, min_size_sim):
@@ -260,8 +260,13 @@ def signatures_one_hap(records: Sequence, hp: str, profile: Profile = PROFILES["
 def pair_sig(sig_hp1, sig_hp2, max_compare_dist=1000, max_shift=200, min_overlap_ratio=0.5, min_size_similarity=0.5):
     """CCS:504-559.  Note the reference ignores its max_shift/ratio arguments and hard-codes 200 / 0.5 / 0.5."""
     partner1, partner2 = [-1] * len(sig_hp1), [-1] * len(sig_hp2)
+    pos2 = [b[2] for b in sig_hp2]
+    in_order = all(pos2[k] <= pos2[k + 1] for k in range(len(pos2) - 1))   # the reference always passes sort_sig output
     for i, a in enumerate(sig_hp1):
-        for j, b in enumerate(sig_hp2):
+        # a pair needs |dpos| <= 200: signatures more than that to the left cannot match, so the scan may start behind them
+        j0 = bisect_left(pos2, a[2] - 200) if in_order else 0
+        for j in range(j0, len(sig_hp2)):
+            b = sig_hp2[j]
             if b[2] - a[2] > max_compare_dist:
                 break
             if a[:2] == b[:2] and partner2[j] == -1:
