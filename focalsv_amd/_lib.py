@@ -346,7 +346,7 @@ class Context:
             cseq = np.frombuffer(b"".join(contigs) + b"\0", dtype=np.uint8)
             total = int(coff[-1])
         cref = np.ascontiguousarray(contig_ref, dtype=np.uint32)
-        rec = np.zeros(max(1, n), dtype=ALN_REC_DTYPE)
+        rec = np.zeros(max(1, 3 * n), dtype=ALN_REC_DTYPE)   # primary + up to two supplementary records per contig
         cap = total // 8 + 4096 * max(1, n)
         cigar = np.empty(cap, dtype=np.uint32)
         status = np.zeros(max(1, n), dtype=np.int32)

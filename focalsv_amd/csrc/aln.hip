@@ -18,6 +18,8 @@
 namespace {
 
 #define ALN_AMAX 8192
+#define ALN_MAX_REC 3       // records per contig: the primary chain and up to two supplementary ones
+#define ALN_SUP_MIN 200     // chain score a supplementary chain needs
 #define ALN_EV_CAP 2048      // events per pair
 #define ALN_CG_CAP 1024      // CIGAR runs per event
 #define NW_LDS_Q 3072        // query length up to which the rolling DP rows live in LDS (11 x 4 B x 3072 = 132 KB of the CU's 160)
@@ -40,11 +42,13 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
     __shared__ int32_t s_f[ALN_AMAX];
     __shared__ uint16_t s_aux[ALN_AMAX];
     const int lane = threadIdx.x;
-    const uint32_t p = blockIdx.x, rq = pair_q[p], rt = pair_t[p];
+    // one block per contig; its records go to the slots p0 .. p0 + ALN_MAX_REC - 1 (pair_q / pair_t / hdr / chain are per slot)
+    const uint32_t p0 = blockIdx.x * ALN_MAX_REC, rq = pair_q[p0], rt = pair_t[p0];
     const int lenq = read_len[rq];
     const int nq = (int)mz_cnt[rq], nt = (int)mz_cnt[rt];
     const fsv_mz *mq = mz + mz_off[rq] + nq, *mt = mz + mz_off[rt]; // contig: position-sorted copy, reference: hash-sorted
     AlnHeader h; h.qbeg = h.tbeg = h.qend = h.tend = 0; h.n_events = 0; h.n_chain = 0; h.rev = 0; h.status = 1; h.ev_off = 0; h.pad = 0;
+    if (lane < ALN_MAX_REC) hdr[p0 + lane] = h;   // every slot starts out empty
     int n = 0, nrev = 0, nfwd = 0;
     for (int base = 0; base < nq; base += 64) {
         int i = base + lane;
@@ -86,54 +90,76 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
         __syncthreads();
     }
     n = m2;
-    if (n < P.min_anchors) { if (lane == 0) hdr[p] = h; return; }
+    if (n < P.min_anchors) return;
     // anchors arrive in contig order; on the reverse strand the contig coordinate was mirrored, so the order is reversed
     if (rev) {
         for (int i = lane; i < n / 2; i += 64) { const uint64_t a = s_key[i], b = s_key[n - 1 - i]; s_key[i] = b; s_key[n - 1 - i] = a; }
         __syncthreads();
     }
-    for (int i = 0; i < n; i++) {
-        const uint64_t ki = s_key[i];
-        const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
-        const int j = i - 1 - lane;
-        int cand = -1; // -1 = no legal predecessor (a legal candidate is >= k - 200 + k > -1 ... kept distinct by `ok`)
-        bool ok = false;
-        if (j >= 0) {
-            const uint64_t kj = s_key[j];
-            const int dq = qe - (int)(kj >> 32), dt = te - (int)(uint32_t)kj;
-            if (dq > 0 && dt > 0) {
-                const int gap = dq > dt ? dq - dt : dt - dq;
-                if (gap <= P.max_gap) {
-                    int sc = min(min(dq, dt), P.k);
-                    if (gap) sc -= (gap >> 7) + (ilog2_u32((uint32_t)gap) >> 1) + 1;
-                    cand = sc + s_f[j];
-                    ok = true;
+    // The best chain is the primary alignment.  What it leaves uncovered is chained again (minimap2 reports such pieces as
+    // supplementary alignments, and DipPAV calls the SVs beyond the chaining gap from consecutive records of one contig,
+    // extract_contig_signature_CCS.py:251-327): the anchors inside the query interval of a chain are taken out -- they are a
+    // contiguous run, the list is in query order -- and the rest goes through the same DP, up to ALN_MAX_REC chains.
+    for (int rec = 0; rec < ALN_MAX_REC && n >= P.min_anchors; rec++) {
+        for (int i = 0; i < n; i++) {
+            const uint64_t ki = s_key[i];
+            const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
+            const int j = i - 1 - lane;
+            int cand = -1; // -1 = no legal predecessor (a legal candidate is >= k - 200 + k > -1 ... kept distinct by `ok`)
+            bool ok = false;
+            if (j >= 0) {
+                const uint64_t kj = s_key[j];
+                const int dq = qe - (int)(kj >> 32), dt = te - (int)(uint32_t)kj;
+                if (dq > 0 && dt > 0) {
+                    const int gap = dq > dt ? dq - dt : dt - dq;
+                    if (gap <= P.max_gap) {
+                        int sc = min(min(dq, dt), P.k);
+                        if (gap) sc -= (gap >> 7) + (ilog2_u32((uint32_t)gap) >> 1) + 1;
+                        cand = sc + s_f[j];
+                        ok = true;
+                    }
                 }
             }
+            // scores can drop below zero here (gap penalty), so bias before packing; lanes without a legal predecessor sit out
+            const bool legal = ok;
+            const int mine = legal ? ((cand + (1 << 20)) * 64 + (63 - lane)) : -1; // < 2^27
+            const int bestp = wave_max_i32(mine);
+            const int bests = bestp < 0 ? -(1 << 30) : (int)(bestp >> 6) - (1 << 20);
+            if (bests > P.k) { if (mine == bestp) { s_f[i] = bests; s_aux[i] = (uint16_t)j; } }
+            else if (lane == 0) { s_f[i] = P.k; s_aux[i] = 0xffff; }
+            __syncthreads();
         }
-        // scores can drop below zero here (gap penalty), so bias before packing; lanes without a legal predecessor sit out
-        const bool legal = ok;
-        const int mine = legal ? ((cand + (1 << 20)) * 64 + (63 - lane)) : -1; // < 2^27
-        const int bestp = wave_max_i32(mine);
-        const int bests = bestp < 0 ? -(1 << 30) : (int)(bestp >> 6) - (1 << 20);
-        if (bests > P.k) { if (mine == bestp) { s_f[i] = bests; s_aux[i] = (uint16_t)j; } }
-        else if (lane == 0) { s_f[i] = P.k; s_aux[i] = 0xffff; }
+        long long bk = -1;
+        for (int i = lane; i < n; i += 64) { long long v = (long long)s_f[i] * 16384 + (16383 - i); bk = v > bk ? v : bk; }
+        bk = wave_max_i64(bk);
+        const int best = 16383 - (int)(bk & 16383);
+        int cnt = 0, first = best;
+        if (lane == 0) { int c = best; while (c != 0xffff) { cnt++; first = c; c = s_aux[c]; } }
+        cnt = __shfl(cnt, 0, 64); first = __shfl(first, 0, 64);
+        if (cnt < P.min_anchors || (rec > 0 && s_f[best] < ALN_SUP_MIN)) break;
+        if (lane == 0) {
+            uint64_t *out = chain_out + (size_t)(p0 + rec) * ALN_AMAX;
+            int c = best, k2 = cnt;
+            while (c != 0xffff) { out[--k2] = s_key[c]; c = s_aux[c]; }
+            h.n_chain = cnt; h.status = 0;
+            hdr[p0 + rec] = h;
+        }
+        // drop the anchors whose query coordinate lies in [q(first), q(best)]: indices lo .. hi of the sorted list
+        const int qlo = (int)(s_key[first] >> 32), qhi = (int)(s_key[best] >> 32);
+        int lo = n, hi = -1;
+        for (int i = lane; i < n; i += 64) { const int qe = (int)(s_key[i] >> 32); if (qe >= qlo && qe <= qhi) { lo = min(lo, i); hi = max(hi, i); } }
+        lo = -wave_max_i32(-lo); hi = wave_max_i32(hi);
         __syncthreads();
-    }
-    long long bk = -1;
-    for (int i = lane; i < n; i += 64) { long long v = (long long)s_f[i] * 16384 + (16383 - i); bk = v > bk ? v : bk; }
-    bk = wave_max_i64(bk);
-    const int best = 16383 - (int)(bk & 16383);
-    int cnt = 0;
-    if (lane == 0) { int c = best; while (c != 0xffff) { cnt++; c = s_aux[c]; } }
-    cnt = __shfl(cnt, 0, 64);
-    if (cnt < P.min_anchors) { if (lane == 0) hdr[p] = h; return; }
-    if (lane == 0) {
-        uint64_t *out = chain_out + (size_t)p * ALN_AMAX;
-        int c = best, k2 = cnt;
-        while (c != 0xffff) { out[--k2] = s_key[c]; c = s_aux[c]; }
-        h.n_chain = cnt; h.status = 0;
-        hdr[p] = h;
+        const int tail = n - 1 - hi;
+        for (int base = 0; base < tail; base += 64) {   // move the tail down, front to back (ascending: no overlap hazard inside a pass)
+            const int i = base + lane;
+            uint64_t v = 0;
+            if (i < tail) v = s_key[hi + 1 + i];
+            __syncthreads();
+            if (i < tail) s_key[lo + i] = v;
+            __syncthreads();
+        }
+        n = lo + tail;
     }
 }
 
@@ -672,8 +698,14 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     TRY(pack_pairs(ctx, W, seq, slen, word_off, len, from_dev ? ctx->last_contigs_dev + contig_off[0] : nullptr, n_refs));
     trace("pack+h2d");
     TRY(upload(ctx, W.wper, wper));
-    TRY(upload(ctx, W.pair_q, pair_q));
-    TRY(upload(ctx, W.pair_t, pair_t));
+    // kernels index pairs by record slot: ALN_MAX_REC slots per contig (primary + supplementary chains)
+    const uint32_t R = ALN_MAX_REC, ns = np * R;
+    {
+        std::vector<uint32_t> sq(ns), st(ns);
+        for (uint32_t p = 0; p < np; p++) for (uint32_t r = 0; r < R; r++) { sq[p * R + r] = pair_q[p]; st[p * R + r] = pair_t[p]; }
+        TRY(upload(ctx, W.pair_q, sq));
+        TRY(upload(ctx, W.pair_t, st));
+    }
     std::vector<uint32_t> mz_off(nr + 1, 0);
     uint64_t m = 0;
     for (uint32_t r = 0; r < nr; r++) { mz_off[r] = (uint32_t)m; m += (uint64_t)len[r] + 64; } // worst case one minimizer per base
@@ -711,9 +743,9 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     trace("sketch+uniq");
     W.stats.ms_seed = tseed.stop();
     Timer tchain(ctx);
-    TRY(ensure(ctx, W.chain, (size_t)np * ALN_AMAX * 8));
-    TRY(ensure(ctx, W.hdr, (size_t)np * sizeof(AlnHeader)));
-    TRY(ensure(ctx, W.events, (size_t)np * ALN_EV_CAP * sizeof(AlnEvent)));
+    TRY(ensure(ctx, W.chain, (size_t)ns * ALN_AMAX * 8));
+    TRY(ensure(ctx, W.hdr, (size_t)ns * sizeof(AlnHeader)));
+    TRY(ensure(ctx, W.events, (size_t)ns * ALN_EV_CAP * sizeof(AlnEvent)));
     hipLaunchKernelGGL(k_chain_aln, dim3(np), dim3(64), 0, ctx->stream, (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p,
                        (const fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (const uint32_t *)W.mz_cnt.p, (const uint32_t *)W.pair_q.p,
                        (const uint32_t *)W.pair_t.p, (uint64_t *)W.chain.p, (AlnHeader *)W.hdr.p, P);
@@ -721,16 +753,16 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     trace("chain");
     W.stats.ms_chain = tchain.stop();
     Timer tev(ctx);
-    TRY(ensure(ctx, W.ev_packed, (size_t)np * ALN_EV_CAP * sizeof(AlnEvent)));
+    TRY(ensure(ctx, W.ev_packed, (size_t)ns * ALN_EV_CAP * sizeof(AlnEvent)));
     TRY(ensure(ctx, W.ev_count, 16));
     FSV_HIP(ctx, hipMemsetAsync(W.ev_count.p, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_aln_events, dim3(np), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+    hipLaunchKernelGGL(k_aln_events, dim3(ns), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
                        (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const uint64_t *)W.chain.p,
                        (AlnHeader *)W.hdr.p, (AlnEvent *)W.events.p, (AlnEvent *)W.ev_packed.p, (uint32_t *)W.ev_count.p, P);
     FSV_HIP(ctx, hipGetLastError());
-    std::vector<AlnHeader> hdr(np);
+    std::vector<AlnHeader> hdr(ns);
     uint32_t n_ev = 0;
-    FSV_HIP(ctx, hipMemcpyAsync(hdr.data(), W.hdr.p, (size_t)np * sizeof(AlnHeader), hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipMemcpyAsync(hdr.data(), W.hdr.p, (size_t)ns * sizeof(AlnHeader), hipMemcpyDeviceToHost, ctx->stream));
     FSV_HIP(ctx, hipMemcpyAsync(&n_ev, W.ev_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<AlnEvent> events(n_ev);
@@ -743,11 +775,11 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     // DP tasks
     Timer tdp(ctx);
     std::vector<NwTask> tasks;
-    std::vector<uint32_t> first_task(np + 1, 0);
+    std::vector<uint32_t> first_task(ns + 1, 0);
     uint64_t bt = 0, rows = 0;
-    for (uint32_t p = 0; p < np; p++) {
+    for (uint32_t p = 0; p < ns; p++) {   // p: record slot; contig = p / R
         first_task[p] = (uint32_t)tasks.size();
-        if (pre_status[p] != 0 || hdr[p].status != 0) continue;
+        if (pre_status[p / R] != 0 || hdr[p].status != 0) continue;
         for (int e = 0; e < hdr[p].n_events; e++) {
             const AlnEvent &ev = events[(size_t)hdr[p].ev_off + e];
             NwTask t;
@@ -761,7 +793,7 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
             tasks.push_back(t);
         }
     }
-    first_task[np] = (uint32_t)tasks.size();
+    first_task[ns] = (uint32_t)tasks.size();
     // CIGAR runs of the events: nearly all have a handful; the first CG_HEAD runs of every task come back in one strided copy,
     // longer ones are fetched individually
     constexpr uint32_t CG_HEAD = 8;
@@ -785,13 +817,15 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     trace("dp");
     W.stats.ms_dp = tdp.stop();
     W.stats.n_pairs = np; W.stats.n_events = tasks.size();
-    // stitch: S, M runs, events, S
-    for (uint32_t p = 0; p < np; p++) {
-        W.stats.algo_bytes += (uint64_t)(len[pair_q[p]] + len[pair_t[p]] + 3) / 4;
-        int32_t st = pre_status[p] != 0 ? pre_status[p] : hdr[p].status;
-        if (st == 0) {
-            std::vector<uint32_t> c;
+    // stitch: S, M runs, events, S -- one record per used slot, the primary first
+    for (uint32_t cp = 0; cp < np; cp++) {
+        W.stats.algo_bytes += (uint64_t)(len[pair_q[cp]] + len[pair_t[cp]] + 3) / 4;
+        int32_t st = pre_status[cp] != 0 ? pre_status[cp] : hdr[cp * R].status;
+        for (uint32_t r = 0; r < R && st == 0; r++) {
+            const uint32_t p = cp * R + r;
             const AlnHeader &h = hdr[p];
+            if (h.status != 0) { if (r == 0) st = h.status; break; }   // slots fill up in order
+            std::vector<uint32_t> c;
             push_cg(c, 4, (uint32_t)h.qbeg);
             int mstart = h.qbeg;
             for (uint32_t t = first_task[p]; t < first_task[p + 1] && st == 0; t++) {
@@ -804,17 +838,18 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
             }
             if (st == 0) {
                 push_cg(c, 0, (uint32_t)(h.qend + 1 - mstart));
-                push_cg(c, 4, (uint32_t)(len[pair_q[p]] - 1 - h.qend));
+                push_cg(c, 4, (uint32_t)(len[pair_q[cp]] - 1 - h.qend));
+                if (out->n_rec >= out->rec_cap) return fsv_fail(ctx, FSV_ECAP, "record buffer too small (rec_cap >= 3 x n_contigs holds every case)");
                 if (out->n_cigar + c.size() > out->cigar_cap) return fsv_fail(ctx, FSV_ECAP, "cigar buffer too small");
-                fsv_aln_rec &r = out->rec[out->n_rec++];
-                r.ref_start = h.tbeg; r.ref_end = h.tend + 1; r.q_start = h.qbeg; r.q_end = h.qend + 1; r.n_cigar = (uint32_t)c.size();
-                r.n_chain = (uint32_t)h.n_chain; r.cigar_off = out->n_cigar; r.contig = p; r.rev = (uint8_t)h.rev; r.mapq = 60; r.pad[0] = r.pad[1] = 0;
+                fsv_aln_rec &rr = out->rec[out->n_rec++];
+                rr.ref_start = h.tbeg; rr.ref_end = h.tend + 1; rr.q_start = h.qbeg; rr.q_end = h.qend + 1; rr.n_cigar = (uint32_t)c.size();
+                rr.n_chain = (uint32_t)h.n_chain; rr.cigar_off = out->n_cigar; rr.contig = cp; rr.rev = (uint8_t)h.rev; rr.mapq = 60; rr.pad[0] = rr.pad[1] = 0;
                 memcpy(out->cigar + out->n_cigar, c.data(), c.size() * 4);
                 out->n_cigar += c.size();
                 W.stats.algo_bytes += c.size() * 4;
             }
         }
-        out->contig_status[p] = st;
+        out->contig_status[cp] = st;
     }
     trace("stitch");
     W.stats.ms_total = ttot.stop();

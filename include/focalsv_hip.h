@@ -264,14 +264,18 @@ typedef struct fsv_aln_rec {
 } fsv_aln_rec;                    /* 40 bytes */
 
 typedef struct fsv_alns {
-    fsv_aln_rec *rec;       /* host, capacity rec_cap (>= n_contigs) */
+    fsv_aln_rec *rec;       /* host, capacity rec_cap: 3 x n_contigs holds every case (FSV_ALN_MAX_REC records per contig) */
     uint32_t  rec_cap, n_rec;
     uint32_t *cigar;        /* host, BAM encoding len << 4 | op */
     uint64_t  cigar_cap, n_cigar;
     int32_t  *contig_status; /* host, n_contigs: 0 aligned, 1 no chain (unaligned), <0 FSV_E* for that contig */
 } fsv_alns;
 
-/* contig i is aligned to reference window contig_ref[i].
+#define FSV_ALN_MAX_REC 3
+/* contig i is aligned to reference window contig_ref[i].  A contig yields its primary record and, when the primary chain leaves
+ * part of the contig uncovered (an SV beyond max_gap), up to two supplementary records -- consecutive in `rec`, primary first,
+ * soft clips for the parts the record does not align -- from which DipPAV's split-alignment rules call the SV
+ * (extract_contig_signature_CCS.py:251-327).
  * contig_seq == NULL (contig_off ignored): align the n_contigs contigs of the last fsv_assemble_batch on this context straight
  * from device memory, in their output order -- the device-resident hand-off between the two boundaries. */
 int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint64_t *contig_off, uint32_t n_contigs,

@@ -129,12 +129,16 @@ static int anc_cmp(const void *a, const void *b)
 
 static inline int ilog2_32(uint32_t v) { int l = 0; while (v >>= 1) l++; return l; }
 
-/* chain of (contig, reference); on the reverse strand the contig coordinates are those of its reverse complement.
- * returns the number of chain anchors (0 = none) */
-int orc_aln_chain(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, const orc_aln_params *P, int *rev_out,
-                  int32_t *cq, int32_t *ct, int cap)
+/* chains of (contig, reference); on the reverse strand the contig coordinates are those of its reverse complement.
+ * The best chain is the primary alignment.  Like minimap2, which reports what the primary leaves uncovered as supplementary
+ * alignments (DipPAV calls SVs beyond the chaining gap from consecutive records of one contig,
+ * extract_contig_signature_CCS.py:251-327), the anchors inside the query interval of a chain are then taken out and the rest
+ * is chained again, up to ORC_ALN_MAX_REC chains on the contig's majority strand; a supplementary chain needs a score of
+ * ORC_ALN_SUP_MIN.  chain_n[r] anchors of chain r follow each other in cq/ct.  Returns the number of chains. */
+int orc_aln_chains(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, const orc_aln_params *P, int *rev_out,
+                   int32_t *cq, int32_t *ct, int cap, int *chain_n, int max_rec)
 {
-    int i = 0, j = 0, n = 0, nf = 0, nr = 0, rev, best = -1, cnt = 0, c;
+    int i = 0, j = 0, n = 0, nf = 0, nr = 0, rev, c, n_rec = 0, used = 0;
     int lim = nq < nt ? nq : nt;
     anc_t *a; uint8_t *sr; int32_t *f, *pre;
     if (lim <= 0) return 0;
@@ -159,28 +163,43 @@ int orc_aln_chain(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, 
     if (n < P->min_anchors) { free(a); return 0; }
     qsort(a, (size_t)n, sizeof(anc_t), anc_cmp);
     f = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 2); pre = f + n;
-    for (i = 0; i < n; i++) {
-        int32_t bs = P->k, bp = -1;
-        int lo = i - P->lookback < 0 ? 0 : i - P->lookback;
-        for (j = i - 1; j >= lo; j--) {
-            int32_t dq = a[i].qe - a[j].qe, dt = a[i].te - a[j].te, gap, sc;
-            if (dq <= 0 || dt <= 0) continue;
-            gap = dq > dt ? dq - dt : dt - dq;
-            if (gap > P->max_gap) continue;
-            sc = dq < dt ? dq : dt;
-            if (sc > P->k) sc = P->k;
-            if (gap) sc -= (gap >> 7) + (ilog2_32((uint32_t)gap) >> 1) + 1;
-            sc += f[j];
-            if (sc > bs) { bs = sc; bp = j; }
+    while (n_rec < max_rec && n >= P->min_anchors) {
+        int best = -1, cnt = 0, qlo, qhi;
+        for (i = 0; i < n; i++) {
+            int32_t bs = P->k, bp = -1;
+            int lo = i - P->lookback < 0 ? 0 : i - P->lookback;
+            for (j = i - 1; j >= lo; j--) {
+                int32_t dq = a[i].qe - a[j].qe, dt = a[i].te - a[j].te, gap, sc;
+                if (dq <= 0 || dt <= 0) continue;
+                gap = dq > dt ? dq - dt : dt - dq;
+                if (gap > P->max_gap) continue;
+                sc = dq < dt ? dq : dt;
+                if (sc > P->k) sc = P->k;
+                if (gap) sc -= (gap >> 7) + (ilog2_32((uint32_t)gap) >> 1) + 1;
+                sc += f[j];
+                if (sc > bs) { bs = sc; bp = j; }
+            }
+            f[i] = bs; pre[i] = bp;
         }
-        f[i] = bs; pre[i] = bp;
+        for (i = 0; i < n; i++) if (best < 0 || f[i] > f[best]) best = i;
+        for (c = best; c >= 0; c = pre[c]) cnt++;
+        if (cnt < P->min_anchors || used + cnt > cap || (n_rec > 0 && f[best] < ORC_ALN_SUP_MIN)) break;
+        { int k2 = used + cnt; for (c = best; c >= 0; c = pre[c]) { k2--; cq[k2] = a[c].qe; ct[k2] = a[c].te; } }
+        chain_n[n_rec++] = cnt;
+        qlo = cq[used]; qhi = cq[used + cnt - 1];
+        used += cnt;
+        for (i = 0, j = 0; i < n; i++) if (a[i].qe < qlo || a[i].qe > qhi) a[j++] = a[i]; /* the rest, still in query order */
+        n = j;
     }
-    for (i = 0; i < n; i++) if (best < 0 || f[i] > f[best]) best = i;
-    for (c = best; c >= 0; c = pre[c]) cnt++;
-    if (cnt >= P->min_anchors && cnt <= cap) { int k2 = cnt; for (c = best; c >= 0; c = pre[c]) { k2--; cq[k2] = a[c].qe; ct[k2] = a[c].te; } }
-    else cnt = 0;
     free(f); free(a);
-    return cnt;
+    return n_rec;
+}
+
+int orc_aln_chain(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, const orc_aln_params *P, int *rev_out,
+                  int32_t *cq, int32_t *ct, int cap)
+{
+    int cn[1] = {0};
+    return orc_aln_chains(mq, nq, lenq, mt, nt, P, rev_out, cq, ct, cap, cn, 1) ? cn[0] : 0;
 }
 
 /* ------------------------------------------------------------------ one contig against one reference window */
@@ -191,22 +210,12 @@ static void push(uint32_t *cg, int *n, int cap, uint32_t op, uint32_t len)
     if (*n < cap) cg[(*n)++] = len << 4 | op;
 }
 
-int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
-                     uint32_t *cigar, int cigar_cap)
+/* one chain -> one record: 1 ok, -1 an event larger than max_cells */
+static int align_chain(const char *Q, int lenq, const char *ref, int lent, const int32_t *cq, const int32_t *ct, int nch, int rev,
+                       const orc_aln_params *P, orc_aln *out, uint32_t *cigar, int cigar_cap)
 {
-    orc_mz *mq = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)(lenq + 8)), *mt = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)(lent + 8));
-    int nq, nt, rev = 0, nch, i, n = 0, w = P->w;
-    int32_t *cq, *ct;
-    char *q = NULL;
-    const char *Q;
+    int i, n = 0;
     memset(out, 0, sizeof(*out));
-    nq = orc_unique_sorted(mq, orc_sketch(contig, lenq, w, P->k, 0, mq, lenq + 8));
-    nt = orc_unique_sorted(mt, orc_sketch(ref, lent, w, P->k, 0, mt, lent + 8));
-    cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nq + 1) * 2); ct = cq + nq + 1;
-    nch = orc_aln_chain(mq, nq, lenq, mt, nt, P, &rev, cq, ct, nq);
-    free(mq); free(mt);
-    if (nch == 0) { free(cq); return 0; }
-    if (rev) { q = (char *)malloc((size_t)lenq); for (i = 0; i < lenq; i++) q[i] = comp(contig[lenq - 1 - i]); Q = q; } else Q = contig;
     {
         /* segment classes between consecutive anchors: 0 identical, 1 few mismatches ('M'), 2 needs DP */
         int nseg = nch - 1, s;
@@ -260,7 +269,7 @@ int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, co
                     eqs -= lp; ets -= lp; eqe += rp; ete += rp;
                     ql = eqe - eqs + 1; tl = ete - ets + 1;
                     push(cigar, &n, cigar_cap, 0, (uint32_t)(eqs - mstart_q));
-                    if ((int64_t)ql * tl > P->max_cells) { free(cls); free(cq); free(q); return -1; }
+                    if ((int64_t)ql * tl > P->max_cells) { free(cls); return -1; }
                     cg2 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(ql + tl + 2));
                     bt = (uint8_t *)malloc((size_t)(ql > 0 ? ql : 1) * (size_t)(tl > 0 ? tl : 1));
                     if (ql == 0) { nc = 1; cg2[0] = (uint32_t)tl << 4 | 2; }
@@ -279,6 +288,39 @@ int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, co
         out->n_chain = nch; out->q_start = qbeg; out->q_end = qend + 1;
         free(cls);
     }
-    free(cq); free(q);
     return 1;
+}
+
+/* all records of one contig (primary first, then supplementary chains); cigar[r] holds record r's ops from r * cigar_cap.
+ * returns the number of records, -1 when an event exceeds max_cells */
+int orc_align_contig_multi(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
+                           uint32_t *cigar, int cigar_cap, int max_rec)
+{
+    orc_mz *mq = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)(lenq + 8)), *mt = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)(lent + 8));
+    int nq, nt, rev = 0, n_rec, i, r, w = P->w, off = 0, rc = 0;
+    int chain_n[ORC_ALN_MAX_REC];
+    int32_t *cq, *ct;
+    char *q = NULL;
+    const char *Q;
+    if (max_rec > ORC_ALN_MAX_REC) max_rec = ORC_ALN_MAX_REC;
+    nq = orc_unique_sorted(mq, orc_sketch(contig, lenq, w, P->k, 0, mq, lenq + 8));
+    nt = orc_unique_sorted(mt, orc_sketch(ref, lent, w, P->k, 0, mt, lent + 8));
+    cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nq + 1) * 2); ct = cq + nq + 1;
+    n_rec = orc_aln_chains(mq, nq, lenq, mt, nt, P, &rev, cq, ct, nq, chain_n, max_rec);
+    free(mq); free(mt);
+    if (n_rec == 0) { free(cq); return 0; }
+    if (rev) { q = (char *)malloc((size_t)lenq); for (i = 0; i < lenq; i++) q[i] = comp(contig[lenq - 1 - i]); Q = q; } else Q = contig;
+    for (r = 0; r < n_rec && rc >= 0; r++) {
+        rc = align_chain(Q, lenq, ref, lent, cq + off, ct + off, chain_n[r], rev, P, &out[r], cigar + (size_t)r * cigar_cap, cigar_cap);
+        off += chain_n[r];
+    }
+    free(cq); free(q);
+    return rc < 0 ? -1 : n_rec;
+}
+
+int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
+                     uint32_t *cigar, int cigar_cap)
+{
+    int n = orc_align_contig_multi(contig, lenq, ref, lent, P, out, cigar, cigar_cap, 1);
+    return n < 0 ? -1 : (n > 0);
 }

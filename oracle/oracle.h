@@ -84,6 +84,12 @@ int orc_aln_chain(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, 
                   int32_t *cq, int32_t *ct, int cap);
 int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
                      uint32_t *cigar, int cigar_cap);
+#define ORC_ALN_MAX_REC 3      /* records per contig: primary + supplementary chains */
+#define ORC_ALN_SUP_MIN 200    /* chain score a supplementary chain needs */
+int orc_aln_chains(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, const orc_aln_params *P, int *rev_out,
+                   int32_t *cq, int32_t *ct, int cap, int *chain_n, int max_rec);
+int orc_align_contig_multi(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
+                           uint32_t *cigar, int cigar_cap, int max_rec);
 int orc_sketch(const char *s, int len, int w, int k, int hpc, orc_mz *out, int cap);
 int orc_bpm(const char *y, int m, const char *x, int n, int k, int *err);
 int orc_bpm_path(const char *y, int m, const char *x, int n, int k, int *err, int *start_site, int *path_len,

@@ -144,3 +144,19 @@ def align_contig(contig: bytes, ref: bytes, params=None):
         return None
     return {"ref_start": a.ref_start, "ref_end": a.ref_end, "rev": int(a.rev), "mapq": int(a.mapq), "q_start": a.q_start, "q_end": a.q_end,
             "cigar": [(int(c) & 0xf, int(c) >> 4) for c in cg[: a.n_cigar]], "raw": cg[: a.n_cigar].copy()}
+
+
+def align_contig_multi(contig: bytes, ref: bytes, params=None, max_rec=3):
+    """primary + supplementary records of one contig -> list of dicts as align_contig returns (empty: unaligned)"""
+    p = params or aln_default_params()
+    cap = 1 << 16
+    cg = np.zeros(cap * max_rec, dtype=np.uint32)
+    recs = (Aln * max_rec)()
+    n = lib().orc_align_contig_multi(contig, len(contig), ref, len(ref), C.byref(p), recs, cg.ctypes.data_as(C.c_void_p), cap, max_rec)
+    out = []
+    for r in range(max(0, n)):
+        a = recs[r]
+        c = cg[r * cap: r * cap + a.n_cigar]
+        out.append({"ref_start": a.ref_start, "ref_end": a.ref_end, "rev": int(a.rev), "mapq": int(a.mapq), "q_start": a.q_start, "q_end": a.q_end,
+                    "cigar": [(int(x) & 0xf, int(x) >> 4) for x in c], "raw": c.copy()})
+    return out

@@ -80,3 +80,35 @@ def test_unalignable_contig_is_reported(ctx):
     rec, cigar, status = ctx.align_batch([junk, ref[100:4000]], [0, 0], [ref])
     assert status[0] == 1 and status[1] == 0 and len(rec) == 1
     assert int(rec[0]["ref_start"]) == 100 and int(rec[0]["ref_end"]) == 4000
+
+
+def test_supplementary_records_for_svs_beyond_the_chaining_gap(ctx):
+    """a 30 kb deletion / insertion breaks the chain (max_gap 20 kb): the rest of the contig comes back as a supplementary
+    record, identical to the oracle's, and DipPAV's split-alignment rule turns the two records into the call"""
+    import numpy as np
+    from focalsv_amd.dippav import signatures as S
+    rng = np.random.default_rng(5)
+    A = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = A[rng.integers(0, 4, 150000)].tobytes()
+    contigs = [ref[:40000] + ref[70000:], ref[:40000] + A[rng.integers(0, 4, 30000)].tobytes() + ref[40000:], ref[1000:90000]]
+    rec, cigar, status = ctx.align_batch(contigs, [0, 0, 0], [ref])
+    assert list(status) == [0, 0, 0]
+    by = {}
+    for r in rec:
+        by.setdefault(int(r["contig"]), []).append(r)
+    assert [len(by[i]) for i in range(3)] == [2, 2, 1]
+    for i, c in enumerate(contigs):
+        want = O.align_contig_multi(c, ref)
+        assert len(want) == len(by[i])
+        for r, w in zip(by[i], want):
+            cg = cigar[int(r["cigar_off"]): int(r["cigar_off"]) + int(r["n_cigar"])]
+            assert (int(r["ref_start"]), int(r["ref_end"]), int(r["rev"])) == (w["ref_start"], w["ref_end"], w["rev"])
+            assert list(cg) == list(w["raw"])
+    # the deletion through the host logic
+    segs = []
+    for r in by[0]:
+        cg = cigar[int(r["cigar_off"]): int(r["cigar_off"]) + int(r["n_cigar"])]
+        segs.append(S.AlignedSegment("chr21", int(r["ref_start"]), int(r["ref_end"]), [(int(x) & 0xf, int(x) >> 4) for x in cg], "contig_hp1_0", bool(r["rev"]), 60, None))
+    segs.sort(key=lambda x: x.pos)
+    dels, inss = S.extract_sig_from_split(segs[0], segs[1])
+    assert len(dels) == 1 and abs(dels[0][3] - 30000) <= 2 and abs(dels[0][2] - 40000) <= 2
