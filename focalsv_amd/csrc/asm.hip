@@ -282,22 +282,25 @@ void layout_set(const int32_t *len, uint32_t n, const fsv_hit *hits, uint32_t n_
     }
     for (uint32_t v = 0; v < 2 * n; v++) { int w = succ[v]; if (w >= 0 && succ[w ^ 1] != (int)(v ^ 1)) succ[v] = -1; }
     for (uint32_t v = 0; v < 2 * n; v++) if (succ[v] >= 0) pred[succ[v]] = (int)v;
-    for (int pass = 0; pass < 2; pass++)
-        for (uint32_t v = 0; v < 2 * n; v++) {
-            const uint32_t r = v >> 1;
-            if (contained[r] || used[r]) continue;
-            if (pass == 0 && pred[v] >= 0) continue;
-            int cnt = 0;
-            for (int w = (int)v; w >= 0 && !used[w >> 1]; w = succ[w]) { cnt++; if (cnt > (int)n) break; }
-            if (cnt < min_reads) continue;
-            std::vector<Piece> c;
-            for (int w = (int)v; w >= 0 && !used[w >> 1]; w = succ[w]) {
-                used[w >> 1] = 1;
-                const bool more = succ[w] >= 0 && !used[succ[w] >> 1];
-                c.push_back(Piece{(uint32_t)(w >> 1), (uint32_t)(w & 1), (uint32_t)(more ? sovl[w] : len[w >> 1])});
-            }
-            contigs.push_back(std::move(c));
+    // ma_ug_gen (Overlaps.cpp:7759): vertices in increasing order; the unitig through the first unvisited one is emitted in that
+    // vertex's direction, from its start (found by walking the in-arcs back).  So the lowest-numbered read of a chain sits on its
+    // forward strand -- the two directions spell reverse complements only while every overlap is exact.
+    for (uint32_t v = 0; v < 2 * n; v++) {
+        const uint32_t r = v >> 1;
+        if (contained[r] || used[r]) continue;
+        int start = (int)v, steps = 0;
+        while (pred[start] >= 0 && !used[pred[start] >> 1] && steps < (int)(2 * n)) { start = pred[start]; steps++; if (start == (int)v) break; }
+        int cnt = 0;
+        for (int w = start; w >= 0 && !used[w >> 1] && cnt <= (int)(2 * n); w = succ[w]) { cnt++; if (succ[w] == start) break; }
+        if (cnt < min_reads) continue;
+        std::vector<Piece> c;
+        for (int w = start; w >= 0 && !used[w >> 1]; w = succ[w]) {
+            used[w >> 1] = 1;
+            const bool more = succ[w] >= 0 && !used[succ[w] >> 1];
+            c.push_back(Piece{(uint32_t)(w >> 1), (uint32_t)(w & 1), (uint32_t)(more ? sovl[w] : len[w >> 1])});
         }
+        contigs.push_back(std::move(c));
+    }
     // no fall-back to a single read: hifiasm's asg_cut_tip (Overlaps.cpp:4666-4709) removes dead-end chains of fewer than four
     // reads, a lone read included, and writes no contig for such a set
     fallback = contigs.empty();

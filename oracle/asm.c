@@ -634,7 +634,7 @@ int orc_layout(const int *len, int n, const orc_ovl *hit, int n_hit, int min_rea
     uint8_t *contained = (uint8_t *)calloc((size_t)n, 1), *used = (uint8_t *)calloc((size_t)n, 1);
     int32_t *succ = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 2), *sovl = (int32_t *)calloc((size_t)n * 2, sizeof(int32_t));
     int32_t *pred = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * 2);
-    int i, v, n_piece = 0, n_contig = 0, pass;
+    int i, v, n_piece = 0, n_contig = 0;
     /* ma_hit2arc (Overlaps.h:178-246) from the query's side of every hit; the mirrored hit supplies the other side.
      * tl5 / tl3 = overhang of the target in front of / behind the overlap, on the query's strand (y is strand-corrected). */
 #define HIT_GEOM(h) const int ql = len[(h)->q], tl = len[(h)->t], qs = (h)->x_s, qe = (h)->x_e + 1, tl5 = (h)->y_s, tl3 = tl - ((h)->y_e + 1); \
@@ -672,22 +672,23 @@ int orc_layout(const int *len, int n, const orc_ovl *hit, int n_hit, int min_rea
         for (i = 0; i < n; i++) fprintf(stderr, "read %d len %d contained %d succ+ %d(%d) succ- %d(%d)\n", i, len[i], contained[i], succ[2*i], sovl[2*i], succ[2*i+1], sovl[2*i+1]);
     }
     for (v = 0; v < 2 * n; v++) if (succ[v] >= 0) pred[succ[v]] = v;
-    for (pass = 0; pass < 2; pass++) { /* pass 0: paths with a free start; pass 1: leftovers (cycles) */
-        for (v = 0; v < 2 * n; v++) {
-            int r = v >> 1, cnt = 0, w, first = n_piece;
-            if (contained[r] || used[r]) continue;
-            if (pass == 0 && pred[v] >= 0) continue;
-            for (w = v; w >= 0 && !used[w >> 1]; w = succ[w]) cnt++;
-            if (cnt < min_reads) { if (pass == 0 && succ[v] < 0 && pred[v] < 0 && (v & 1) == 0) {} continue; }
-            if (n_contig >= contig_cap || n_piece + cnt > piece_cap) break;
-            for (w = v; w >= 0 && !used[w >> 1]; w = succ[w]) {
-                used[w >> 1] = 1;
-                piece_read[n_piece] = w >> 1; piece_rev[n_piece] = (uint8_t)(w & 1);
-                piece_len[n_piece] = (succ[w] >= 0 && !used[succ[w] >> 1]) ? sovl[w] : len[w >> 1];
-                n_piece++;
-            }
-            contig_first[n_contig++] = first;
+    /* ma_ug_gen (Overlaps.cpp:7759): vertices in increasing order; the unitig through the first unvisited one is emitted in
+     * that vertex's direction, from its start (found by walking the in-arcs back).  So the lowest-numbered read of a chain sits
+     * on its forward strand -- the two directions spell reverse complements only while every overlap is exact. */
+    for (v = 0; v < 2 * n; v++) {
+        int r = v >> 1, cnt = 0, w, first = n_piece, start = v, steps = 0;
+        if (contained[r] || used[r]) continue;
+        while (pred[start] >= 0 && !used[pred[start] >> 1] && steps < 2 * n) { start = pred[start]; steps++; if (start == v) break; }
+        for (w = start; w >= 0 && !used[w >> 1] && cnt <= 2 * n; w = succ[w]) { cnt++; if (succ[w] == start) break; }
+        if (cnt < min_reads) continue;
+        if (n_contig >= contig_cap || n_piece + cnt > piece_cap) break;
+        for (w = start; w >= 0 && !used[w >> 1]; w = succ[w]) {
+            used[w >> 1] = 1;
+            piece_read[n_piece] = w >> 1; piece_rev[n_piece] = (uint8_t)(w & 1);
+            piece_len[n_piece] = (succ[w] >= 0 && !used[succ[w] >> 1]) ? sovl[w] : len[w >> 1];
+            n_piece++;
         }
+        contig_first[n_contig++] = first;
     }
     /* no fall-back: hifiasm's asg_cut_tip (Overlaps.cpp:4666-4709, max_short_tip = 3) deletes every dead-end chain of
      * fewer than four reads, a lone uncontained read included, and then writes no contig at all for the set */
