@@ -32,16 +32,68 @@ def extract_sig_from_cigar(read, min_svlen=30):
     return dels, inss
 
 
+def _sort(sigs):
+    order = np.argsort([s[2] for s in sigs])   # numpy's default argsort on the positions, as the reference (:44-54)
+    return [sigs[k] for k in order]
+
+
+def _read_len(cigar):
+    return sum(n for op, n in cigar if op in (BAM_M, BAM_I, BAM_S, BAM_H))
+
+
+def extract_sig_from_split(read1, read2, min_mapq=0, max_svlen=50000):
+    """two consecutive records of one read -> (del_sigs, ins_sigs); extract_reads_signature.py:108-158 (the reference's
+    spelling of the source tag is kept: it ends up in chr<N>_reads_sig.txt)"""
+    assert read1.pos <= read2.pos and read1.qname == read2.qname and read1.reference_name == read2.reference_name
+    dels, inss = [], []
+    c1, c2 = read1.cigar, read2.cigar
+    if read1.is_reverse == read2.is_reverse and read1.mapq >= min_mapq and read2.mapq >= min_mapq \
+            and c1[-1][0] in (BAM_S, BAM_H) and c2[0][0] in (BAM_S, BAM_H):
+        rl1, rl2 = _read_len(c1), _read_len(c2)
+        assert rl1 == rl2
+        ref1e, ref2s = read1.reference_end, read2.pos
+        r1e, r2s = rl1 - c1[-1][1], c2[0][1]
+        diffdis = (ref2s - ref1e) - (r2s - r1e)
+        diffolp = ref1e - ref2s
+        strand = '-' if read1.is_reverse else '+'
+        if abs(diffdis) <= max_svlen:
+            if diffolp < 30 and diffdis >= 30:
+                dels.append([read1.reference_name, 'DEL', ref1e, diffdis, read1.qname, r1e, r2s, strand, 'split-alignemnt'])
+            elif diffolp < 30 and diffdis <= -30:
+                inss.append([read1.reference_name, 'INS', int((ref1e + ref2s) / 2), abs(diffdis), read1.qname, r1e, r2s, strand, 'split_alignment'])
+    return dels, inss
+
+
 def reads_signatures(records, min_mapq=50):
-    """all reads of one chromosome -> position-sorted signature list (cigar source only; the split source of
-    extract_reads_signature.py:108-209 needs supplementary records, which region-cropped inputs do not carry)"""
-    sigs = []
+    """all records of one chromosome, in BAM (position) order -> the signature list of chr<N>_reads_sig.txt:
+    CIGAR source from records with mapq >= 50 (extract_signature_from_cigar, :68-105), split source from consecutive records
+    of reads that have several, any mapq (extract_sig_from_split_reads, :160-209), merged by position (merge_all, :221)."""
+    dc, ic = [], []
+    by_name = {}
     for r in records:
+        by_name.setdefault(r.qname, []).append(r)
         if r.mapq >= min_mapq:
             d, i = extract_sig_from_cigar(r, 30)
-            sigs += d + i
-    order = np.argsort([s[2] for s in sigs])
-    return [sigs[k] for k in order]
+            dc += d
+            ic += i
+    ds, is_ = [], []
+    for name, rs in by_name.items():   # first-seen order of the names, as the reference's Counter
+        for k in range(len(rs) - 1):
+            d, i = extract_sig_from_split(rs[k], rs[k + 1], 0, 50000)
+            ds += d
+            is_ += i
+    return _sort(_sort(dc) + _sort(ic) + _sort(ds) + _sort(is_))
+
+
+def records_from_bam(bam_path, chrom):
+    """the records pysam yields for one chromosome; None when pysam is not installed (it is not in the build image, it is
+    wherever the reference runs)"""
+    try:
+        import pysam
+    except ImportError:
+        return None
+    with pysam.AlignmentFile(bam_path) as bam:
+        return list(bam.fetch(chrom))
 
 
 def write_reads_sig(sigs, output_dir, chrom):

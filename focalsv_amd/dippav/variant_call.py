@@ -135,10 +135,12 @@ def dippav_variant_call(data_type, read_bam_file, reference_path, hp1_contig_pat
     with open(raw, 'w') as f:
         f.writelines(header); f.writelines(body)
     # read signatures (extract_reads_signature.py) -> FP filter -> redundancy
+    if read_records is None and read_bam_file:
+        read_records = reads_signature.records_from_bam(read_bam_file, chrom)
+        if read_records is None:
+            logger.warning("read BAM %s cannot be parsed here (pysam is not installed); pass read_records=", read_bam_file)
     rsigs = reads_signature.reads_signatures(read_records or [], 50)
     reads_signature.write_reads_sig(rsigs, output_dir, chrom)
-    if read_records is None and read_bam_file:
-        logger.warning("read BAM %s cannot be parsed in this image (no pysam); pass read_records=", read_bam_file)
     filtered = os.path.join(output_dir, "dippav_variant_filtered.vcf")
     fp_filter.FP_filter(raw, os.path.join(output_dir, 'reads_signature'), filtered)
     redundancy.remove_redundancy(filtered, os.path.join(output_dir, 'final_vcf'))

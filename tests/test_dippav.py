@@ -91,3 +91,19 @@ def test_edit_similarity(gold_vcf):
     for c in gold_vcf["edit_sim"]:
         assert redundancy.edit_distance(c["a"], c["b"]) == c["dist"]
         assert redundancy.edit_sim(c["a"], c["b"]) == c["sim"]
+
+
+def test_reads_signature_file_matches_reference(golden_dir):
+    """extract_reads_signature.py end to end: CIGAR source + split source + merge -> the lines of chr21_reads_sig.txt"""
+    import json
+    import os
+    from focalsv_amd.dippav import signatures as S
+    cases = json.load(open(os.path.join(golden_dir, "dippav_reads_sig.json")))["cases"]
+    n = 0
+    for c in cases:
+        recs = [S.AlignedSegment(r["reference_name"], r["pos"], r["reference_end"], [tuple(x) for x in r["cigar"]], r["qname"], r["is_reverse"], r["mapq"], None)
+                for r in c["records"]]
+        sigs = reads_signature.reads_signatures(recs, 50)
+        assert ['\t'.join(str(x) for x in s) for s in sigs] == c["reads_sig_lines"]
+        n += len(sigs)
+    assert n > 1000 and any('split' in l for c in cases for l in c["reads_sig_lines"])

@@ -202,5 +202,52 @@ def main():
     print("ok", len(cig), len(spl), len(clu), len(pair), len(vcfs), len(fps), len(reds))
 
 
+def main_reads():
+    """extract_reads_signature.py end to end (cigar source + split source + merge) on synthetic records, through a stand-in for
+    pysam.AlignmentFile -> tests/golden/dippav_reads_sig.json (separate RNG: the other golden files stay as they are)"""
+    import tempfile
+    rng = random.Random(77)
+    cases = []
+    for ci in range(12):
+        recs = []
+        pos = 1000
+        for i in range(rng.randint(20, 60)):
+            pos += rng.randint(0, 4000)
+            name = "read_%d" % i
+            if rng.random() < 0.25:   # a split read: two or three records of one name, in position order
+                total = rng.randint(3000, 30000)
+                cut1 = rng.randint(500, total - 500)
+                cut2 = min(max(cut1 + rng.choice([0, rng.randint(-200, 200), rng.randint(30, 4000), -rng.randint(30, 2000)]), 1), total - 1)
+                rev = rng.random() < 0.5
+                mq = rng.choice([60, 60, 30, 0])
+                r1 = rec_from(rng, name, pos, [[0, cut1], [rng.choice([4, 5]), total - cut1]], rev, mq)
+                gap = rng.choice([0, rng.randint(-20, 25), rng.randint(30, 6000), rng.randint(-3000, -30), 70000])
+                r2 = rec_from(rng, name, max(pos, pos + cut1 + gap), [[rng.choice([4, 5]), cut2], [0, total - cut2]], rev if rng.random() < 0.9 else not rev, rng.choice([60, 10]))
+                recs += [r1, r2]
+                if rng.random() < 0.2:
+                    recs.append(rec_from(rng, name, r2["reference_end"] + rng.randint(0, 500), [[4, total - 300], [0, 300]], rev, 60))
+            else:
+                recs.append(rec_from(rng, name, pos, rand_cigar(rng, rng.choice([None, 37]), rng.choice([None, 55]), rng.random() < 0.3)))
+        recs.sort(key=lambda r: r["pos"])   # fetch() yields position order
+
+        class FakeBam:
+            def __init__(self, path):
+                pass
+
+            def fetch(self, chrom):
+                return [Rec(r) for r in recs]
+        RS.pysam.AlignmentFile = FakeBam
+        with tempfile.TemporaryDirectory() as tmp:
+            RS.extract_reads_signature(21, "none.bam", tmp)
+            lines = open(os.path.join(tmp, "reads_signature", "chr21_reads_sig.txt")).read().splitlines()
+        cases.append({"records": recs, "reads_sig_lines": lines})
+    json.dump({"source": "extract_reads_signature.extract_reads_signature of the reference on synthetic records", "cases": cases},
+              open(os.path.join(OUT, "dippav_reads_sig.json"), "w"), separators=(",", ":"))
+    print("reads ok", len(cases), sum(len(c["reads_sig_lines"]) for c in cases))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "reads":
+        main_reads()
+    else:
+        main()
