@@ -43,6 +43,58 @@ def find_read_sets(regions_dir: str, data_type: int = 0) -> List[str]:
     return out
 
 
+def _set_cost(reads) -> int:
+    """device bytes a read set needs, dominated by the window-task bound: every read against every other, 176 B per window"""
+    n = len(reads)
+    win = sum((len(r) + 374) // 375 for r in reads)
+    return (n - 1) * win * 176 + n * n * 72 + sum(len(r) for r in reads) * 24 if n > 1 else 4096
+
+
+def assemble_sets(ctx: _lib.Context, sets, logger=None, budget_bytes: Optional[int] = None):
+    """all read sets of a chromosome through fsv_assemble_batch, in as few batches as the device memory allows
+    (FSV_BATCH_GB overrides the default budget of 64 GB of workspace per batch); a batch the library refuses as too large is
+    halved and retried.  -> [(contigs, status)] per set, in input order."""
+    if budget_bytes is None:
+        budget_bytes = int(float(os.environ.get("FSV_BATCH_GB", "64")) * (1 << 30))
+    out = [None] * len(sets)
+
+    def run(idx):
+        b = pack_sets([sets[i] for i in idx])
+        d = ctx.upload(b.words)
+        try:
+            contigs, cset, cnr, st = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start)
+        finally:
+            ctx.dev_free(d)
+        per = [[] for _ in idx]
+        for c, s in zip(contigs, cset):
+            per[int(s)].append(c)
+        for k, i in enumerate(idx):
+            out[i] = (per[k], int(st[k]))
+
+    def run_or_split(idx):
+        try:
+            run(idx)
+        except _lib.FsvError as e:
+            if e.code not in (-3, -5, -6) or len(idx) == 1:   # FSV_ENOMEM, FSV_ECAP, FSV_EUNSUP: too much for one batch
+                raise
+            if logger:
+                logger.warning(f"batch of {len(idx)} read sets refused ({e}); halving")
+            run_or_split(idx[: len(idx) // 2])
+            run_or_split(idx[len(idx) // 2:])
+
+    batch, used = [], 0
+    for i, rs in enumerate(sets):
+        c = _set_cost(rs)
+        if batch and used + c > budget_bytes:
+            run_or_split(batch)
+            batch, used = [], 0
+        batch.append(i)
+        used += c
+    if batch:
+        run_or_split(batch)
+    return out
+
+
 def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, logger=None, ctx: Optional[_lib.Context] = None,
              device: int = 0, skip_existing: bool = True) -> Dict[str, int]:
     """3_assembly.py:28-41.  cpu/threads are accepted for CLI compatibility (the GPU batch replaces both)."""
@@ -60,21 +112,16 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
         own = ctx is None
         ctx = ctx or _lib.Context(device)
         try:
-            b = pack_sets(sets)
-            d = ctx.upload(b.words)
-            try:
-                contigs, cset, cnr, st = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start)
-            finally:
-                ctx.dev_free(d)
+            per_set = assemble_sets(ctx, sets, logger)
         finally:
             if own:
                 ctx.close()
-        for si, f in enumerate(fas):
+        for f, (contigs, st) in zip(fas, per_set):
             outp = f[:-3] + ".asm.p_ctg.gfa.fa"
-            fasta.write_contig_fasta(outp, outp, [c for c, s in zip(contigs, cset) if s == si])
-            status[f] = int(st[si])
-            if st[si]:
-                logger.warning(f"{f}: assembly status {int(st[si])}")
+            fasta.write_contig_fasta(outp, outp, contigs)
+            status[f] = int(st)
+            if st:
+                logger.warning(f"{f}: assembly status {int(st)}")
     combine_fas(regions_dir, logger)
     return status
 

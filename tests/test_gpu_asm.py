@@ -111,3 +111,14 @@ def test_low_coverage_and_narrow_regions_match_oracle(ctx):
         if not oc:
             assert status[si] & 4   # FSV_W_NO_LAYOUT
     assert ctx.asm_stats()["n_inexact_candidates"] > 0
+
+
+def test_assemble_sets_batches_by_memory(ctx):
+    """the file drop-in feeds a chromosome's read sets in memory-bounded batches: same contigs whatever the batch size"""
+    from focalsv_amd import assembly
+    regions = [synth.make_region(i) for i in (4, 9, 11)]
+    sets = [rd for r in regions for rd in r.reads] + [[]]
+    one = assembly.assemble_sets(ctx, sets)
+    many = assembly.assemble_sets(ctx, sets, budget_bytes=60 << 20)   # ~one set per batch
+    assert [(list(c), s) for c, s in one] == [(list(c), s) for c, s in many]
+    assert all(len(c) == 1 for c, s in one[:-1]) and one[-1] == ([], 0)
