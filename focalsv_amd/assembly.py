@@ -107,7 +107,8 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
     status: Dict[str, int] = {}
     if fas:
         if any('unphased' in os.path.basename(f) for f in fas):
-            logger.warning("unphased read sets are assembled as a single haplotype (dual-haplotype partition is not implemented)")
+            logger.warning("unphased read sets are assembled as one haplotype and written to both HP1 and HP2 "
+                           "(right where the reads carry no heterozygosity; the dual-haplotype partition is not implemented)")
         sets = [fasta.read_reads(f) for f in fas]
         own = ctx is None
         ctx = ctx or _lib.Context(device)
@@ -117,8 +118,17 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
             if own:
                 ctx.close()
         for f, (contigs, st) in zip(fas, per_set):
-            outp = f[:-3] + ".asm.p_ctg.gfa.fa"
-            fasta.write_contig_fasta(outp, outp, contigs)
+            if 'unphased' in os.path.basename(f):
+                # the reference runs hifiasm-0.16.1 here, whose bp.hap1 / bp.hap2 contigs combine_fas puts into HP1 / HP2
+                # (run_assembly.py:17-21, combine_fas.py:13-14).  On a read set without heterozygosity both are the same contig
+                # (checked against oracle/_ref/hifiasm-0.16.1); that case is reproduced -- the single assembly goes to both
+                # haplotypes.  A heterozygous unphased set needs the haplotype partition, which is not built.
+                for hap in (1, 2):
+                    outp = f[:-3] + ".asm.bp.hap%d.p_ctg.gfa.fa" % hap
+                    fasta.write_contig_fasta(outp, outp, contigs)
+            else:
+                outp = f[:-3] + ".asm.p_ctg.gfa.fa"
+                fasta.write_contig_fasta(outp, outp, contigs)
             status[f] = int(st)
             if st:
                 logger.warning(f"{f}: assembly status {int(st)}")

@@ -44,3 +44,33 @@ def test_region_directories_to_vcf(tmp_path):
     truth_all = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth]
     tp, fp, fn, gt = pipeline.match_truth(pipeline.parse_calls(raw), truth_all, bp_tol=1, len_tol=0.0)
     assert (tp, fp, fn) == (len(truth_all), 0, 0)
+
+
+def test_unphased_region_goes_to_both_haplotypes(tmp_path):
+    """a region whose reads could not be phased (no heterozygosity: every read in unphased.fa): the reference's hifiasm-0.16.1
+    returns the same contig as hap1 and hap2, combine_fas puts it into HP1.fa and HP2.fa, and the homozygous SV comes out 1/1"""
+    out = str(tmp_path)
+    r = synth.make_region(1, start=10000)
+    d = os.path.join(out, "regions", "Region_chr21_S%d_E%d" % (r.start, r.start + len(r.ref)))
+    os.makedirs(d)
+    with open(os.path.join(d, "unphased.fa"), "w") as f:
+        for j, rd in enumerate(r.reads[0]):
+            f.write(">u%d\n%s\n" % (j, rd.decode()))
+    import random
+    rng = random.Random(6)
+    seq = [rng.choice("ACGT") for _ in range(r.start + len(r.ref) + 20000)]
+    seq[r.start:r.start + len(r.ref)] = r.ref.decode()
+    ref_fa = os.path.join(out, "ref.fa")
+    with open(ref_fa, "w") as f:
+        f.write(">chr21\n" + fasta.fold("".join(seq), 60) + "\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env)
+    hp1 = list(fasta.read_fasta(os.path.join(d, "HP1.fa")))
+    hp2 = list(fasta.read_fasta(os.path.join(d, "HP2.fa")))
+    assert len(hp1) == 1 and [s for _, s in hp1] == [s for _, s in hp2] and len(hp1[0][1]) == len(r.haps[0])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env,
+                          stdout=subprocess.DEVNULL)
+    raw = [l for l in open(os.path.join(out, "SV", "chr21", "dippav_raw_variant.vcf")) if l[0] != '#']
+    calls = pipeline.parse_calls(raw)
+    hap1_truth = [t for t in r.truth if t.hap in (1, 3)]
+    assert len(calls) == len(hap1_truth) and all(c["gt"] == "1/1" for c in calls)
