@@ -440,7 +440,11 @@ static orc_win *align_overlaps(const readset *R, orc_ovl *ov, int n_ov, const in
 }
 
 /* consensus of read q given all accepted overlaps; returns new length, writes into out (cap >= 2*len+64) */
-static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, const orc_win *W, char *out)
+/* trans != NULL: no output; instead the overlaps that carry the other allele at a heterozygous column of q are marked
+ * (the haplotype partition of an unphased read set, a much reduced partition_overlaps_advance, Correct.cpp:7127-7206): a column
+ * is heterozygous when at least ORC_HET_MIN overlapping reads agree with q and at least ORC_HET_MIN agree on one other base. */
+#define ORC_HET_MIN 3
+static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, const orc_win *W, char *out, uint8_t *trans)
 {
     const char *x = R->seq[q];
     int xlen = R->len[q], nwin = (xlen + ORC_WINDOW - 1) / ORC_WINDOW, g, i, outn = 0;
@@ -463,7 +467,7 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
             const orc_win *w;
             const char *y = R->seq[o->t];
             int ylen = R->len[o->t], j = g - o->x_s / ORC_WINDOW, xp, yp, p, pend;
-            if (!o->is_match || j < 0 || j >= o->n_win) continue;
+            if (o->is_match != 1 || j < 0 || j >= o->n_win) continue;
             w = &W[o->first_win + j];
             if (w->err < 0) continue;
             cover++;
@@ -504,6 +508,36 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
                 else { cnt[xp][base2(ybase(y, ylen, o->rev, yp))]++; yp++; }
                 xp++; p++;
             }
+        }
+        if (trans) {
+            uint8_t het[ORC_WINDOW + 1];
+            int any = 0;
+            if (cover < 3) continue;
+            for (c = 0; c < glen; c++) {
+                int own = base2(x[gs + c]), b, alt = -1;
+                for (b = 0; b < 4; b++) if (b != own && (alt < 0 || cnt[c][b] > cnt[c][alt])) alt = b;
+                het[c] = (cnt[c][alt] >= ORC_HET_MIN && cnt[c][own] >= ORC_HET_MIN) ? (uint8_t)(alt + 1) : 0;
+                any |= het[c];
+            }
+            if (!any) continue;
+            for (i = o0; i < o1; i++) { /* the same walk again: who shows the other allele at a heterozygous column */
+                const orc_ovl *o = &ov[i];
+                const orc_win *w;
+                const char *y = R->seq[o->t];
+                int ylen = R->len[o->t], j = g - o->x_s / ORC_WINDOW, xp, yp, p;
+                if (o->is_match != 1 || j < 0 || j >= o->n_win) continue;
+                w = &W[o->first_win + j];
+                if (w->err <= 0) continue;
+                xp = w->x_start - gs; yp = w->ry_start;
+                for (p = 0; p < w->path_len; p++) {
+                    int op = w->path[p];
+                    if (op == 2) { yp++; continue; }
+                    if (op == 1 && het[xp] && base2(ybase(y, ylen, o->rev, yp)) + 1 == het[xp]) trans[i] = 1;
+                    if (op != 3) yp++;
+                    xp++;
+                }
+            }
+            continue;
         }
         if (cover < 3) { /* MIN_COVERAGE_THRESHOLD: copy verbatim */
             memcpy(out + outn, x + gs, (size_t)glen); outn += glen;
@@ -551,15 +585,22 @@ static void correction_round(readset *R, const orc_asm_params *P, int do_rc, orc
     sketch_set(R, P, &uq, &nuq);
     collect_overlaps(R, P, P->bw_ec, uq, nuq, &ov, &cq, &ct, &n_ov);
     W = align_overlaps(R, ov, n_ov, cq, ct, &n_win);
+    if (P->diploid) { /* unphased read set: overlaps between the two haplotypes leave the consensus (is_match = 2 as in hifiasm) */
+        uint8_t *trans = (uint8_t *)calloc((size_t)n_ov + 1, 1);
+        int i;
+        for (q = 0; q < R->n; q++) correct_read(R, q, ov, n_ov, W, NULL, trans);
+        for (i = 0; i < n_ov; i++) if (trans[i] && ov[i].is_match == 1) ov[i].is_match = 2;
+        free(trans);
+    }
     for (q = 0; q < R->n; q++) {
         nseq[q] = (char *)malloc((size_t)R->len[q] * 2 + 64 + (size_t)ORC_WINDOW * 16);
-        nlen[q] = correct_read(R, q, ov, n_ov, W, nseq[q]);
+        nlen[q] = correct_read(R, q, ov, n_ov, W, nseq[q], NULL);
         if (do_rc) revcomp_inplace(nseq[q], nlen[q]);
     }
     for (q = 0; q < R->n; q++) { free(R->seq[q]); R->seq[q] = nseq[q]; R->len[q] = nlen[q]; }
     if (accepted) { /* the overlaps this round verified (coordinates on the reads as they were before the round) */
         int i, m = 0;
-        for (i = 0; i < n_ov; i++) if (ov[i].is_match) ov[m++] = ov[i];
+        for (i = 0; i < n_ov; i++) if (ov[i].is_match == 1) ov[m++] = ov[i];
         *accepted = ov; *n_accepted = m; ov = NULL;
     }
     free(nseq); free(nlen); free(W); free(ov); free(cq); free(ct);
@@ -572,7 +613,7 @@ typedef struct { int to, to_rev, ovl; } arc_t; /* best successor of an oriented 
 void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
-    P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4;
+    P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->diploid = 0;
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),

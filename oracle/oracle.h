@@ -27,6 +27,7 @@ typedef struct {
                                  homopolymer run yields an HPC k-mer whose end is off by the truncated bases, which a non-zero
                                  budget lets into the chain and shifts the exact-overlap interval by one) */
     int32_t min_contig_reads; /* chains of fewer reads are dropped (asg_cut_tip with max_short_tip = 3, Overlaps.cpp:4666): 4 */
+    int32_t diploid;          /* 1: unphased read set -- overlaps that carry the other allele at a heterozygous column are kept out of the consensus */
 } orc_asm_params;
 
 typedef struct {

@@ -72,7 +72,7 @@ def sketch(seq: str, w=51, k=51, hpc=1):
 
 
 class AsmParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads")]
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "diploid")]
 
 
 def default_params():

@@ -60,3 +60,29 @@ def test_thresholds_follow_reference_formulas():
     assert L.orc_thr_for_len(375) == 15
     assert L.orc_thr_for_len(3) == 0 and L.orc_thr_for_len(4) == 1 and L.orc_thr_for_len(100) == 4
     assert L.orc_double_thr(15, 375) == 31 and L.orc_double_thr(4, 100) == 8 and L.orc_double_thr(13, 320) == 31
+
+
+def _unphased_sets(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
+    return json.load(open(os.path.join(golden_dir, "hifiasm016_unphased.json")))["sets"]
+
+
+@pytest.mark.parametrize("idx", range(len(_unphased_sets())))
+def test_unphased_sets_equal_hifiasm016_haplotypes(golden_dir, idx):
+    """unphased.fa (both haplotypes' reads in one set): the diploid mode keeps overlaps that carry the other allele at a
+    heterozygous column out of the consensus, and the two contigs that come out are byte-identical to the bp.hap1 / bp.hap2
+    contigs of the reference's hifiasm-0.16.1; a set without heterozygosity gives one contig, which 0.16.1 reports as both"""
+    g = _unphased_sets()[idx]
+    r = synth.make_region(g["region"])
+    reads = r.reads[0] + r.reads[1] if g["mode"] == "mixed" else r.reads[0 if g["mode"] == "hp1" else 1]
+    assert hashlib.md5(b"\n".join(reads)).hexdigest() == g["reads_md5"]
+    p = O.default_params()
+    p.diploid = 1
+    contigs, _ = O.assemble(reads, p)
+    got = sorted((len(c), hashlib.md5(canon(c)).hexdigest()) for c in contigs)
+    exp = sorted({(c["len"], c["md5"]) for h in ("hap1", "hap2") for c in g[h]})
+    if (g["region"], g["mode"]) == (7, "hp2"):
+        # 0.16.1 (unlike 0.14) loses 6 kb around the 2 kb tandem-repeat block of this region; the 0.14-style assembly used here
+        # returns the whole haplotype
+        assert got != exp and len(got) == 1 and canon(contigs[0]) == canon(r.haps[1])
+    else:
+        assert got == exp
