@@ -32,7 +32,10 @@ class AsmParams(C.Structure):
 
 class ReadSets(C.Structure):
     _fields_ = [("store_dev", C.c_void_p), ("word_off", C.c_void_p), ("read_len", C.c_void_p), ("set_start", C.c_void_p),
-                ("n_reads", C.c_uint32), ("n_sets", C.c_uint32)]
+                ("n_reads", C.c_uint32), ("n_sets", C.c_uint32), ("set_flags", C.c_void_p)]
+
+
+SET_UNPHASED = 1
 
 
 class Contigs(C.Structure):
@@ -274,13 +277,16 @@ class Context:
     def dev_free(self, ptr):
         self.check(self._lib.fsv_dev_free(self._h, C.c_void_p(ptr)), "fsv_dev_free")
 
-    def assemble_batch(self, store_dev, word_off, read_len, set_start, params=None):
+    def assemble_batch(self, store_dev, word_off, read_len, set_start, params=None, set_flags=None):
         """fsv_assemble_batch.  store_dev: device pointer of the 2-bit store; the rest are host numpy arrays.
         -> (contigs: list[bytes], contig_set: ndarray, contig_n_reads: ndarray, set_status: ndarray)"""
         word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
         read_len = np.ascontiguousarray(read_len, dtype=np.int32)
         set_start = np.ascontiguousarray(set_start, dtype=np.uint32)
-        rs = ReadSets(C.c_void_p(store_dev), _ptr(word_off).value, _ptr(read_len).value, _ptr(set_start).value, len(read_len), len(set_start) - 1)
+        flags = None if set_flags is None else np.ascontiguousarray(set_flags, dtype=np.uint8)
+        assert flags is None or len(flags) == len(set_start) - 1
+        rs = ReadSets(C.c_void_p(store_dev), _ptr(word_off).value, _ptr(read_len).value, _ptr(set_start).value, len(read_len), len(set_start) - 1,
+                      None if flags is None else _ptr(flags).value)
         cap, ccap = C.c_uint64(), C.c_uint32()
         self.check(self._lib.fsv_assemble_batch_bound(C.byref(rs), C.byref(cap), C.byref(ccap)), "fsv_assemble_batch_bound")
         seq = np.empty(cap.value, dtype=np.uint8)

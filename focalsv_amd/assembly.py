@@ -50,7 +50,7 @@ def _set_cost(reads) -> int:
     return (n - 1) * win * 176 + n * n * 72 + sum(len(r) for r in reads) * 24 if n > 1 else 4096
 
 
-def assemble_sets(ctx: _lib.Context, sets, logger=None, budget_bytes: Optional[int] = None):
+def assemble_sets(ctx: _lib.Context, sets, logger=None, budget_bytes: Optional[int] = None, set_flags=None):
     """all read sets of a chromosome through fsv_assemble_batch, in as few batches as the device memory allows
     (FSV_BATCH_GB overrides the default budget of 64 GB of workspace per batch); a batch the library refuses as too large is
     halved and retried.  -> [(contigs, status)] per set, in input order."""
@@ -62,7 +62,8 @@ def assemble_sets(ctx: _lib.Context, sets, logger=None, budget_bytes: Optional[i
         b = pack_sets([sets[i] for i in idx])
         d = ctx.upload(b.words)
         try:
-            contigs, cset, cnr, st = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start)
+            contigs, cset, cnr, st = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start, None,
+                                                         None if set_flags is None else [set_flags[i] for i in idx])
         finally:
             ctx.dev_free(d)
         per = [[] for _ in idx]
@@ -107,25 +108,25 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
     status: Dict[str, int] = {}
     if fas:
         if any('unphased' in os.path.basename(f) for f in fas):
-            logger.warning("unphased read sets are assembled as one haplotype and written to both HP1 and HP2 "
-                           "(right where the reads carry no heterozygosity; the dual-haplotype partition is not implemented)")
+            logger.info("unphased read sets go through the haplotype partition (FSV_SET_UNPHASED)")
         sets = [fasta.read_reads(f) for f in fas]
         own = ctx is None
         ctx = ctx or _lib.Context(device)
         try:
-            per_set = assemble_sets(ctx, sets, logger)
+            per_set = assemble_sets(ctx, sets, logger, set_flags=[_lib.SET_UNPHASED if 'unphased' in os.path.basename(f) else 0 for f in fas])
         finally:
             if own:
                 ctx.close()
         for f, (contigs, st) in zip(fas, per_set):
             if 'unphased' in os.path.basename(f):
                 # the reference runs hifiasm-0.16.1 here, whose bp.hap1 / bp.hap2 contigs combine_fas puts into HP1 / HP2
-                # (run_assembly.py:17-21, combine_fas.py:13-14).  On a read set without heterozygosity both are the same contig
-                # (checked against oracle/_ref/hifiasm-0.16.1); that case is reproduced -- the single assembly goes to both
-                # haplotypes.  A heterozygous unphased set needs the haplotype partition, which is not built.
+                # (run_assembly.py:17-21, combine_fas.py:13-14).  The set was assembled in the unphased mode: two contigs are the
+                # two haplotypes; a single contig means no heterozygosity, and 0.16.1 then reports it for both haplotypes
+                # (checked against oracle/_ref/hifiasm-0.16.1).  More fragments alternate between the two files.
+                haps = ([contigs[0]], [contigs[0]]) if len(contigs) == 1 else (contigs[0::2], contigs[1::2])
                 for hap in (1, 2):
                     outp = f[:-3] + ".asm.bp.hap%d.p_ctg.gfa.fa" % hap
-                    fasta.write_contig_fasta(outp, outp, contigs)
+                    fasta.write_contig_fasta(outp, outp, haps[hap - 1])
             else:
                 outp = f[:-3] + ".asm.p_ctg.gfa.fa"
                 fasta.write_contig_fasta(outp, outp, contigs)

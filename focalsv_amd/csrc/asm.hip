@@ -38,7 +38,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
                                         "k_repack", "k_exact", "k_stitch"};
 
 struct AsmWs {
-    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, set_cols,
+    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, set_cols, trans, read_flag,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     // state of the last run (for fsv_asm_fetch_reads / stats)
@@ -52,7 +52,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &set_cols, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &set_cols, &trans, &read_flag, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -456,6 +456,13 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     }
     TRY(ensure(ctx, W.warn, (size_t)B.n_reads * 4));
     FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+    bool any_unphased = false;
+    if (sets->set_flags) {
+        std::vector<uint8_t> rf(B.n_reads, 0);
+        for (uint32_t s2 = 0; s2 < B.n_sets; s2++)
+            if (sets->set_flags[s2] & FSV_SET_UNPHASED) { any_unphased = true; for (uint32_t r = B.set_start[s2]; r < B.set_start[s2 + 1]; r++) rf[r] = 1; }
+        if (any_unphased) TRY(upload(ctx, W.read_flag, rf));
+    }
 
     Geometry G;
     TRY(make_geometry(ctx, B, len, G, P.w));
@@ -578,6 +585,17 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         C.gwin_tab = (const uint4 *)W.gwin_tab.p; C.tasks = (const fsv_wtask *)W.tasks.p;
         C.paths = (const fsv_wpath *)W.paths.p; C.cwin = (uint8_t *)W.cwin.p; C.cwin_len = (uint16_t *)W.cwin_len.p; C.warn = (uint32_t *)W.warn.p;
         C.n_reads = B.n_reads;
+        if (any_unphased && n_tasks && B.n_pairs) {
+            // unphased sets: mark the overlaps that carry the other allele at a heterozygous column, then take them out of
+            // the consensus (and, through is_match = 2, out of what the final pass accepts as verified)
+            TRY(ensure(ctx, W.trans, (size_t)B.n_pairs * 4));
+            FSV_HIP(ctx, hipMemsetAsync(W.trans.p, 0, (size_t)B.n_pairs * 4, ctx->stream));
+            hipLaunchKernelGGL(k_het, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, (const uint8_t *)W.read_flag.p, (uint32_t *)W.trans.p);
+            FSV_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_apply_trans, dim3(fsv_grid_for(B.n_pairs, 256)), dim3(256), 0, ctx->stream, (fsv_ovl *)W.ovl.p, (uint4 *)W.ovl_c.p,
+                               (const uint32_t *)W.trans.p, B.n_pairs);
+            FSV_HIP(ctx, hipGetLastError());
+        }
         W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_tasks * 128 + (uint64_t)n_gwin * (96 + 448));
     hipLaunchKernelGGL(k_consensus, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
         FSV_HIP(ctx, hipGetLastError());

@@ -1224,6 +1224,126 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
 #undef CNT_GET
 }
 
+// ------------------------------------------------------------------------------------------------ k_het / k_apply_trans
+// Unphased read sets (FSV_SET_UNPHASED): a much reduced partition_overlaps_advance (Correct.cpp:7127-7206).  Same tally as
+// k_consensus over one grid window; a column is heterozygous when at least FSV_HET_MIN overlapping reads agree with the
+// backbone and at least FSV_HET_MIN agree on one other base; an overlap whose path shows that other base there comes from the
+// other haplotype.  It is marked (trans[pair slot]) and k_apply_trans takes it out of the consensus (is_match = 2, as hifiasm
+// labels such overlaps), so each haplotype's reads are corrected by their own kind and assemble into their own contig.
+#define FSV_HET_MIN 3
+__global__ __launch_bounds__(64) void k_het(ConsArgs A, uint32_t n_gwin, const uint8_t *__restrict__ read_flag, uint32_t *__restrict__ trans)
+{
+    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][3];  // 16 bits each: A C | G T votes that differ from the backbone | deleted, -
+    __shared__ int32_t s_cov[FSV_WINDOW + 2];
+    __shared__ uint32_t s_path[64][27];
+    __shared__ uint8_t s_het[FSV_WINDOW + 1];      // 0, or 1 + the other allele of a heterozygous column
+    __shared__ uint32_t s_cover, s_any;
+    __shared__ uint32_t s_xraw[28];
+    __shared__ uint32_t s_scan[64];
+    const int lane = threadIdx.x;
+    const uint32_t gw = blockIdx.x;
+    if (gw >= n_gwin) return;
+    const uint4 gt = A.gwin_tab[gw];
+    const uint32_t r = gt.x, pbase = gt.y, n_ovl = gt.z;
+    if (!read_flag[r]) return;
+    const int g = (int)gt.w;
+    const int xlen = A.read_len[r];
+    const int gs = g * FSV_WINDOW, glen = min(FSV_WINDOW, xlen - gs);
+    const uint32_t xw = A.word_off[r];
+    const int xw0 = (gs >> 4) - 1;
+    if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((xlen + 15) >> 4)) ? A.store[xw + wi] : 0u; }
+    for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
+    for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
+    for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_het[i] = 0;
+    if (lane == 0) { s_cover = 0; s_any = 0; }
+    __syncthreads();
+#define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
+#define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
+#define CNT_GET(c, b) ((s_cnt[(c)][(b) >> 1] >> (((b) & 1u) << 4)) & 0xffffu)
+#define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
+    for (int pass = 0; pass < 2; pass++) {
+        for (uint32_t oi = lane; oi < n_ovl; oi += 64) {
+            const uint4 oc = A.ovl_c[pbase + oi];
+            const int o_x_s = (int)oc.x, o_n_win = (int)(oc.z & 0x7fffffffu);
+            const int j = g - o_x_s / FSV_WINDOW;
+            if (!(oc.z >> 31) || j < 0 || j >= o_n_win) continue;
+            const fsv_wpath *P = A.paths + (oc.y + (uint32_t)j);
+            const uint4 h0 = *reinterpret_cast<const uint4 *>(P);
+            if ((h0.w & 0xffu) != 1u) continue;
+            const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16);
+            const bool clean_path = (int16_t)(h0.z >> 16) == 0;
+            const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
+            const int xs = max(gs, o_x_s) - gs;
+            if (pass == 0) atomicAdd(&s_cover, 1u);
+            int n2 = 0, n3 = 0;
+            if (!clean_path) {
+                const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
+#pragma unroll
+                for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
+                const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
+                bool other = false;
+                for (int p = 0; p < plen;) {
+                    const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1);
+                    if (rest == 0u) { p = ((p >> 4) + 1) << 4; continue; }
+                    const uint32_t op = rest & 3u;
+                    const int xp = xs + p - n2;
+                    if (op == 2u) { n2++; p++; continue; }
+                    if (op == 3u) { if (pass == 0) CNT_ADD(xp, 4u); n3++; }
+                    else if (op == 1u) {
+                        const uint32_t yb = fsv_base_at(A.store, y_word, y_len, y_rev, ry_start + p - n3);
+                        if (pass == 0) CNT_ADD(xp, yb);
+                        else if (s_het[xp] == yb + 1u) other = true;
+                    }
+                    p++;
+                }
+                if (pass == 1 && other) trans[pbase + oi] = 1u;
+            }
+            if (pass == 0) {
+                const int xcols = plen - n2;   // clean paths: n2 = 0
+                atomicAdd(&s_cov[xs], 1);
+                atomicAdd(&s_cov[xs + xcols], -1);
+            }
+        }
+        __syncthreads();
+        if (pass == 1 || s_cover < 3u) break;
+        // arrived[c] = prefix sum of the difference array; each lane owns the contiguous columns [c0, c1)
+        const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
+        int run = 0;
+        for (int c = c0; c < c1; c++) run += s_cov[c];
+        s_scan[lane] = (uint32_t)run;
+        __syncthreads();
+        int arrived = 0;
+        for (int i = 0; i < lane; i++) arrived += (int)s_scan[i];
+        bool any = false;
+        for (int c = c0; c < c1; c++) {
+            arrived += s_cov[c];
+            const uint32_t own = XB(gs + c);
+            int dev = (int)CNT_GET(c, 4u), alt = -1, altc = -1;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int v = (int)CNT_GET(c, (uint32_t)b);
+                dev += v;
+                if ((uint32_t)b != own && v > altc) { altc = v; alt = b; }
+            }
+            if (altc >= FSV_HET_MIN && arrived - dev >= FSV_HET_MIN) { s_het[c] = (uint8_t)(alt + 1); any = true; }
+        }
+        if (any) s_any = 1u;
+        __syncthreads();
+        if (!s_any) break;
+    }
+#undef XB
+#undef CNT_ADD
+#undef CNT_GET
+#undef OP
+}
+
+__global__ void k_apply_trans(fsv_ovl *__restrict__ ovl, uint4 *__restrict__ ovl_c, const uint32_t *__restrict__ trans, uint32_t n_pairs)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs || !trans[p]) return;
+    if (ovl[p].valid && ovl[p].is_match == 1) { ovl[p].is_match = 2; ovl_c[p].z &= 0x7fffffffu; }
+}
+
 // ------------------------------------------------------------------------------------------------ k_newlen / k_repack
 __global__ void k_newlen(const uint32_t *__restrict__ gwin_off, const uint16_t *__restrict__ cwin_len, uint32_t n_reads, int32_t *__restrict__ new_len)
 {
@@ -1351,7 +1471,7 @@ __global__ void k_inexact_list(const uint4 *__restrict__ upair_tab, const uint8_
     if (up >= n_upairs || exact_flag[up]) return;
     const uint4 pt = upair_tab[up];
     const fsv_ovl a = prev[pt.z], b = prev[pt.w];
-    if ((a.valid && a.is_match) || (b.valid && b.is_match)) list[atomicAdd(n_list, 1u)] = up;
+    if ((a.valid && a.is_match == 1) || (b.valid && b.is_match == 1)) list[atomicAdd(n_list, 1u)] = up;
 }
 
 __global__ void k_accept_inexact(const uint4 *__restrict__ upair_tab, const uint32_t *__restrict__ list, uint32_t n_list,
@@ -1363,7 +1483,7 @@ __global__ void k_accept_inexact(const uint4 *__restrict__ upair_tab, const uint
     const uint4 pt = upair_tab[list[i >> 1]];
     const uint32_t slot = (i & 1) ? pt.w : pt.z;
     const fsv_ovl o = ovl[slot], pv = prev[slot];
-    if (!o.valid || !pv.valid || !pv.is_match || pv.rev != o.rev) return;
+    if (!o.valid || !pv.valid || pv.is_match != 1 || pv.rev != o.rev) return;
     const int lx = pv.x_e - pv.x_s + 1, ly = pv.y_e - pv.y_s + 1, L = max(lx, ly) / 10;
     const bool ok = (abs(o.x_s - pv.x_s) < L && abs(o.x_e - pv.x_e) < L) || (abs(o.y_s - pv.y_s) < L && abs(o.y_e - pv.y_e) < L);
     if (!ok) return;

@@ -179,7 +179,10 @@ typedef struct fsv_readsets {
     const int32_t  *read_len;   /* host: n_reads lengths in bases */
     const uint32_t *set_start;  /* host: n_sets+1 read indices; set s owns reads [set_start[s], set_start[s+1]) */
     uint32_t n_reads, n_sets;
+    const uint8_t  *set_flags;  /* host: n_sets flags, or NULL; FSV_SET_UNPHASED marks a set that mixes both haplotypes' reads */
 } fsv_readsets;
+#define FSV_SET_UNPHASED 1      /* unphased.fa (run_assembly.py:17-21): overlaps that carry the other allele at a heterozygous
+                                 * column stay out of the consensus, so each haplotype comes out as its own contig */
 
 typedef struct fsv_contigs {
     char     *seq;         /* host, capacity seq_cap: ASCII contig bases back to back */

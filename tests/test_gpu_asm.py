@@ -24,11 +24,11 @@ def canon(s):
     return min(s, synth.revcomp(s))
 
 
-def gpu_assemble(ctx, sets, params=None):
+def gpu_assemble(ctx, sets, params=None, set_flags=None):
     b = pack_sets(sets)
     d = ctx.upload(b.words)
     try:
-        contigs, cset, cnr, status = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start, params)
+        contigs, cset, cnr, status = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start, params, set_flags)
         reads = ctx.fetch_reads(b.n_reads, int(b.read_len.sum()) * 2 + 1024)
     finally:
         ctx.dev_free(d)
@@ -122,3 +122,27 @@ def test_assemble_sets_batches_by_memory(ctx):
     many = assembly.assemble_sets(ctx, sets, budget_bytes=60 << 20)   # ~one set per batch
     assert [(list(c), s) for c, s in one] == [(list(c), s) for c, s in many]
     assert all(len(c) == 1 for c, s in one[:-1]) and one[-1] == ([], 0)
+
+
+def test_unphased_sets_give_both_haplotypes(ctx, golden_dir):
+    """FSV_SET_UNPHASED: both haplotypes' reads in one set -> two contigs, bit-identical to the oracle's diploid mode and to the
+    bp.hap1 / bp.hap2 contigs of the reference's hifiasm-0.16.1; phased sets in the same batch are untouched"""
+    gold = {(g["region"], g["mode"]): g for g in json.load(open(os.path.join(golden_dir, "hifiasm016_unphased.json")))["sets"]}
+    regs = {i: synth.make_region(i) for i in (0, 3, 12)}
+    sets = [regs[0].reads[0] + regs[0].reads[1], regs[3].reads[0], regs[3].reads[0] + regs[3].reads[1], regs[12].reads[0] + regs[12].reads[1], regs[0].reads[0]]
+    flags = [1, 0, 1, 1, 1]
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets, None, flags)
+    k = 0
+    for si, (s, fl) in enumerate(zip(sets, flags)):
+        p = O.default_params()
+        p.diploid = fl
+        oc, ocorr = O.assemble(s, p)
+        for j in range(len(s)):
+            assert reads[k + j] == ocorr[j], (si, j)
+        k += len(s)
+        mine = [c for c, cs in zip(contigs, cset) if cs == si]
+        assert mine == oc, (si, [len(c) for c in mine], [len(c) for c in oc])
+    for si, key in ((0, (0, "mixed")), (2, (3, "mixed")), (3, (12, "mixed")), (4, (0, "hp1"))):
+        got = sorted((len(c), hashlib.md5(canon(c)).hexdigest()) for c, cs in zip(contigs, cset) if cs == si)
+        exp = sorted({(c["len"], c["md5"]) for h in ("hap1", "hap2") for c in gold[key][h]})
+        assert got == exp

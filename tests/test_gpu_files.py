@@ -74,3 +74,33 @@ def test_unphased_region_goes_to_both_haplotypes(tmp_path):
     calls = pipeline.parse_calls(raw)
     hap1_truth = [t for t in r.truth if t.hap in (1, 3)]
     assert len(calls) == len(hap1_truth) and all(c["gt"] == "1/1" for c in calls)
+
+
+def test_heterozygous_unphased_region(tmp_path):
+    """both haplotypes' reads unphased in one FASTA: the haplotype partition gives two contigs, one per HP file, and the
+    planted SVs come out with their genotypes (a homozygous DEL 1/1, the haplotype-private events 0/1)"""
+    out = str(tmp_path)
+    r = synth.make_region(0, start=10000)
+    d = os.path.join(out, "regions", "Region_chr21_S%d_E%d" % (r.start, r.start + len(r.ref)))
+    os.makedirs(d)
+    with open(os.path.join(d, "unphased.fa"), "w") as f:
+        for j, rd in enumerate(r.reads[0] + r.reads[1]):
+            f.write(">u%d\n%s\n" % (j, rd.decode()))
+    import random
+    rng = random.Random(7)
+    seq = [rng.choice("ACGT") for _ in range(r.start + len(r.ref) + 20000)]
+    seq[r.start:r.start + len(r.ref)] = r.ref.decode()
+    ref_fa = os.path.join(out, "ref.fa")
+    with open(ref_fa, "w") as f:
+        f.write(">chr21\n" + fasta.fold("".join(seq), 60) + "\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env)
+    hp1 = [s for _, s in fasta.read_fasta(os.path.join(d, "HP1.fa"))]
+    hp2 = [s for _, s in fasta.read_fasta(os.path.join(d, "HP2.fa"))]
+    assert len(hp1) == 1 and len(hp2) == 1 and sorted(map(len, hp1 + hp2)) == sorted(map(len, r.haps))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env,
+                          stdout=subprocess.DEVNULL)
+    raw = [l for l in open(os.path.join(out, "SV", "chr21", "dippav_raw_variant.vcf")) if l[0] != '#']
+    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for t in r.truth]
+    tp, fp, fn, gt = pipeline.match_truth(pipeline.parse_calls(raw), truth, bp_tol=1, len_tol=0.0)
+    assert (tp, fp, fn, gt) == (len(truth), 0, 0, len(truth))
