@@ -56,8 +56,10 @@ def records_from_alignment(rec, cigar, names: Sequence[str], chrom_of: Sequence[
     for r in rec:
         i = int(r["contig"])
         cg = cigar[int(r["cigar_off"]): int(r["cigar_off"]) + int(r["n_cigar"])]
-        out.append(S.AlignedSegment(chrom_of[i], int(r["ref_start"]) + offset_of[i], int(r["ref_end"]) + offset_of[i],
-                                    [(int(c) & 0xf, int(c) >> 4) for c in cg], names[i], bool(r["rev"]), int(r["mapq"]), None))
+        ops = [(int(c) & 0xf, int(c) >> 4) for c in cg]
+        for name in ([names[i]] if isinstance(names[i], str) else names[i]):   # a contig filed under both haplotypes has two names
+            out.append(S.AlignedSegment(chrom_of[i], int(r["ref_start"]) + offset_of[i], int(r["ref_end"]) + offset_of[i],
+                                        ops, name, bool(r["rev"]), int(r["mapq"]), None))
     order = sorted(range(len(out)), key=lambda k: (out[k].reference_name, out[k].pos))
     return [out[k] for k in order]
 

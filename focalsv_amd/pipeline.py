@@ -29,10 +29,11 @@ class RegionInput:
     reads_hp2: List[bytes]
     read_records: List[S.AlignedSegment] = field(default_factory=list)  # what the region BAM says about the reads (FP filter)
     name: str = ""
+    reads_unphased: List[bytes] = field(default_factory=list)   # unphased.fa: reads of both haplotypes, assembled with the partition
 
     @property
     def work(self) -> int:
-        return sum(map(len, self.reads_hp1)) + sum(map(len, self.reads_hp2))
+        return sum(map(len, self.reads_hp1)) + sum(map(len, self.reads_hp2)) + 2 * sum(map(len, self.reads_unphased))
 
 
 @dataclass
@@ -41,6 +42,8 @@ class DeviceBatch:
     packed: PackedBatch
     store_dev: int
     refs: tuple = None               # reference windows joined for fsv_align_batch (_lib.join_refs)
+    set_region: List[int] = None     # per read set: its region ...
+    set_kind: List[int] = None       # ... and what it holds: 1 / 2 = that haplotype's reads, 0 = unphased reads
 
     def free(self, ctx):
         if self.store_dev:
@@ -69,10 +72,11 @@ class CallResult:
 
 
 class _ContigText:
-    """contig name -> sequence text for vcf.allele_sequence, decoded on first use (only contigs carrying an INS are touched)"""
+    """contig name -> sequence text for vcf.allele_sequence, decoded on first use (only contigs carrying an INS are touched);
+    names[i] lists the names of contig i (two when one contig stands for both haplotypes)"""
 
     def __init__(self, names, batch):
-        self._idx = {n: i for i, n in enumerate(names)}
+        self._idx = {n: i for i, nm in enumerate(names) for n in nm}
         self._batch, self._cache = batch, {}
 
     def __contains__(self, name):
@@ -96,13 +100,16 @@ def region_from_synth(r, flank_start: int = 0) -> RegionInput:
 
 
 def upload_regions(ctx: _lib.Context, regions: Sequence[RegionInput]) -> DeviceBatch:
-    """K0: pack every read set (2 per region) into the 2-bit store and put it in HBM (done before the timed region)"""
-    sets = []
-    for r in regions:
-        sets.append(r.reads_hp1)
-        sets.append(r.reads_hp2)
+    """K0: pack every read set (hp1 and hp2 of every region, plus its unphased reads when there are any) into the 2-bit store
+    and put it in HBM (done before the timed region)"""
+    sets, set_region, set_kind = [], [], []
+    for ri, r in enumerate(regions):
+        for kind, reads in ((1, r.reads_hp1), (2, r.reads_hp2)):
+            sets.append(reads); set_region.append(ri); set_kind.append(kind)
+        if r.reads_unphased:
+            sets.append(r.reads_unphased); set_region.append(ri); set_kind.append(0)
     packed = pack_sets(sets)
-    return DeviceBatch(list(regions), packed, ctx.upload(packed.words), _lib.join_refs([r.ref for r in regions]))
+    return DeviceBatch(list(regions), packed, ctx.upload(packed.words), _lib.join_refs([r.ref for r in regions]), set_region, set_kind)
 
 
 def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> CallResult:
@@ -149,17 +156,32 @@ def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, ch
         host_ms[name] = round((t - t_prev[0]) * 1e3, 2)
         t_prev[0] = t
 
-    contigs, cset, cnr, set_status = ctx.assemble_batch(batch.store_dev, pk.word_off, pk.read_len, pk.set_start, asm_params)
+    set_kind = batch.set_kind if batch.set_kind is not None else [1 + (i & 1) for i in range(len(pk.set_start) - 1)]
+    set_region = batch.set_region if batch.set_region is not None else [i // 2 for i in range(len(pk.set_start) - 1)]
+    flags = [_lib.SET_UNPHASED if k == 0 else 0 for k in set_kind] if 0 in set_kind else None
+    contigs, cset, cnr, set_status = ctx.assemble_batch(batch.store_dev, pk.word_off, pk.read_len, pk.set_start, asm_params, flags)
     lap("assemble_call")
     asm_stats = ctx.asm_stats()
-    # reformat_fasta (DipPAV_variant_call.py:14-23): contigs are numbered per haplotype across the whole call
+    # reformat_fasta (DipPAV_variant_call.py:14-23): contigs are numbered per haplotype across the whole call.  The contigs of an
+    # unphased set are its two haplotypes (combine_fas.py:13-14 files them under HP1 / HP2); a single one stands for both.
     names, cref, chp, counters = [], [], [], {1: 0, 2: 0}
+    n_in_set: Dict[int, int] = {}
     for s in cset:
-        ri, hp = int(s) // 2, int(s) % 2 + 1
-        names.append("contig_hp%d_%d" % (hp, counters[hp]))
-        counters[hp] += 1
-        cref.append(ri)
-        chp.append(hp)
+        n_in_set[int(s)] = n_in_set.get(int(s), 0) + 1
+    seen: Dict[int, int] = {}
+    for s in cset:
+        s = int(s)
+        kind = set_kind[s]
+        k = seen.get(s, 0)
+        seen[s] = k + 1
+        hps = [kind] if kind else ([1, 2] if n_in_set[s] == 1 else [1 + (k & 1)])
+        nm = []
+        for hp in hps:
+            nm.append("contig_hp%d_%d" % (hp, counters[hp]))
+            counters[hp] += 1
+        names.append(nm)
+        cref.append(set_region[s])
+        chp.append(hps[0])
     # contigs=None: the aligner takes them from device memory, where the assembler left them
     rec, cigar, contig_status = ctx.align_batch(None, cref, batch.refs or [r.ref for r in regions], aln_params) if len(contigs) else (np.zeros(0, _lib.ALN_REC_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.int32))
     aln_stats = ctx.aln_stats() if len(contigs) else {}

@@ -75,3 +75,25 @@ def test_real_bed_geometry_config3(ctx, golden_dir):
     truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth]
     tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.02)
     assert (tp, fp, fn) == (len(truth), 0, 0), (calls, truth)
+
+
+def test_unphased_reads_in_memory_path(ctx):
+    """a region whose reads are all unphased (both haplotypes in one set) next to a phased region in the same batch: the
+    partition inside fsv_assemble_batch recovers both haplotypes and every planted SV comes out with its genotype"""
+    ra, rb, rc = (synth.make_region(i, start=i * 60000) for i in (8, 9, 12))
+    inputs = [pipeline.region_from_synth(r) for r in (ra, rb, rc)]
+    un = inputs[0]
+    un.reads_unphased, un.reads_hp1, un.reads_hp2 = un.reads_hp1 + un.reads_hp2, [], []
+    hom = inputs[2]            # only one haplotype's reads, unphased: one contig that stands for both haplotypes
+    hom.reads_unphased, hom.reads_hp1, hom.reads_hp2 = list(hom.reads_hp1), [], []
+    batch = pipeline.upload_regions(ctx, inputs)
+    try:
+        res = pipeline.run_hot_path(ctx, batch)
+    finally:
+        batch.free(ctx)
+    assert (res.contig_status == 0).all()
+    calls = pipeline.parse_calls(res.raw_lines)
+    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in (ra, rb) for t in r.truth]
+    truth += [(rc.chrom, t.svtype, rc.start + t.pos_left, t.length, "1/1") for t in rc.truth if t.hap in (1, 3)]
+    tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.02)
+    assert (tp, fp, fn, gt_ok) == (len(truth), 0, 0, len(truth)), (calls, truth)
