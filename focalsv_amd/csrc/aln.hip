@@ -726,7 +726,8 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
         FSV_HIP(ctx, hipMemsetAsync(W.sk_high.p, 0, (total_words + nr + 8) * 4, ctx->stream));
         hipLaunchKernelGGL(k_sketch_fast, dim3(nr), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, nr, P.w, P.k, 0,
-                           (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p);
+                           (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p,
+                           (const uint32_t *)nullptr);
     } else {
         uint32_t max_words = 1; int w_max = 1;
         for (uint32_t r = 0; r < nr; r++) { max_words = std::max<uint32_t>(max_words, (uint32_t)((len[r] + 15) / 16)); w_max = std::max<int>(w_max, wper[r]); }

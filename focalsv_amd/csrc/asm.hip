@@ -38,7 +38,7 @@ const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm
                                         "k_repack", "k_exact", "k_stitch"};
 
 struct AsmWs {
-    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, set_cols, trans, read_flag,
+    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, set_cols, trans, read_flag, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     // state of the last run (for fsv_asm_fetch_reads / stats)
@@ -52,7 +52,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &set_cols, &trans, &read_flag, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &set_cols, &trans, &read_flag, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -123,7 +123,7 @@ struct Geometry {
 // k-mer ties with the window minimum and ha_sketch reports all of them); 16 B x bases is 2 % of HBM for 256 regions
 static inline uint64_t mz_slots(int64_t len, int) { return (uint64_t)len + 64; }
 
-int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len, Geometry &G, int mz_w = 51)
+int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len, Geometry &G, int mz_w = 51, const std::vector<uint32_t> *fixed_mz_off = nullptr)
 {
     G.word_off.assign(B.n_reads + 1, 0); G.mz_off.assign(B.n_reads + 1, 0); G.gwin_off.assign(B.n_reads + 1, 0);
     G.max_words = 1;
@@ -137,6 +137,7 @@ int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len,
     }
     if (w + 4 >= (1ull << 32) || m >= (1ull << 32) || g >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "batch too large for 32-bit offsets; split it");
     G.word_off[B.n_reads] = (uint32_t)w; G.mz_off[B.n_reads] = (uint32_t)m; G.gwin_off[B.n_reads] = (uint32_t)g;
+    if (fixed_mz_off) G.mz_off = *fixed_mz_off;   // slots that do not move between rounds (sized for the longest a read can get)
     G.gwin_read.resize(g);
     for (uint32_t r = 0; r < B.n_reads; r++) for (uint32_t x = G.gwin_off[r]; x < G.gwin_off[r + 1]; x++) G.gwin_read[x] = r;
     G.task_bound = 0;
@@ -151,7 +152,7 @@ int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len,
 
 // sketch + per-read index + chaining on the current store; fills ws.ovl (and ws.tasks when emit_tasks)
 int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, const uint32_t *store, const fsv_asm_params &P, int bw,
-                  bool emit_tasks, uint32_t task_cap)
+                  bool emit_tasks, uint32_t task_cap, const uint32_t *only_changed = nullptr)
 {
     Timer ts(ctx);
     TRY(ensure(ctx, W.mz, (size_t)G.mz_off[B.n_reads] * sizeof(fsv_mz)));
@@ -161,7 +162,9 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     TRY(ensure(ctx, W.counters, 64));
     FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, 64, ctx->stream));
     W.kt.begin(ctx, KN_SKETCH, (uint64_t)G.word_off[B.n_reads] * 4 + (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz));
-    FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+    if (!(only_changed && (P.k & 1))) FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+    // (with only_changed the unchanged reads keep their count; the kernel zeroes the others itself)
+    if (!(P.k & 1)) only_changed = nullptr; // the replay kernel (even k) always sketches every read
     if (P.k & 1) {
         // position-parallel sketch (odd k): per-read scratch for run ends (4 B / base) and two bit planes, planes zeroed per launch
         const size_t total_words = G.word_off[B.n_reads];
@@ -172,7 +175,8 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
         FSV_HIP(ctx, hipMemsetAsync(W.sk_high.p, 0, (total_words + B.n_reads + 8) * 4, ctx->stream));
         hipLaunchKernelGGL(k_sketch_fast, dim3(B.n_reads), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
-                           P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p);
+                           P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p,
+                           only_changed);
         FSV_HIP(ctx, hipGetLastError());
     } else {
         const uint32_t lds_words = std::min<uint32_t>(G.max_words, 8192u);
@@ -193,10 +197,10 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     W.kt.begin(ctx, KN_UNIQ, (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz) * 2);
     if (max_raw <= 1024)
         hipLaunchKernelGGL(k_uniq<1024>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
-                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p);
+                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed);
     else
         hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
-                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p);
+                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
     W.stats.ms_sketch += ts.stop();
@@ -464,8 +468,17 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         if (any_unphased) TRY(upload(ctx, W.read_flag, rf));
     }
 
+    // minimizer slots stay where they are for the whole call (a read grows by a few bases at most when it is corrected): the
+    // final pass can then keep the lists of reads the last round did not change
+    std::vector<uint32_t> mz_fixed(B.n_reads + 1, 0);
+    {
+        uint64_t m = 0;
+        for (uint32_t r = 0; r < B.n_reads; r++) { mz_fixed[r] = (uint32_t)m; m += mz_slots((int64_t)len[r] + len[r] / 8 + 64, P.w); }
+        if (m >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "batch too large for 32-bit offsets; split it");
+        mz_fixed[B.n_reads] = (uint32_t)m;
+    }
     Geometry G;
-    TRY(make_geometry(ctx, B, len, G, P.w));
+    TRY(make_geometry(ctx, B, len, G, P.w, &mz_fixed));
     // round 0 reads the caller's store through the caller's word offsets
     std::vector<uint32_t> woff0(B.n_reads + 1);
     for (uint32_t r = 0; r <= B.n_reads; r++) {
@@ -585,6 +598,9 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         C.gwin_tab = (const uint4 *)W.gwin_tab.p; C.tasks = (const fsv_wtask *)W.tasks.p;
         C.paths = (const fsv_wpath *)W.paths.p; C.cwin = (uint8_t *)W.cwin.p; C.cwin_len = (uint16_t *)W.cwin_len.p; C.warn = (uint32_t *)W.warn.p;
         C.n_reads = B.n_reads;
+        TRY(ensure(ctx, W.changed, (size_t)B.n_reads * 4));
+        FSV_HIP(ctx, hipMemsetAsync(W.changed.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+        C.changed = (uint32_t *)W.changed.p;
         if (any_unphased && n_tasks && B.n_pairs) {
             // unphased sets: mark the overlaps that carry the other allele at a heterozygous column, then take them out of
             // the consensus (and, through is_match = 2, out of what the final pass accepts as verified)
@@ -607,7 +623,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         FSV_HIP(ctx, hipMemcpyAsync(nlen.data(), W.new_len.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         Geometry G2;
-        TRY(make_geometry(ctx, B, nlen, G2, P.w));
+        TRY(make_geometry(ctx, B, nlen, G2, P.w, &mz_fixed));
         DevBuf &dst = W.store[round & 1];
         const uint32_t total_words = G2.word_off[B.n_reads];
         TRY(ensure(ctx, dst, ((size_t)total_words + 8) * 4));
@@ -641,7 +657,8 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         TRY(ensure(ctx, W.ovl_prev, (size_t)B.n_pairs * sizeof(fsv_ovl)));
         FSV_HIP(ctx, hipMemcpyAsync(W.ovl_prev.p, W.ovl.p, (size_t)B.n_pairs * sizeof(fsv_ovl), hipMemcpyDeviceToDevice, ctx->stream));
     }
-    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0));
+    // reads the last round left untouched keep that round's minimizer lists (the last round does not reverse-complement)
+    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0, P.n_rounds > 0 ? (const uint32_t *)W.changed.p : nullptr));
     trace("overlaps");
     const fsv_hit *hraw = nullptr;
     std::vector<uint32_t> hit_first(B.n_sets + 1, 0);
@@ -847,7 +864,8 @@ extern "C" int fsv_sketch_reads(fsv_ctx *ctx, const fsv_readsets *sets, int32_t 
         FSV_HIP(ctx, hipMemsetAsync(W.sk_high.p, 0, (total_words + B.n_reads + 8) * 4, ctx->stream));
         hipLaunchKernelGGL(k_sketch_fast, dim3(B.n_reads), dim3(256), 0, ctx->stream, sets->store_dev, (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, w, k, hpc,
-                           (uint32_t *)W.warn.p, (const uint8_t *)nullptr, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p);
+                           (uint32_t *)W.warn.p, (const uint8_t *)nullptr, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p,
+                           (const uint32_t *)nullptr);
     } else {
         const uint32_t lds_words = std::min<uint32_t>(G.max_words, 8192u);
         FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(w, lds_words)));

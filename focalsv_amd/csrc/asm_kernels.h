@@ -205,13 +205,14 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
 // One workgroup per read: bitonic sort of (hash, pos) in LDS, keep hashes that occur exactly once.
 template <int UQ_MAX>
 __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
-                                              uint32_t *__restrict__ warn)
+                                              uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed = nullptr)
 {
     __shared__ uint64_t s_hash[UQ_MAX];
     __shared__ uint64_t s_pay[UQ_MAX]; // pos | rev << 32 | span << 40
     __shared__ uint32_t s_scan[256];
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
+    if (only_changed && !only_changed[r]) return;   // lists of an unchanged read are already in place
     fsv_mz *a = mz + mz_off[r];
     uint32_t n = min(mz_cnt[r], mz_off[r + 1] - mz_off[r]); // k_sketch counts past the cap when it truncates
     if (n > UQ_MAX) { if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = UQ_MAX; }
@@ -1016,6 +1017,7 @@ struct ConsArgs {
     uint8_t *cwin;               // FSV_CW_STRIDE bytes per grid window (2-bit codes, one per byte)
     uint16_t *cwin_len;
     uint32_t *warn;
+    uint32_t *changed;           // per read: set when the consensus of some window differs from the read (nullptr: not tracked)
     uint32_t n_reads;
 };
 
@@ -1163,6 +1165,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     const uint32_t evn = min(s_evn, (uint32_t)FSV_EV_CAP);
     if (s_evn > FSV_EV_CAP && lane == 0) atomicOr(&A.warn[r], 8u);
     int arrived = before;
+    bool differs = false;
     for (int c = c0; c < c1; c++) {
         arrived += s_cov[c];
         const uint32_t own = XB(gs + c);
@@ -1204,7 +1207,9 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
             if (bestb < 4) s_out[c][1 + nb++] = (uint8_t)bestb;
         }
         s_out[c][0] = nb;
+        if (nb != 1 || s_out[c][1] != (uint8_t)own) differs = true;
     }
+    if (differs && A.changed) A.changed[r] = 1u;
     __syncthreads();
     uint32_t mine = 0;
     for (int c = c0; c < c1; c++) mine += s_out[c][0];
@@ -1534,7 +1539,8 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
                                                      const int32_t *__restrict__ read_len, const uint32_t *__restrict__ mz_off,
                                                      fsv_mz *__restrict__ mz, uint32_t *__restrict__ mz_cnt, uint32_t n_reads, int w, int k,
                                                      int hpc, uint32_t *__restrict__ warn, const uint8_t *__restrict__ w_per_read,
-                                                     uint32_t *__restrict__ sc_ends, uint32_t *__restrict__ sc_low, uint32_t *__restrict__ sc_high)
+                                                     uint32_t *__restrict__ sc_ends, uint32_t *__restrict__ sc_low, uint32_t *__restrict__ sc_high,
+                                                     const uint32_t *__restrict__ only_changed)
 {
     __shared__ uint64_t s_h[SKF_T + 2 * 256];   // w <= 255
     __shared__ uint64_t s_wmin[SKF_T + 2 * 256];
@@ -1545,11 +1551,14 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
     const int tid = threadIdx.x;
     const uint32_t r = blockIdx.x;
     if (r >= n_reads) return;
+    // a read the last correction round left as it was keeps the minimizers of that round (same sequence, same slot)
+    if (only_changed && !only_changed[r]) return;
     const uint32_t woff = word_off[r];
     const int len = read_len[r];
     const uint32_t cap = mz_off[r + 1] - mz_off[r];
     fsv_mz *out = mz + mz_off[r];
     if (w_per_read) w = w_per_read[r];
+    if (tid == 0) mz_cnt[r] = 0;   // (the first emit comes after several barriers)
     uint32_t *ends = sc_ends + (size_t)woff * 16;          // entry -> index of the run's last base
     uint32_t *low = sc_low + woff + r, *high = sc_high + woff + r; // bit planes of the compressed bases (zeroed by the host)
     const uint64_t NONE = ~0ull;
