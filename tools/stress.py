@@ -43,6 +43,23 @@ def main():
         rd = list(r.reads[0]); rd[0] = rd[0][:100] + b"N" * 20 + rd[0][120:]; rd[1] = rd[1].lower()
         r.reads = (rd, r.reads[1])
         run(ctx, "N run and lower case in reads", [r], check=False)
+        # read lengths far from the bench's: 40-80 kb reads over a 200 kb window, and a set of very short reads
+        import numpy as np
+        rng = np.random.default_rng(9)
+        big = synth.make_region(706, width=200000, start=0)
+        hap = np.frombuffer(big.haps[0], dtype=np.uint8)
+        long_reads = []
+        for _ in range(60):
+            L = int(rng.integers(40000, 80000)); s0 = int(rng.integers(0, hap.size - L))
+            long_reads.append(synth._add_errors(rng, hap[s0:s0 + L], 0.002).tobytes())
+        big.reads = (long_reads, big.reads[1])
+        run(ctx, "40-80 kb reads", [big])
+        tiny = synth.make_region(707, start=0)
+        tiny.reads = ([rd[:300] for rd in tiny.reads[0]], [rd[:40] for rd in tiny.reads[1]])
+        run(ctx, "300-base and 40-base reads", [tiny])
+        one = synth.make_region(708, start=0)
+        one.reads = (one.reads[0][:1], [])
+        run(ctx, "one read / empty set", [one])
     print("stress done")
 
 main()
