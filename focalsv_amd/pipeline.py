@@ -205,6 +205,34 @@ def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, ch
     return CallResult(header, final, raw, contigs, cref, chp, set_status, contig_status, asm_stats, aln_stats, host_ms)
 
 
+def run_hot_path_lanes(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBatch], **kw) -> Tuple[List[CallResult], List[str]]:
+    """several batches at once on one GPU, each on its own context (= its own HIP stream and workspace) and host thread: while
+    one lane is in its host-side stretches (CIGAR stitching, the Python SV logic, the layout) or in a latency-bound kernel, the
+    other lane's kernels keep the CUs busy.  Two lanes of 128 regions beat one lane of 256 by ~10 % on MI355X; more lanes only
+    shrink the launches.  Regions are independent, so the union of the lanes' calls is the result.  -> (per-lane results, the
+    merged VCF body in (chrom, pos) order)"""
+    if len(ctxs) == 1:
+        res = run_hot_path(ctxs[0], batches[0], **kw)
+        return [res], list(res.lines)
+    out: List[Optional[CallResult]] = [None] * len(ctxs)
+    errs: List[BaseException] = []
+
+    def work(k):
+        try:
+            out[k] = run_hot_path(ctxs[k], batches[k], **kw)
+        except BaseException as e:
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k,), name="fsv-lane-%d" % k) for k in range(len(ctxs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    return out, sorted((l for o in out for l in o.lines), key=_vcf_key)
+
+
 # ------------------------------------------------------------------------------------------------ multi-GPU
 def shard_regions(work: Sequence[int], world_size: int) -> List[List[int]]:
     """static region -> rank assignment: largest first onto the least loaded rank.  Deterministic."""

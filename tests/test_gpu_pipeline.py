@@ -97,3 +97,25 @@ def test_unphased_reads_in_memory_path(ctx):
     truth += [(rc.chrom, t.svtype, rc.start + t.pos_left, t.length, "1/1") for t in rc.truth if t.hap in (1, 3)]
     tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.02)
     assert (tp, fp, fn, gt_ok) == (len(truth), 0, 0, len(truth)), (calls, truth)
+
+
+def test_two_lanes_give_the_same_calls():
+    """pipeline.run_hot_path_lanes: halves of the batch on two contexts / streams / host threads -> the single-lane VCF body"""
+    rs = [synth.make_region(i, start=i * 60000) for i in range(20, 28)]
+    inputs = [pipeline.region_from_synth(r) for r in rs]
+    with _lib.Context(0) as c0:
+        b0 = pipeline.upload_regions(c0, inputs)
+        one = pipeline.run_hot_path(c0, b0)
+        b0.free(c0)
+    ctxs = [_lib.Context(0), _lib.Context(0)]
+    try:
+        batches = [pipeline.upload_regions(c, inputs[k::2]) for k, c in enumerate(ctxs)]
+        results, lines = pipeline.run_hot_path_lanes(ctxs, batches)
+        for c, b in zip(ctxs, batches):
+            b.free(c)
+    finally:
+        for c in ctxs:
+            c.close()
+    key = lambda ls: sorted((c["chrom"], c["pos"], c["type"], c["svlen"], c["gt"]) for c in pipeline.parse_calls(ls))   # contigs are numbered per call
+    assert key(lines) == key(one.lines) and len(lines) > 10
+    assert sorted(l.split('\t')[4] for l in lines) == sorted(l.split('\t')[4] for l in one.lines)                     # ALT sequences
