@@ -361,7 +361,7 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         TRY(fsv_bpm_windows_dev(ctx, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, n_tasks, (fsv_wres *)d_res.p));
         hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_ovl *)d_ovl.p,
                            (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p, n_tasks, (fsv_wpath *)d_paths.p, (uint32_t *)d_list.p,
-                           (uint32_t *)d_cnt.p + 2, (uint32_t *)d_cnt.p + 6);
+                           (uint32_t *)d_cnt.p + 2, (uint32_t *)d_cnt.p + 6, true);
         FSV_HIP(ctx, hipGetLastError());
         uint32_t cnt[8];
         FSV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -526,7 +526,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             W.kt.begin(ctx, KN_PATH_FAST, (uint64_t)n_tasks * (48 + 128));
             hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
                                (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, n_tasks, (fsv_wpath *)W.paths.p,
-                               (uint32_t *)W.dp_list.p, (uint32_t *)W.counters.p + 2, (uint32_t *)W.counters.p + 6);
+                               (uint32_t *)W.dp_list.p, (uint32_t *)W.counters.p + 2, (uint32_t *)W.counters.p + 6, false);
             FSV_HIP(ctx, hipGetLastError());
             W.kt.end(ctx);
             uint32_t cnt2[8];

@@ -715,7 +715,7 @@ __device__ __forceinline__ uint32_t task_ybase(const uint32_t *__restrict__ stor
 __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ store, const fsv_ovl *__restrict__ ovl,
                                                    const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res, uint32_t n_tasks,
                                                    fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list, uint32_t *__restrict__ dp_count,
-                                                   uint32_t *__restrict__ dp_count_wide)
+                                                   uint32_t *__restrict__ dp_count_wide, bool write_clean_ops)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n_tasks) return;
@@ -770,6 +770,9 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     P->ry_start = t.y_start - t.k + s2;
     P->ry_end = t.y_start - t.k + e2;
     P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
+    // a distance-0 record carries no ops: its consumers (k_consensus, k_het) look at err first and never read them, and in the
+    // later correction rounds nearly every window is one -- 24 bytes out instead of 128
+    if (r.err == 0 && !write_clean_ops) return;
     uint2 *dst = reinterpret_cast<uint2 *>(P->ops); // ops sit at byte 24 of the record: 8-byte aligned
 #pragma unroll
     for (int i = 0; i < 13; i++) dst[i] = make_uint2(ops32[2 * i], ops32[2 * i + 1]);
