@@ -514,11 +514,11 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             TRY(fsv_bpm_windows_dev(ctx, store, (const fsv_wtask *)W.tasks.p, n_tasks, (fsv_wres *)W.res.p));
             W.kt.end(ctx);
             W.kt.begin(ctx, KN_RESCUE, (uint64_t)n_tasks * 48 + (uint64_t)B.n_pairs * sizeof(fsv_ovl) * 2);
-    hipLaunchKernelGGL(k_rescue_accept, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
+            hipLaunchKernelGGL(k_rescue_accept, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
                                B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)((uint32_t *)W.counters.p + 4),
                                (uint4 *)W.ovl_c.p);
             FSV_HIP(ctx, hipGetLastError());
-    W.kt.end(ctx);
+            W.kt.end(ctx);
             W.stats.ms_verify += tv.stop();
             Timer tp(ctx);
             TRY(ensure(ctx, W.paths, (size_t)n_tasks * sizeof(fsv_wpath)));
@@ -613,9 +613,9 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             FSV_HIP(ctx, hipGetLastError());
         }
         W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_tasks * 128 + (uint64_t)n_gwin * (96 + 448));
-    hipLaunchKernelGGL(k_consensus, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
+        hipLaunchKernelGGL(k_consensus, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
         FSV_HIP(ctx, hipGetLastError());
-    W.kt.end(ctx);
+        W.kt.end(ctx);
         hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
                            (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p);
         FSV_HIP(ctx, hipGetLastError());
@@ -630,11 +630,11 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         // k_repack needs the new offsets/lengths while the old ones are still in use by nothing else: stage them in mz_cnt/new_len
         TRY(upload(ctx, W.unpack_off, G2.word_off));
         W.kt.begin(ctx, KN_REPACK, (uint64_t)n_gwin * 384 + (uint64_t)total_words * 4);
-    hipLaunchKernelGGL(k_repack, dim3(fsv_grid_for(total_words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
+        hipLaunchKernelGGL(k_repack, dim3(fsv_grid_for(total_words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
                            (const uint16_t *)W.cwin_len.p, (const uint8_t *)W.cwin.p, (const uint32_t *)W.unpack_off.p,
                            (const int32_t *)W.new_len.p, B.n_reads, total_words, round + 1 < P.n_rounds ? 1 : 0, (uint32_t *)dst.p);
         FSV_HIP(ctx, hipGetLastError());
-    W.kt.end(ctx);
+        W.kt.end(ctx);
         FSV_HIP(ctx, hipMemsetAsync((uint8_t *)dst.p + (size_t)total_words * 4, 0, 32, ctx->stream));
         W.stats.ms_consensus += tcs.stop();
         store = (const uint32_t *)dst.p;
@@ -775,10 +775,10 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         TRY(upload(ctx, W.pieces, pieces));
         TRY(ensure(ctx, W.contig_out, used + 16));
         W.kt.begin(ctx, KN_STITCH, used * 2);
-    hipLaunchKernelGGL(k_stitch, dim3((uint32_t)pieces.size()), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
+        hipLaunchKernelGGL(k_stitch, dim3((uint32_t)pieces.size()), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const fsv_piece *)W.pieces.p, (char *)W.contig_out.p);
         FSV_HIP(ctx, hipGetLastError());
-    W.kt.end(ctx);
+        W.kt.end(ctx);
         ctx->last_contigs_dev = (const char *)W.contig_out.p;
         FSV_HIP(ctx, hipMemcpyAsync(out->seq, W.contig_out.p, used, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
