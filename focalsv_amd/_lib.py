@@ -74,6 +74,17 @@ ALN_REC_DTYPE = np.dtype([("ref_start", "<i4"), ("ref_end", "<i4"), ("q_start", 
 assert ALN_REC_DTYPE.itemsize == 40
 
 
+class BamRecords(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pos", "ref_end", "flag", "mapq", "cigar_off", "n_cigar_op", "qname_off", "l_seq", "cigar", "qname",
+                                          "seq_word_off", "seq_words_buf", "seq_ascii", "seq_ascii_off", "ref_id", "ps", "hp")] + \
+               [(n, C.c_uint64) for n in ("rec_cap", "cigar_cap", "qname_cap", "seq_cap", "seq_ascii_cap", "n_rec", "n_cigar", "qname_bytes",
+                                          "seq_words", "seq_ascii_bytes")]
+
+
+READ_SIG_DTYPE = np.dtype([("rec", "<u4"), ("type", "<u4"), ("ref_pos", "<i4"), ("len", "<i4"), ("read_off", "<i4"), ("pad", "<u4")])
+assert READ_SIG_DTYPE.itemsize == 24
+
+
 class FsvError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -120,6 +131,14 @@ def load():
         "fsv_aln_default_params": (None, [C.POINTER(AlnParams)]),
         "fsv_align_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.POINTER(AlnParams), C.POINTER(Alns)]),
         "fsv_aln_last_stats": (C.c_int, [vp, C.POINTER(AlnStats)]),
+        "fsv_bam_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "fsv_bam_close": (None, [vp]),
+        "fsv_bam_n_refs": (C.c_int, [vp]),
+        "fsv_bam_ref_name": (C.c_char_p, [vp, C.c_int]),
+        "fsv_bam_ref_id": (C.c_int, [vp, C.c_char_p]),
+        "fsv_bam_has_index": (C.c_int, [vp]),
+        "fsv_bam_fetch": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int64, C.POINTER(BamRecords), C.c_int]),
+        "fsv_read_signatures": (C.c_int, [vp, C.POINTER(BamRecords), C.c_int, C.c_int, vp, C.c_uint32, u32p]),
         "fsv_nw": (C.c_int, [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnParams), C.POINTER(C.c_int32), vp, C.c_uint32,
                              C.POINTER(C.c_uint32)]),
     }

@@ -86,14 +86,13 @@ def reads_signatures(records, min_mapq=50):
 
 
 def records_from_bam(bam_path, chrom):
-    """the records pysam yields for one chromosome; None when pysam is not installed (it is not in the build image, it is
-    wherever the reference runs)"""
-    try:
-        import pysam
-    except ImportError:
-        return None
-    with pysam.AlignmentFile(bam_path) as bam:
-        return list(bam.fetch(chrom))
+    """the records pysam's fetch(chrom) yields, through the library's own BAM reader (focalsv_amd.bam; no pysam, no GPU)"""
+    from .. import bam
+    with bam.BamFile(bam_path) as f:
+        if chrom not in f.references:
+            return []
+        recs = f.fetch(chrom)
+    return [recs.segment(r) for r in range(len(recs))]
 
 
 def write_reads_sig(sigs, output_dir, chrom):

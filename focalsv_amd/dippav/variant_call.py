@@ -79,8 +79,8 @@ def dippav_variant_call(data_type, read_bam_file, reference_path, hp1_contig_pat
                         ctx: Optional[_lib.Context] = None, device: int = 0):
     """Drop-in for DipPAV_variant_call.dippav_variant_call.  Extra keyword-only arguments:
       regions       {contig_name: (chrom, win_start, win_end)} when the FASTA headers carry no region tag
-      read_records  AlignedSegment-like records of the chromosome's reads (what pysam would yield from read_bam_file);
-                    without pysam in the image a BAM path alone cannot be read, and the FP filter then sees no read support
+      read_records  AlignedSegment-like records of the chromosome's reads, instead of read_bam_file (which is read with the
+                    library's own BAM reader, focalsv_amd.bam, and its CIGARs scanned on the GPU)
     """
     assert data_type in ('CCS', 'CLR', 'ONT')
     logger = logging.getLogger(" ")
@@ -117,6 +117,12 @@ def dippav_variant_call(data_type, read_bam_file, reference_path, hp1_contig_pat
     try:
         keep = [i for i, w in enumerate(wins) if w[0] == chrom and seqs[i]]
         rec, cigar, status = ctx.align_batch([seqs[i].encode() for i in keep], [win_index[wins[i]] for i in keep], refs)
+        # read signatures (extract_reads_signature.py): from the records handed in, or straight from the BAM
+        if read_records is None and read_bam_file:
+            from .. import bam
+            rsigs = bam.reads_signatures(ctx, read_bam_file, chrom, 50)
+        else:
+            rsigs = reads_signature.reads_signatures(read_records or [], 50)
     finally:
         if own:
             ctx.close()
@@ -136,12 +142,7 @@ def dippav_variant_call(data_type, read_bam_file, reference_path, hp1_contig_pat
     raw = os.path.join(output_dir, "dippav_raw_variant.vcf")
     with open(raw, 'w') as f:
         f.writelines(header); f.writelines(body)
-    # read signatures (extract_reads_signature.py) -> FP filter -> redundancy
-    if read_records is None and read_bam_file:
-        read_records = reads_signature.records_from_bam(read_bam_file, chrom)
-        if read_records is None:
-            logger.warning("read BAM %s cannot be parsed here (pysam is not installed); pass read_records=", read_bam_file)
-    rsigs = reads_signature.reads_signatures(read_records or [], 50)
+    # read signatures -> FP filter -> redundancy
     reads_signature.write_reads_sig(rsigs, output_dir, chrom)
     filtered = os.path.join(output_dir, "dippav_variant_filtered.vcf")
     fp_filter.FP_filter(raw, os.path.join(output_dir, 'reads_signature'), filtered)

@@ -112,6 +112,29 @@ def upload_regions(ctx: _lib.Context, regions: Sequence[RegionInput]) -> DeviceB
     return DeviceBatch(list(regions), packed, ctx.upload(packed.words), _lib.join_refs([r.ref for r in regions]), set_region, set_kind)
 
 
+def upload_bam_regions(ctx: _lib.Context, bam_path: str, regions: Sequence[Tuple[str, int, int]], windows: Sequence[Tuple[int, bytes]]) -> DeviceBatch:
+    """K0 straight from a haplotagged BAM: crop (1_crop_bam.py:74 -- the records `samtools view bam chr:s-e` keeps), group by the
+    PS / HP tags (2_phasing/output_fas.py:28-73) and gather the reads' bases as 2-bit words into the store, without a region.bam, a
+    FASTA or the reads' text in between.  regions[i] = (chrom, start, end) as in the BED line (1-based inclusive, like the samtools
+    region string); windows[i] = (chromosome coordinate of ref[0], reference window)."""
+    from . import bam as B, output_fas as OF
+    from .readsets import concat_packed
+    inputs, packs, set_region, set_kind = [], [], [], []
+    with B.BamFile(bam_path) as f:
+        for ri, ((chrom, start, end), (wstart, ref)) in enumerate(zip(regions, windows)):
+            recs = f.fetch(chrom, start - 1, end, want_seq=1)
+            files = OF.read_set_files(recs)
+            sets = []
+            for fn in sorted(files):
+                kind = 0 if fn == "unphased.fa" else int(fn[:-3].rsplit("_hp", 1)[1])
+                sets.append(files[fn]); set_region.append(ri); set_kind.append(kind)
+            packs.append(OF.pack_record_sets(recs, sets))
+            r = RegionInput(chrom, wstart, ref, [], [], [recs.segment(k) for k in range(len(recs))], "Region_%s_S%d_E%d" % (chrom, start, end))
+            inputs.append(r)
+    packed = concat_packed(packs)
+    return DeviceBatch(inputs, packed, ctx.upload(packed.words), _lib.join_refs([r.ref for r in inputs]), set_region, set_kind)
+
+
 def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> CallResult:
     regions, pk = batch.regions, batch.packed
     chroms = sorted({r.chrom for r in regions}, key=lambda c: (len(c), c))

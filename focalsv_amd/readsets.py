@@ -31,3 +31,19 @@ def pack_sets(sets: Sequence[Sequence[bytes]]) -> PackedBatch:
         start.append(len(reads))
     words, off, lens = _lib.pack_reads(reads)
     return PackedBatch(words, off, lens, np.asarray(start, dtype=np.uint32))
+
+
+def concat_packed(packs: Sequence[PackedBatch]) -> PackedBatch:
+    """several stores back to back (each one's tail slack dropped, one slack at the end)"""
+    words, off, lens, start = [], [np.zeros(1, np.uint64)], [], [np.zeros(1, np.uint32)]
+    w0, r0 = 0, 0
+    for p in packs:
+        n = int(p.word_off[-1]) if len(p.word_off) else 0
+        words.append(p.words[:n])
+        off.append(p.word_off[1:] + np.uint64(w0))
+        lens.append(p.read_len)
+        start.append(p.set_start[1:] + np.uint32(r0))
+        w0 += n
+        r0 += p.n_reads
+    words.append(np.zeros(4, np.uint32))
+    return PackedBatch(np.concatenate(words), np.concatenate(off), np.concatenate(lens) if lens else np.zeros(0, np.int32), np.concatenate(start))

@@ -295,6 +295,55 @@ int fsv_aln_last_stats(const fsv_ctx *ctx, fsv_aln_stats *out);
 int fsv_nw(fsv_ctx *ctx, const char *target, int32_t tl, const char *query, int32_t ql, const fsv_aln_params *params,
            int32_t *score, uint32_t *cigar, uint32_t cigar_cap, uint32_t *n_cigar);
 
+/* ---- BAM input without pysam / samtools --------------------------------------------------------------
+ * Replaces, at the reference's pysam boundary, `pysam.AlignmentFile(bam).fetch(chr)` with its per-record fields
+ * (extract_reads_signature.py:68-105, 160-209: reference_name, pos, reference_end, cigar, qname, is_reverse, mapq, flag) and the
+ * `samtools view bam chr:start-end` crop of 1_crop_bam.py:74.  BGZF blocks are inflated with zlib on the host; a .bai next to the
+ * file (x.bam.bai or x.bai) gives the start of a region, without one the file is scanned from its first record.  No GPU needed
+ * for fsv_bam_*; fsv_read_signatures runs the CIGAR scan (extract_sig_from_cigar, extract_reads_signature.py:11-44) as a kernel. */
+typedef struct fsv_bam fsv_bam;
+int  fsv_bam_open(const char *path, fsv_bam **out);
+void fsv_bam_close(fsv_bam *bam);
+int  fsv_bam_n_refs(const fsv_bam *bam);
+const char *fsv_bam_ref_name(const fsv_bam *bam, int ref_id);
+int  fsv_bam_ref_id(const fsv_bam *bam, const char *name);   /* -1: no such reference sequence */
+int  fsv_bam_has_index(const fsv_bam *bam);
+
+typedef struct fsv_bam_records {
+    /* all host; caller-allocated with the capacities below (a first call with pos == NULL only counts) */
+    int32_t  *pos, *ref_end;      /* 0-based start, exclusive end on the reference (pysam pos / reference_end) */
+    uint16_t *flag;
+    uint8_t  *mapq;
+    uint64_t *cigar_off;          /* record r owns cigar[cigar_off[r] .. + n_cigar_op[r]) */
+    uint32_t *n_cigar_op;
+    uint64_t *qname_off;          /* NUL-terminated name of record r at qname + qname_off[r] */
+    int32_t  *l_seq;
+    uint32_t *cigar;              /* BAM encoding len << 4 | op */
+    char     *qname;
+    uint64_t *seq_word_off;       /* want_seq: bases of record r, 2 bits each as in the read store, from seq_words_buf[seq_word_off[r]] */
+    uint32_t *seq_words_buf;
+    char     *seq_ascii;          /* want_seq & 2: bases of record r as text (pysam read.seq), l_seq[r] bytes from seq_ascii + seq_ascii_off[r] */
+    uint64_t *seq_ascii_off;
+    int32_t  *ref_id;             /* optional: reference sequence of the record (-1 unmapped) */
+    int32_t  *ps, *hp;            /* optional (both or neither): integer PS / HP tags of the record, FSV_BAM_NO_TAG when absent (output_fas.py:31-33) */
+    uint64_t rec_cap, cigar_cap, qname_cap, seq_cap, seq_ascii_cap;
+    uint64_t n_rec, n_cigar, qname_bytes, seq_words, seq_ascii_bytes;   /* out */
+} fsv_bam_records;
+#define FSV_BAM_NO_TAG (-2147483647 - 1)
+/* mapped records of reference ref_id that overlap [beg, end) (end <= 0: to the end), in file order; ref_id -1: every record of the
+ * file (pysam fetch(until_eof=True), output_fas.py:26).  want_seq: bit 0 the 2-bit words, bit 1 the text */
+int fsv_bam_fetch(fsv_bam *bam, int ref_id, int64_t beg, int64_t end, fsv_bam_records *out, int want_seq);
+
+typedef struct fsv_read_sig {
+    uint32_t rec;                 /* index into the fetched records */
+    uint32_t type;                /* 0 DEL, 1 INS */
+    int32_t  ref_pos, len;        /* 0-based reference position of the event, its length */
+    int32_t  read_off;            /* offset in the read, hard clip at the head included (extract_reads_signature.py:19-24) */
+    uint32_t pad;
+} fsv_read_sig;                   /* 24 bytes */
+/* DEL / INS of at least min_svlen in the CIGARs of records with mapq >= min_mapq; order of `out` is unspecified (sort by rec, read_off) */
+int fsv_read_signatures(fsv_ctx *ctx, const fsv_bam_records *rec, int min_mapq, int min_svlen, fsv_read_sig *out, uint32_t cap, uint32_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

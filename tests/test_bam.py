@@ -1,0 +1,282 @@
+"""The native BAM reader (focalsv_amd/csrc/bam.hip host side; no GPU needed): round trip against the test-side writer."""
+import random
+
+import pytest
+
+from focalsv_amd import bam as B
+from tests import bam_writer as W
+
+
+def make_records(seed, n=400, ref_lens=(200000, 150000, 90000), long_names=False):
+    rng = random.Random(seed)
+    recs = []
+    for ri, L in enumerate(ref_lens):
+        pos = sorted(rng.randrange(0, L - 30000) for _ in range(n))
+        for j, p in enumerate(pos):
+            ln = rng.randrange(200, 6000)
+            seq = "".join(rng.choice("ACGTN" if j % 17 == 0 else "ACGT") for _ in range(ln))
+            cigar, left = [], ln
+            if rng.random() < 0.3:
+                c = rng.randrange(1, 50)
+                cigar.append((4 if rng.random() < 0.7 else 5, c))
+                left -= c if cigar[-1][0] == 4 else 0
+            while left > 0:
+                m = min(left, rng.randrange(1, 900))
+                cigar.append((0, m))
+                left -= m
+                if left > 0 and rng.random() < 0.6:
+                    if rng.random() < 0.5:
+                        cigar.append((2, rng.choice([1, 2, 29, 30, 31, 120, 2500])))
+                    else:
+                        i = min(left, rng.choice([1, 3, 29, 30, 45, 400]))
+                        cigar.append((1, i))
+                        left -= i
+            if cigar[-1][0] == 1:
+                cigar.append((0, 1))
+                seq += "A"
+            qn = ("read/%d/%d/ccs" % (ri, j)) * (8 if long_names and j % 5 == 0 else 1)
+            recs.append({"ref": ri, "pos": p, "mapq": rng.choice([0, 20, 49, 50, 60]), "flag": rng.choice([0, 16, 2048, 2064, 256]),
+                         "qname": qn[:250], "cigar": cigar, "seq": seq})
+    return recs
+
+
+def expect(recs, ri, beg=0, end=None):
+    out = []
+    for r in recs:
+        e = r["pos"] + W._ref_len(r["cigar"])
+        if r["ref"] == ri and (end is None or r["pos"] < end) and e > beg:
+            out.append(r)
+    return out
+
+
+@pytest.mark.parametrize("index", [True, False])
+@pytest.mark.parametrize("block", [0xff00, 700])
+def test_fetch_round_trip(tmp_path, index, block):
+    refs = [("chr1", 200000), ("chr2", 150000), ("chrX", 90000)]
+    recs = make_records(3, n=120 if block == 700 else 400, long_names=True)
+    path = W.write_bam(str(tmp_path / "t.bam"), refs, recs, block=block, index=index)
+    with B.BamFile(path) as bam:
+        assert bam.references == ["chr1", "chr2", "chrX"]
+        assert bam.has_index == index
+        for ri, (name, _) in enumerate(refs):
+            got = bam.fetch(name, want_seq=True)
+            exp = expect(recs, ri)
+            assert len(got) == len(exp)
+            assert got.names == [r["qname"] for r in exp]
+            for k, r in enumerate(exp):
+                s = got.segment(k)
+                assert (s.pos, s.reference_end, s.mapq, s.is_reverse, s.cigar) == \
+                       (r["pos"], r["pos"] + W._ref_len(r["cigar"]), r["mapq"], bool(r["flag"] & 16), r["cigar"])
+                assert int(got.flag[k]) == r["flag"] and int(got.l_seq[k]) == len(r["seq"])
+            for k in range(0, len(exp), 7):
+                assert got.sequence(k) == exp[k]["seq"].replace("N", "A")
+        with pytest.raises(KeyError):
+            bam.fetch("chr9")
+
+
+def test_region_fetch_matches_samtools_view_semantics(tmp_path):
+    refs = [("chr1", 200000), ("chr2", 150000), ("chrX", 90000)]
+    recs = make_records(11)
+    for index in (True, False):
+        path = W.write_bam(str(tmp_path / ("r%d.bam" % index)), refs, recs, index=index)
+        with B.BamFile(path) as bam:
+            for ri, beg, end in ((0, 50000, 64000), (1, 0, 1000), (1, 100000, 150000), (2, 16384, 16385), (2, 89000, 90000)):
+                got = bam.fetch(refs[ri][0], beg, end)
+                exp = expect(recs, ri, beg, end)
+                assert got.names == [r["qname"] for r in exp], (index, ri, beg, end)
+                assert list(got.pos) == [r["pos"] for r in exp]
+
+
+def test_empty_reference_and_unmapped(tmp_path):
+    refs = [("chr1", 50000), ("chr2", 50000), ("chr3", 50000)]
+    recs = [r for r in make_records(5, n=40, ref_lens=(50000, 50000, 50000)) if r["ref"] != 1]
+    recs.append({"ref": 2, "pos": 49990, "mapq": 0, "flag": 4, "qname": "placed_unmapped", "cigar": [], "seq": "ACGT"})
+    recs.append({"ref": -1, "pos": -1, "mapq": 0, "flag": 4, "qname": "unmapped", "cigar": [], "seq": "ACGT"})
+    for index in (True, False):
+        path = W.write_bam(str(tmp_path / ("e%d.bam" % index)), refs, recs, index=index)
+        with B.BamFile(path) as bam:
+            assert len(bam.fetch("chr2")) == 0
+            assert bam.fetch("chr3").names == [r["qname"] for r in recs if r["ref"] == 2 and not r["flag"] & 4]
+
+
+def test_bad_files(tmp_path):
+    from focalsv_amd._lib import FsvError
+    p = tmp_path / "x.bam"
+    p.write_bytes(b"not a bam at all, just text" * 10)
+    with pytest.raises(FsvError):
+        B.BamFile(str(p))
+    with pytest.raises(FsvError):
+        B.BamFile(str(tmp_path / "missing.bam"))
+    refs = [("chr1", 200000)]
+    good = W.write_bam(str(tmp_path / "g.bam"), refs, make_records(1, n=50, ref_lens=(200000,)), index=False)
+    raw = open(good, "rb").read()
+    t = tmp_path / "trunc.bam"
+    t.write_bytes(raw[: len(raw) // 2])
+    with B.BamFile(str(t)) as bam, pytest.raises(FsvError):
+        bam.fetch("chr1")
+
+
+# ---- output_fas: phase blocks -> read sets (reference logic restated independently here, then compared) -------------------
+def _expected_output_fa(records):
+    """a plain re-derivation of what output_fas.py:28-85 writes, from the record dicts the test BAM was made of"""
+    phase, unph = {}, []
+    for r in records:
+        t = {k: v for k, _, v in r.get("tags", ())}
+        e = r["pos"] + W._ref_len(r["cigar"])
+        item = (r["qname"], r["seq"], r["pos"], e)
+        if "PS" in t and "HP" in t:
+            phase.setdefault("%d_%d" % (t["PS"], t["HP"]), []).append(item)
+        else:
+            unph.append(item)
+    st, en = {}, {}
+    for k, v in phase.items():
+        pb = int(k.split("_")[0])
+        st[pb] = min(st.get(pb, 1e18), min(x[2] for x in v))
+        en[pb] = max(en.get(pb, -1e18), max(x[3] for x in v))
+    for it in unph:
+        if len(phase) == 2:
+            for k in phase:
+                phase[k].append(it)
+        else:
+            best, bpb = -1e18, None
+            for pb in en:
+                ov = min(it[3], en[pb]) - max(it[2], st[pb])
+                if ov > best:
+                    best, bpb = ov, pb
+            if bpb is not None:
+                phase.setdefault("%d_1" % bpb, []).append(it)
+                phase.setdefault("%d_2" % bpb, []).append(it)
+    files = {}
+    for k, v in phase.items():
+        seen, txt = set(), ""
+        for name, seq, _, _ in v:
+            if name not in seen:
+                seen.add(name)
+                txt += ">%s\n%s\n" % (name, seq)
+        files["PS%s_hp%s.fa" % tuple(k.split("_"))] = txt
+    if not phase:
+        seen, txt = set(), ""
+        for name, seq, _, _ in unph:
+            if name not in seen:
+                seen.add(name)
+                txt += ">%s\n%s\n" % (name, seq)
+        files["unphased.fa"] = txt
+    return files
+
+
+def _phased_records(seed, blocks, n=60, untagged=0.2, L=60000):
+    rng = random.Random(seed)
+    recs = []
+    for j, p in enumerate(sorted(rng.randrange(0, L - 8000) for _ in range(n))):
+        ln = rng.randrange(500, 3000)
+        seq = "".join(rng.choice("ACGT") for _ in range(ln))
+        tags = [("NM", "C", 3), ("RG", "Z", "grp"), ("ml", "B", ("C", [1, 2, 3]))]
+        if blocks and rng.random() > untagged:
+            ps = rng.choice(blocks)
+            tags += [("PS", "i" if ps > 60000 else "S", ps), ("HP", "C", rng.choice([1, 2]))]
+        tags.append(("zz", "f", 1.5))
+        recs.append({"ref": 0, "pos": p, "mapq": 60, "flag": rng.choice([0, 16]), "qname": "m%d" % (j // 2 if j % 9 == 0 else j),
+                     "cigar": [(0, ln)], "seq": seq, "tags": tags})
+    return recs
+
+
+@pytest.mark.parametrize("blocks", [[1001], [1001, 30001], [], [70001, 5, 123456]])
+def test_output_fa_matches_reference_grouping(tmp_path, blocks):
+    import os
+    from focalsv_amd import output_fas
+    recs = _phased_records(len(blocks) + 7, blocks)
+    if len(blocks) == 1:   # one block with a single haplotype present: the unphased reads create the other
+        for r in recs:
+            r["tags"] = [(k, ty, (1 if k == "HP" else v)) for k, ty, v in r["tags"]]
+    fd = tmp_path / "Region_chr1_S0_E60000"
+    fd.mkdir()
+    W.write_bam(str(fd / "region_phased.bam"), [("chr1", 60000)], recs, index=False)
+    written = output_fas.output_fa(str(fd))
+    exp = _expected_output_fa(recs)
+    assert set(written) == set(exp)
+    for fn, txt in exp.items():
+        assert open(os.path.join(fd, fn)).read() == txt, fn
+    # falls back to region.bam, like the reference
+    fd2 = tmp_path / "Region_chr1_S1_E2"
+    fd2.mkdir()
+    W.write_bam(str(fd2 / "region.bam"), [("chr1", 60000)], recs[:10], index=True)
+    assert set(output_fas.output_fa(str(fd2))) == set(_expected_output_fa(recs[:10]))
+
+
+def test_pack_record_sets_equals_pack_reads(tmp_path):
+    """the word gather out of the BAM decode gives the store fsv_pack_reads builds from the same reads' text"""
+    import numpy as np
+    from focalsv_amd import output_fas, readsets
+    recs = _phased_records(21, [1001], n=80)
+    path = W.write_bam(str(tmp_path / "p.bam"), [("chr1", 60000)], recs, index=False)
+    with B.BamFile(path) as f:
+        got = f.fetch(until_eof=True, want_seq=3)
+    files = output_fas.read_set_files(got)
+    sets = [files[k] for k in sorted(files)]
+    pk = output_fas.pack_record_sets(got, sets)
+    ref = readsets.pack_sets([[got.seq_text(r).encode() for r in s] for s in sets])
+    assert np.array_equal(pk.word_off, ref.word_off) and np.array_equal(pk.read_len, ref.read_len) and np.array_equal(pk.set_start, ref.set_start)
+    n = int(ref.word_off[-1])
+    assert np.array_equal(pk.words[:n], ref.words[:n]) and len(pk.words) >= n + 4
+
+
+def _golden_bams(tmp_path, golden_dir):
+    import json
+    import os
+    cases = json.load(open(os.path.join(golden_dir, "dippav_reads_sig.json")))["cases"]
+    for k, c in enumerate(cases):
+        recs = [{"ref": 1, "pos": r["pos"], "mapq": r["mapq"], "flag": 16 if r["is_reverse"] else 0, "qname": r["qname"],
+                 "cigar": [tuple(x) for x in r["cigar"]], "seq": ""} for r in c["records"]]
+        srt = all(recs[i]["pos"] <= recs[i + 1]["pos"] for i in range(len(recs) - 1))
+        path = W.write_bam(str(tmp_path / ("g%d.bam" % k)), [("chr20", 1000), ("chr21", 50000000)], recs, index=srt and k % 2 == 0)
+        yield path, c
+
+
+def test_reads_signature_file_from_bam(tmp_path, golden_dir):
+    """the reference's chr21_reads_sig.txt lines out of a BAM of the golden records: native reader + the host-side signature walk"""
+    from focalsv_amd.dippav import reads_signature as RS
+    n = 0
+    for path, c in _golden_bams(tmp_path, golden_dir):
+        recs = RS.records_from_bam(path, "chr21")
+        assert len(recs) == len(c["records"])
+        assert all(a.reference_end == b["reference_end"] for a, b in zip(recs, c["records"]))
+        sigs = RS.reads_signatures(recs, 50)
+        assert ['\t'.join(str(x) for x in s) for s in sigs] == c["reads_sig_lines"]
+        assert RS.records_from_bam(path, "chr20") == [] and RS.records_from_bam(path, "chr5") == []
+        n += len(sigs)
+    assert n > 1000
+
+
+@pytest.mark.gpu
+def test_gpu_reads_signatures_from_bam(tmp_path, golden_dir):
+    """same lines with the CIGAR scan on the GPU (fsv_read_signatures), through the C ABI"""
+    from focalsv_amd import _lib
+    n = 0
+    with _lib.Context(0) as ctx:
+        for path, c in _golden_bams(tmp_path, golden_dir):
+            sigs = B.reads_signatures(ctx, path, "chr21", 50)
+            assert ['\t'.join(str(x) for x in s) for s in sigs] == c["reads_sig_lines"]
+            n += len(sigs)
+            assert B.reads_signatures(ctx, path, "chr20", 50) == []
+    assert n > 1000
+
+
+@pytest.mark.gpu
+def test_gpu_cigar_signatures_random(tmp_path):
+    """random CIGARs (hard/soft clips, sub-threshold and threshold-length events, mapq on both sides of the cut)"""
+    from focalsv_amd import _lib
+    from focalsv_amd.dippav import reads_signature as RS
+    recs = make_records(77, n=600)
+    path = W.write_bam(str(tmp_path / "r.bam"), [("chr1", 200000), ("chr2", 150000), ("chrX", 90000)], recs)
+    with _lib.Context(0) as ctx, B.BamFile(path) as bam:
+        for chrom in ("chr1", "chr2", "chrX"):
+            got = bam.fetch(chrom)
+            dels, inss = B.cigar_signatures(ctx, got, 50, 30)
+            ed, ei = [], []
+            for r in range(len(got)):
+                s = got.segment(r)
+                if s.mapq >= 50:
+                    d, i = RS.extract_sig_from_cigar(s, 30)
+                    ed += d
+                    ei += i
+            assert dels == ed and inss == ei and len(ed) > 50 and len(ei) > 50

@@ -11,6 +11,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def write_reads_bam(path, rs, total):
+    """the read BAM step 4 reads its read-level signatures from: every synthetic read with its true alignment"""
+    from tests import bam_writer as W
+    recs = []
+    for r in rs:
+        for h in (0, 1):
+            for j, (pos, ops, rev) in enumerate(r.read_aln[h]):
+                recs.append({"ref": 0, "pos": r.start + pos, "mapq": 60, "flag": 16 if rev else 0, "qname": "r%d_h%d_%d" % (r.index, h + 1, j),
+                             "cigar": ops, "seq": ""})
+    recs.sort(key=lambda x: x["pos"])
+    return W.write_bam(path, [("chr21", total)], recs)
+
+
 def test_region_directories_to_vcf(tmp_path):
     out = str(tmp_path)
     rs = [synth.make_region(i, start=10000 + i * 80000) for i in (1, 6)]
@@ -25,19 +38,22 @@ def test_region_directories_to_vcf(tmp_path):
     with open(ref_fa, "w") as f:
         f.write(">chr21\n" + fasta.fold("".join(seq), 60) + "\n")
     env = dict(os.environ, PYTHONPATH=ROOT)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env)
+    bam = write_reads_bam(os.path.join(out, "reads.bam"), rs, total)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", bam, "-chr", "21", "-r", ref_fa, "-o", out], env=env)
     for r in rs:
         d = os.path.join(out, "regions", "Region_chr21_S%d_E%d" % (r.start, r.start + 50000))
         hp1 = list(fasta.read_fasta(os.path.join(d, "HP1.fa")))
         assert len(hp1) == 1 and len(hp1[0][1]) == len(r.haps[0])
         assert os.path.exists(os.path.join(d, "PS1_hp1.asm.p_ctg.gfa.fa")) and os.path.exists(os.path.join(out, "log", "3_ASSEMBLY.log"))
-    vcf = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out],
+    vcf = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", bam, "-chr", "21", "-r", ref_fa, "-o", out],
                                   env=env).decode().strip().splitlines()[-1]
     assert vcf.endswith("final_vcf/dippav_variant_no_redundancy.vcf")
     body = [l for l in open(vcf) if l[0] != '#']
     calls = pipeline.parse_calls(body)
-    # without read records the FP filter keeps only calls longer than 250 bp (FP_filter_v1.py:56-90)
-    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth if t.length > 250]
+    # the read BAM's CIGARs support every planted SV, so the FP filter (FP_filter_v1.py:56-90) keeps them all
+    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth]
+    sig_lines = open(os.path.join(out, "SV", "chr21", "reads_signature", "chr21_reads_sig.txt")).read().splitlines()
+    assert len(sig_lines) > 20 and all(l.split("\t")[1] in ("DEL", "INS") for l in sig_lines)
     tp, fp, fn, gt = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.0)
     assert (tp, fp, fn) == (len(truth), 0, 0) and len(truth) >= 1
     raw = [l for l in open(os.path.join(out, "SV", "chr21", "dippav_raw_variant.vcf")) if l[0] != '#']
@@ -64,11 +80,12 @@ def test_unphased_region_goes_to_both_haplotypes(tmp_path):
     with open(ref_fa, "w") as f:
         f.write(">chr21\n" + fasta.fold("".join(seq), 60) + "\n")
     env = dict(os.environ, PYTHONPATH=ROOT)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env)
+    bam = write_reads_bam(os.path.join(out, "reads.bam"), [r], len(seq))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", bam, "-chr", "21", "-r", ref_fa, "-o", out], env=env)
     hp1 = list(fasta.read_fasta(os.path.join(d, "HP1.fa")))
     hp2 = list(fasta.read_fasta(os.path.join(d, "HP2.fa")))
     assert len(hp1) == 1 and [s for _, s in hp1] == [s for _, s in hp2] and len(hp1[0][1]) == len(r.haps[0])
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env,
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", bam, "-chr", "21", "-r", ref_fa, "-o", out], env=env,
                           stdout=subprocess.DEVNULL)
     raw = [l for l in open(os.path.join(out, "SV", "chr21", "dippav_raw_variant.vcf")) if l[0] != '#']
     calls = pipeline.parse_calls(raw)
@@ -94,11 +111,12 @@ def test_heterozygous_unphased_region(tmp_path):
     with open(ref_fa, "w") as f:
         f.write(">chr21\n" + fasta.fold("".join(seq), 60) + "\n")
     env = dict(os.environ, PYTHONPATH=ROOT)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env)
+    bam = write_reads_bam(os.path.join(out, "reads.bam"), [r], len(seq))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", bam, "-chr", "21", "-r", ref_fa, "-o", out], env=env)
     hp1 = [s for _, s in fasta.read_fasta(os.path.join(d, "HP1.fa"))]
     hp2 = [s for _, s in fasta.read_fasta(os.path.join(d, "HP2.fa"))]
     assert len(hp1) == 1 and len(hp2) == 1 and sorted(map(len, hp1 + hp2)) == sorted(map(len, r.haps))
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", "none.bam", "-chr", "21", "-r", ref_fa, "-o", out], env=env,
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", bam, "-chr", "21", "-r", ref_fa, "-o", out], env=env,
                           stdout=subprocess.DEVNULL)
     raw = [l for l in open(os.path.join(out, "SV", "chr21", "dippav_raw_variant.vcf")) if l[0] != '#']
     truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for t in r.truth]

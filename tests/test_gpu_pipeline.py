@@ -119,3 +119,34 @@ def test_two_lanes_give_the_same_calls():
     key = lambda ls: sorted((c["chrom"], c["pos"], c["type"], c["svlen"], c["gt"]) for c in pipeline.parse_calls(ls))   # contigs are numbered per call
     assert key(lines) == key(one.lines) and len(lines) > 10
     assert sorted(l.split('\t')[4] for l in lines) == sorted(l.split('\t')[4] for l in one.lines)                     # ALT sequences
+
+
+def test_bam_regions_straight_into_the_store(ctx, tmp_path):
+    """N2: a haplotagged BAM -> crop + PS/HP grouping + 2-bit gather (pipeline.upload_bam_regions) gives the calls of the
+    in-memory path fed with the same reads (BAM stores reverse-strand reads reverse-complemented; the assembler does not care)"""
+    from tests import bam_writer as W
+    rs = _regions([1, 4, 7])
+    recs = []
+    for r in rs:
+        for h in (0, 1):
+            for j, (pos, ops, rev) in enumerate(r.read_aln[h]):
+                seq = r.reads[h][j]
+                recs.append({"ref": 0, "pos": r.start + pos, "mapq": 60, "flag": 16 if rev else 0, "qname": "r%d_h%d_%d" % (r.index, h + 1, j),
+                             "cigar": ops, "seq": (synth.revcomp(seq) if rev else seq).decode(),
+                             "tags": [("PS", "I", r.start + 1), ("HP", "C", h + 1)]})
+    recs.sort(key=lambda x: x["pos"])
+    path = W.write_bam(str(tmp_path / "wgs.bam"), [("chr21", 46_000_000)], recs)
+    batch = pipeline.upload_bam_regions(ctx, path, [(r.chrom, r.start + 1, r.start + len(r.ref)) for r in rs], [(r.start, r.ref) for r in rs])
+    try:
+        assert batch.set_kind == [1, 2] * 3 and batch.set_region == [0, 0, 1, 1, 2, 2]
+        assert [int(x) for x in np.diff(batch.packed.set_start)] == [len(r.reads[h]) for r in rs for h in (0, 1)]
+        res = pipeline.run_hot_path(ctx, batch)
+    finally:
+        batch.free(ctx)
+    mem = pipeline.upload_regions(ctx, [pipeline.region_from_synth(r) for r in rs])
+    try:
+        exp = pipeline.run_hot_path(ctx, mem)
+    finally:
+        mem.free(ctx)
+    assert pipeline.parse_calls(res.lines) == pipeline.parse_calls(exp.lines) and len(res.lines) >= 6
+    assert sorted(map(len, res.contig_batch)) == sorted(map(len, exp.contig_batch))
