@@ -122,8 +122,8 @@ def main():
     lanes = max(1, min(args.lanes, n))
     ctxs = [_lib.Context(local) for _ in range(lanes)]
     by_steps = args.lane_mode == "steps" and lanes > 1
-    # reads resident in HBM before timing starts ("steps": every lane holds the whole batch, its own copy of the store)
-    batches = [pipeline.upload_regions(c, inputs if by_steps else inputs[k::lanes]) for k, c in enumerate(ctxs)]
+    # reads resident in HBM before timing starts ("steps": one copy of the whole batch, read by every lane)
+    batches = [pipeline.upload_regions(ctxs[0], inputs)] if by_steps else [pipeline.upload_regions(c, inputs[k::lanes]) for k, c in enumerate(ctxs)]
 
     # the inputs (regions, read records, packed store) live for the whole run: keep the cyclic collector from re-scanning them
     # on every generation-2 pass (a 10 ms pause per step otherwise)
@@ -138,50 +138,15 @@ def main():
         return results, lines
 
     def run_steps(count, static=False):
-        """`count` whole-batch steps dealt to the lanes as they come free (one batch in flight per lane); the VCF gather of
-        step s is done here, on the main thread, in step order -> (per-step results, the last step's lines).  static: step s goes
-        to lane s % lanes (warm-up: every lane gets its share and allocates its workspace there)"""
-        import itertools
-        import threading
-        results, done, errs = [None] * count, [threading.Event() for _ in range(count)], []
-        nxt, lock = itertools.count(), threading.Lock()
+        """`count` whole-batch steps over the lanes (pipeline.run_stream: one batch in flight per lane); the VCF gather of step s
+        runs on this thread in step order -> (per-step results, the last step's lines)"""
+        last = [[]]
 
-        def work(k):
-            mine = iter(range(k, count, lanes))
-            while True:
-                if static:
-                    s_ = next(mine, count)
-                else:
-                    with lock:
-                        s_ = next(nxt)
-                if s_ >= count:
-                    return
-                try:
-                    results[s_] = pipeline.run_hot_path(ctxs[k], batches[k])
-                except BaseException as e:   # noqa: B902 -- handed to the main thread
-                    errs.append(e)
-                done[s_].set()
-                if errs:
-                    return
+        def gathered(i, r):
+            last[0] = pipeline.gather_vcf(list(r.lines)) if world > 1 else list(r.lines)
 
-        th = [threading.Thread(target=work, args=(k,), name="fsv-lane-%d" % k) for k in range(lanes)]
-        for t_ in th:
-            t_.start()
-        lines = []
-        for s_ in range(count):
-            while not done[s_].wait(0.05):
-                if errs:
-                    break
-            if errs:
-                break
-            lines = list(results[s_].lines)
-            if world > 1:
-                lines = pipeline.gather_vcf(lines)
-        for t_ in th:
-            t_.join()
-        if errs:
-            raise errs[0]
-        return results, lines
+        results = pipeline.run_stream(ctxs, [batches[0]] * count, on_result=gathered, static=static)
+        return results, last[0]
 
     def fence():
         for c in ctxs:
@@ -302,8 +267,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 0)
         print(json.dumps(out))
     fence()
-    for c, b_ in zip(ctxs, batches):
-        b_.free(c)
+    for b_ in batches:
+        b_.free(ctxs[0])
+    for c in ctxs:
         c.close()
     if world > 1:
         dist.destroy_process_group()

@@ -256,6 +256,54 @@ def run_hot_path_lanes(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBat
     return out, sorted((l for o in out for l in o.lines), key=_vcf_key)
 
 
+def run_stream(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBatch], on_result=None, static: bool = False, **kw) -> List[CallResult]:
+    """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
+    next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
+    host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
+    MI355X).  The read store is only read, so several entries of `batches` may be the same DeviceBatch.  on_result(i, result) is
+    called on the calling thread in batch order (the place for an ordered collective such as gather_vcf); static deals batch i to
+    lane i % len(ctxs).  -> results in batch order"""
+    import itertools
+    count, lanes = len(batches), len(ctxs)
+    results: List[Optional[CallResult]] = [None] * count
+    done = [threading.Event() for _ in range(count)]
+    errs: List[BaseException] = []
+    nxt, lock = itertools.count(), threading.Lock()
+
+    def work(k):
+        mine = iter(range(k, count, lanes))
+        while not errs:
+            if static:
+                i = next(mine, count)
+            else:
+                with lock:
+                    i = next(nxt)
+            if i >= count:
+                return
+            try:
+                results[i] = run_hot_path(ctxs[k], batches[i], **kw)
+            except BaseException as e:
+                errs.append(e)
+            done[i].set()
+
+    th = [threading.Thread(target=work, args=(k,), name="fsv-lane-%d" % k) for k in range(min(lanes, count))]
+    for t in th:
+        t.start()
+    for i in range(count):
+        while not done[i].wait(0.05):
+            if errs:
+                break
+        if errs:
+            break
+        if on_result is not None:
+            on_result(i, results[i])
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    return results
+
+
 # ------------------------------------------------------------------------------------------------ multi-GPU
 def shard_regions(work: Sequence[int], world_size: int) -> List[List[int]]:
     """static region -> rank assignment: largest first onto the least loaded rank.  Deterministic."""

@@ -150,3 +150,26 @@ def test_bam_regions_straight_into_the_store(ctx, tmp_path):
         mem.free(ctx)
     assert pipeline.parse_calls(res.lines) == pipeline.parse_calls(exp.lines) and len(res.lines) >= 6
     assert sorted(map(len, res.contig_batch)) == sorted(map(len, exp.contig_batch))
+
+
+def test_run_stream_equals_sequential(ctx):
+    """batches dealt to three lanes (whole batches in flight, a shared read store) give what one lane gives one after the other,
+    in batch order, and on_result sees them in that order"""
+    ra = [pipeline.region_from_synth(r) for r in _regions([2, 5, 9])]
+    rb = [pipeline.region_from_synth(r) for r in _regions([3, 6])]
+    ba, bb = pipeline.upload_regions(ctx, ra), pipeline.upload_regions(ctx, rb)
+    lanes = [ctx, _lib.Context(0), _lib.Context(0)]
+    try:
+        seq = [pipeline.run_hot_path(ctx, b) for b in (ba, bb)]
+        order = []
+        got = pipeline.run_stream(lanes, [ba, bb, ba, ba, bb], on_result=lambda i, r: order.append(i))
+        assert order == [0, 1, 2, 3, 4]
+        for g, e in zip(got, [seq[0], seq[1], seq[0], seq[0], seq[1]]):
+            assert g.lines == e.lines and g.raw_lines == e.raw_lines and list(g.contig_batch) == list(e.contig_batch)
+        st = pipeline.run_stream(lanes[:2], [bb, ba, bb], static=True)
+        assert [r.lines for r in st] == [seq[1].lines, seq[0].lines, seq[1].lines]
+        assert pipeline.run_stream(lanes, []) == []
+    finally:
+        for c in lanes[1:]:
+            c.close()
+        ba.free(ctx); bb.free(ctx)
