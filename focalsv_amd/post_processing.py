@@ -1,0 +1,378 @@
+"""Read-support filter and genotype correction: the HiFi branch of focalsv/5_post_processing/FocalSV_Filter_GT_Correct.py:163-214
+(SURVEY.md 8f, row N1), given the read-level signature files DEL.sigs / INS.sigs (`--sigdir`; producing them is the reference's
+Reads_Based_Scan, a separate read-based caller that is not restated here).
+
+  step 1  signature_support   calculate_signature_support.py     signature bases within 1 kb of every call -> <vcf>_cutesv_sig_support_mins30_fl1000.csv
+  step 2  filter_by_support   filter_vcf_by_sig_cov_insdel.py    calls whose support per SV base is far from the median are dropped (filter_para.csv)
+  step 3  correct_gt('DEL')   correct_gt_del_real_data.py        supporting reads / reads spanning the breakpoints against thresholds -> new GT
+  step 4  correct_gt('INS')   correct_gt_ins_real_data.py
+  step 5  final_vcf           `cat header .newgt.DEL .newgt.INS | vcf-sort`
+
+Every intermediate file has the reference's name and, written through pandas as there, its text.  Reads spanning a breakpoint are
+counted from the BAM with the library's own reader (focalsv_amd.bam; the reference uses pysam), once per chromosome instead of one
+fetch per call.  The scans keep the reference's bookkeeping (resume indices, index spaces), including where it is only right for
+position-sorted input."""
+import math
+import os
+from collections import defaultdict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+
+from . import bam as B
+
+# 5_post_processing/filter_para.csv: bounds on (support per SV base) / median, by assembler family and data type
+FILTER_PARA = {
+    ('other', 'hifi'): (0.048, 2.61, 0.097, 2.59), ('other', 'clr'): (0.0327, 2.476, 0.102, 2.638), ('other', 'ont'): (0.191, 2.44, 0.123, 2.67),
+    ('volcano', 'hifi'): (0.097, 2.754, 0.2, 2.605), ('volcano', 'clr'): (0.075, 2.383, 0.186, 3.018), ('volcano', 'ont'): (0.206, 2.79, 0.242, 2.77),
+}
+NAN = float('nan')
+# 5_post_processing/para/GT_correction_para_<dtype>_<vtype>.txt: t_large_11, t_small_11, t_large_01, t_small_01
+GT_PARA = {
+    ('Hifi', 'DEL'): (0.6, 0.69, 0.71, 0.91), ('Hifi', 'INS'): (NAN, 0.59, 0.63, 0.79),
+    ('CLR', 'DEL'): (0.55, 0.59, 0.65, 0.75), ('CLR', 'INS'): (NAN, NAN, 0.64, 0.75),
+    ('ONT', 'DEL'): (0.61, 0.61, 0.68, 0.79), ('ONT', 'INS'): (NAN, NAN, 0.67, 0.72),
+}
+
+
+# ------------------------------------------------------------------------------------------------ step 1
+def _load_calls(vcffile, svtype, min_size):
+    """calculate_signature_support.py:29-53 -> {chrom: [(start, end, svlen, svid, gt, svtype)]}"""
+    dc = defaultdict(list)
+    with open(vcffile) as f:
+        for line in f:
+            if line[0] != '#' and 'SVTYPE=%s' % svtype in line:
+                data = line.split()
+                svlen = int(data[7].split('SVLEN=')[1].split(';')[0])
+                if abs(svlen) >= min_size:
+                    start = int(data[1])
+                    end = start + 1 if svtype == 'INS' else start - svlen
+                    dc[data[0]].append((start, end, svlen, data[2], data[-1].split(':')[0], svtype))
+    return dc
+
+
+def _load_sigs(path, svtype):
+    """calculate_signature_support.py:55-79 -> {chrom: [(start, end, svlen)]} (DEL lengths negated)"""
+    dc = defaultdict(list)
+    with open(path) as f:
+        for line in f:
+            data = line.split()
+            start, svlen = int(data[2]), int(data[3])
+            if svtype == 'INS':
+                end = start + 1
+            else:
+                svlen = -svlen
+                end = start - svlen
+            dc[data[1]].append((start, end, svlen))
+    return dc
+
+
+def _ins_cov(calls, sigs, flanking):
+    """inserted bases of the signatures within `flanking` of each call position (calculate_signature_support.py:81-126)"""
+    call_pos = sorted(set(c[0] for c in calls))
+    if not sigs:
+        return {p: 0.0 for p in call_pos}   # the reference stops here (np.vectorize on an empty list)
+    pos = np.array([s[0] for s in sigs], dtype=np.int64)
+    upos, inv = np.unique(pos, return_inverse=True)
+    w = np.bincount(inv, weights=[s[2] for s in sigs])
+    pre = np.concatenate([[0.0], np.cumsum(w)])   # integer-valued doubles: any order of summation gives the same value
+    out = {}
+    for p in call_pos:
+        a, b = np.searchsorted(upos, p - flanking, 'left'), np.searchsorted(upos, p + flanking, 'right')
+        out[p] = float(pre[b] - pre[a])
+    return out
+
+
+def _sweep(intervals, points_sorted, point_items, sink):
+    """the reference's resumable scan: for interval j = (lb, rb), every point with lb <= point <= rb hands its items to sink(j, items);
+    the next interval resumes at the first point the previous one matched (calculate_signature_support.py:166-180)"""
+    start_i = 0
+    for j, (lb, rb) in enumerate(intervals):
+        cnt, real_i = 0, 0
+        for i in range(start_i, len(points_sorted)):
+            p = points_sorted[i]
+            if p > rb:
+                break
+            if p >= lb:
+                cnt += 1
+                if cnt == 1:
+                    real_i = i
+                sink(j, point_items[p])
+        if cnt:
+            start_i = real_i
+
+
+def _del_cov(calls, sigs, flanking):
+    """deleted bases (negative) of the signatures that touch the call widened by `flanking`: a signature end inside the widened call,
+    or a widened-call end inside the signature (calculate_signature_support.py:138-279).  Returns {(start, end): total}"""
+    sig_start, sig_end = defaultdict(list), defaultdict(list)
+    for i, (s, e, _) in enumerate(sigs):
+        sig_start[s].append(i)
+        sig_end[e].append(i)
+    bed_call = [(c[0] - flanking, c[1] + flanking) for c in calls]
+    order = np.argsort([b[0] for b in bed_call])          # the reference's sort_region: numpy's default argsort on the starts
+    bed_sorted = [bed_call[i] for i in order]
+    call_start, call_end = defaultdict(list), defaultdict(list)
+    for i, (s, e) in enumerate(bed_call):
+        call_start[s].append(i)
+        call_end[e].append(i)
+    hit = defaultdict(list)
+    _sweep(bed_sorted, sorted(sig_start), sig_start, lambda j, items: hit[j].extend(items))
+    _sweep(bed_sorted, sorted(sig_end), sig_end, lambda j, items: hit[j].extend(items))
+    bed_sig = [(s, e) for s, e, _ in sigs]
+
+    def to_calls(j, call_ids):
+        for cid in call_ids:            # indices of the calls as given, filed with the indices of the sorted list: the reference's
+            hit[cid].append(j)          # bookkeeping, the same thing for a position-sorted VCF
+
+    _sweep(bed_sig, sorted(call_start), call_start, to_calls)
+    _sweep(bed_sig, sorted(call_end), call_end, to_calls)
+    out = {}
+    for key in hit:
+        total = sum(sigs[i][2] for i in set(hit[key]))
+        lb, rb = bed_sorted[key]
+        out[(lb + flanking, rb - flanking)] = total
+    return out
+
+
+def signature_support(vcffile, sigdir, wdir, flanking=1000, min_size=30):
+    """step 1 -> path of <wdir>/<vcf basename>_cutesv_sig_support_mins30_fl1000.csv"""
+    sig_ins, sig_del = _load_sigs(os.path.join(sigdir, 'INS.sigs'), 'INS'), _load_sigs(os.path.join(sigdir, 'DEL.sigs'), 'DEL')
+    call_ins, call_del = _load_calls(vcffile, 'INS', min_size), _load_calls(vcffile, 'DEL', min_size)
+    rows = []
+    for chrom, calls in call_ins.items():
+        cov = _ins_cov(calls, sig_ins[chrom] if chrom in sig_ins else [], flanking)
+        for start, end, svlen, svid, gt, svtype in calls:
+            rows.append([start, end, svlen, svid, gt, svtype, cov.get(start, 0)])
+    for chrom, calls in call_del.items():
+        cov = _del_cov(calls, sig_del[chrom] if chrom in sig_del else [], flanking)
+        for start, end, svlen, svid, gt, svtype in calls:
+            rows.append([start, end, svlen, svid, gt, svtype, cov.get((start, end), 0)])
+    df = pd.DataFrame(rows, columns=['start', 'end', 'svlen', 'svid', 'gt', 'svtype', 'cov'])
+    df['rel_cov'] = df['cov'] / df['svlen']
+    out = os.path.join(wdir, os.path.basename(vcffile).split('.')[0] + '_cutesv_sig_support_mins%d_fl%d.csv' % (min_size, flanking))
+    df.to_csv(out, index=False)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ step 2
+def filter_by_support(vcffile, wdir, dtype='hifi', asm='volcano', vtype='DEL'):
+    """step 2 (filter_vcf_by_sig_cov_insdel.py): keep a call when its support per SV base lies within [lb, rb] x the median of its
+    type; vtype says which types are filtered (the driver passes DEL) -> path of <basename>_filter_<vtype>.vcf"""
+    assert vtype in ('INS', 'DEL', 'INSDEL')
+    lb_ins_r, rb_ins_r, lb_del_r, rb_del_r = FILTER_PARA[(asm, dtype)]
+    base = os.path.basename(vcffile).replace('.vcf', '')
+    df = pd.read_csv(os.path.join(wdir, base + '_cutesv_sig_support_mins30_fl1000.csv'))
+    df['re_cov'] = df['cov'] / df['svlen']
+    keep = set()
+    for svtype, lo_r, hi_r, skip in (('INS', lb_ins_r, rb_ins_r, 'DEL'), ('DEL', lb_del_r, rb_del_r, 'INS')):
+        d = df[df['svtype'] == svtype]
+        if d.shape[0]:
+            if vtype != skip:
+                med = np.quantile(d['re_cov'], 0.5)
+                d = d[(d['re_cov'] >= med * lo_r) & (d['re_cov'] <= med * hi_r)]
+            keep |= set(d['svid'].values)
+    out = os.path.join(wdir, "%s_filter_%s.vcf" % (base, vtype))
+    with open(out, 'w') as fw, open(vcffile) as f:
+        for line in f:
+            if line[0] == '#' or line.split()[2] in keep:
+                fw.write(line)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ steps 3, 4
+class SpanCounter:
+    """reads of one BAM that start before a and end after b (count_reads_span_region / check_full_cover_reads of the two
+    correct_gt scripts): per chromosome the records are fetched once and kept as sorted start / end arrays"""
+
+    def __init__(self, bamfile):
+        self._bam = B.BamFile(bamfile)
+        self._chrom: Dict[str, Optional[Tuple[np.ndarray, np.ndarray, int]]] = {}
+
+    def close(self):
+        self._bam.close()
+
+    def count(self, chrom, a, b):
+        if chrom not in self._chrom:
+            if chrom in self._bam.references:
+                r = self._bam.fetch(chrom)
+                pos, end = r.pos.astype(np.int64), r.ref_end.astype(np.int64)
+                self._chrom[chrom] = (pos, end, int((end - pos).max()) if len(pos) else 0)
+            else:
+                self._chrom[chrom] = None
+        arr = self._chrom[chrom]
+        if arr is None:
+            raise ValueError("invalid contig `%s`" % chrom)   # what pysam's fetch raises
+        pos, end, longest = arr
+        k = int(np.searchsorted(pos, a, 'left'))    # records are position-sorted: those starting before a ...
+        k0 = int(np.searchsorted(pos, b - longest, 'left'))   # ... and late enough for the longest record to reach past b
+        return int(np.count_nonzero(end[k0:k] > b))
+
+
+def _resumable_support(calls, sigs, count_of, min_size_sim, max_shift_ratio):
+    """supporting reads per call: signatures of the same chromosome within max(500, 2.3 x svlen) of the call whose length is within
+    a factor 0.6; the scan runs forward and backward from where the previous call first matched, the resume index itself is looked
+    at by both (match_varlist_siglist, correct_gt_del_real_data.py:94-140; extract_sig_support, correct_gt_ins_real_data.py:109-150).
+    calls: (chrom, pos, svlen); sigs: (chrom, pos, svlen) -> (support per call, resume index per call)"""
+    last, sup, resume = 0, [], []
+    n = len(sigs)
+    for chrom, pos, svlen in calls:
+        shift = max(svlen * max_shift_ratio, 500)
+        lo, hi = pos - shift, pos + shift
+        smin, smax = svlen * min_size_sim, svlen / min_size_sim
+        matched, total = [], 0
+        resume.append(last)
+        for i in range(last, n):
+            c, p, l = sigs[i]
+            if c == chrom:
+                if lo <= p <= hi:
+                    matched.append(i)
+                    if smin <= l <= smax:
+                        total += count_of[i]
+                elif p > hi:
+                    break
+        for i in range(min(last, n - 1), -1, -1):
+            c, p, l = sigs[i]
+            if c == chrom:
+                if lo <= p <= hi:
+                    matched.append(i)
+                    if smin <= l <= smax:
+                        total += count_of[i]
+                elif p < lo:
+                    break
+        if matched:
+            last = min(matched)
+        sup.append(total)
+    return sup, resume
+
+
+def _apply_thresholds(df, para):
+    """correct_gt_eval: the call's genotype and size class pick a threshold on supporting / spanning reads"""
+    t_large_11, t_small_11, t_large_01, t_small_01 = para
+    new_gt = df['call_gt'].values.copy()
+    large = df['svlen'] > 1000
+    for cond, t in ((large & (df['call_gt'] == '1/1'), t_large_11), (~large & (df['call_gt'] == '1/1'), t_small_11),
+                    (large & (df['call_gt'] == '0/1'), t_large_01), (~large & (df['call_gt'] == '0/1'), t_small_01)):
+        if not math.isnan(t):
+            new_gt[(cond & (df['n_ratio'] > t)).values] = '1/1'
+            new_gt[(cond & (df['n_ratio'] <= t)).values] = '0/1'
+    return new_gt
+
+
+def _write_new_gt(vcffile, outfile, vtype, new_gt_of):
+    with open(vcffile) as fin, open(outfile, 'w') as fout:
+        for line in fin:
+            if line[0] != '#' and 'SVTYPE=%s' % vtype in line:
+                data = line.split()
+                data[-1] = new_gt_of[data[2]]
+                fout.write('\t'.join(data) + '\n')
+
+
+def correct_gt(vcffile, output_path, bamfile, sigfile, dtype='Hifi', vtype='DEL', spans: Optional[SpanCounter] = None):
+    """steps 3 / 4 -> path of <vcffile>.newgt.<vtype>; also writes output_path (tsv), output_path + '.newgt' and, for INS,
+    sigfile + '.gte30auto', as the reference does"""
+    assert vtype in ('DEL', 'INS')
+    own = spans is None
+    spans = spans or SpanCounter(bamfile)
+    try:
+        lines = [l for l in open(vcffile) if l[0] != '#' and 'SVTYPE=%s' % vtype in l]
+        if vtype == 'DEL':
+            # calls: (gt, |svlen|, line); signatures grouped by (chrom, pos, svlen) in first-seen order, weight = number of reads
+            gts = [l.split()[-1].split(':')[0] for l in lines]
+            svlens = [abs(int(l.split('SVLEN=')[1].split(';')[0])) for l in lines]
+            chroms, poss, svids = [l.split()[0] for l in lines], [int(l.split()[1]) for l in lines], [l.split()[2] for l in lines]
+            groups: Dict[tuple, int] = {}
+            for line in open(sigfile):
+                _, chrom, pos, svlen, rname = line.split()
+                key = (chrom, int(pos), int(svlen))
+                groups[key] = groups.get(key, 0) + 1
+            sigs = list(groups)
+            sup, _ = _resumable_support(list(zip(chroms, poss, svlens)), sigs, [groups[s] for s in sigs], 0.6, 2.3)
+            depth = []
+            for chrom, pos, svlen in zip(chroms, poss, svlens):
+                if svlen <= 1000:
+                    depth.append(spans.count(chrom, pos, pos + svlen))
+                else:   # long deletions: the mean of the reads spanning 100 bp windows 150 bp outside either breakpoint
+                    l0, r0 = pos - 150, pos + svlen + 150
+                    depth.append((spans.count(chrom, l0, l0 + 100) + spans.count(chrom, r0, r0 + 100)) / 2)
+            sup_a, depth_a = np.array(sup), np.array(depth)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                ratio = sup_a / depth_a
+            df = pd.DataFrame({'svlen': svlens, 'svid': svids, 'call_gt': gts, 'n_support': sup_a, 'n_cov': depth_a, 'n_ratio': ratio})
+            df.to_csv(output_path, sep='\t', index=False)
+        else:
+            rows = []
+            for l in lines:
+                data = l.split()
+                rows.append([int(data[0][3:]), int(data[1]), int(l.split('SVLEN=')[1].split(';')[0]), data[-1].split(':')[0], data[2]])
+            counts: Dict[tuple, int] = {}
+            for line in open(sigfile):
+                _, chrom, pos, svlen, rname = line.split()[:5]
+                if int(svlen) >= 30:
+                    try:
+                        key = (int(chrom[3:]), int(pos), int(svlen))
+                    except ValueError:
+                        continue
+                    counts[key] = counts.get(key, 0) + 1
+            with open(sigfile + '.gte30auto', 'w') as f:
+                for (chrom, pos, svlen), c in counts.items():
+                    f.write('%d\t%d\t%d\t%d\n' % (chrom, pos, svlen, c))
+            sigs = list(counts)
+            sup, resume = _resumable_support([(r[0], r[1], r[2]) for r in rows], sigs, [counts[s] for s in sigs], 0.6, 2.3)
+            cov = [spans.count('chr' + str(r[0]), r[1] - 100, r[1] + 100) for r in rows]
+            df = pd.DataFrame(rows, columns=['chrom', 'pos', 'svlen', 'call_gt', 'svid'])
+            df['match_id'] = resume
+            df['n_support'] = sup
+            df['n_cov'] = cov
+            with np.errstate(divide='ignore', invalid='ignore'):
+                df['n_ratio'] = df['n_support'] / df['n_cov']
+            df.to_csv(output_path, index=False, sep='\t')
+        df = pd.read_csv(output_path, sep='\t')
+        df['new_gt'] = _apply_thresholds(df, GT_PARA[(dtype, vtype)])
+        df.to_csv(output_path + '.newgt', sep='\t', index=False)
+        out = vcffile + '.newgt.%s' % vtype
+        _write_new_gt(vcffile, out, vtype, dict(zip(df['svid'].values, df['new_gt'].values)))
+        return out
+    finally:
+        if own:
+            spans.close()
+
+
+# ------------------------------------------------------------------------------------------------ step 5 and the driver
+def final_vcf(filtered_vcf, parts, out_path):
+    """header of the filtered VCF + the corrected records in (chromosome, position) order: `cat header a b | vcf-sort`
+    (FocalSV_Filter_GT_Correct.py:205-212; vcf-sort orders the body with `sort -k1,1d -k2,2n`)"""
+    header = [l for l in open(filtered_vcf) if '#' in l]     # grep '#', as the reference
+    body = [l for p in parts for l in open(p)]
+    body.sort(key=lambda l: (l.split('\t', 2)[0], int(l.split('\t', 2)[1]), l))   # sort's last resort on ties: the whole line
+    with open(out_path, 'w') as f:
+        f.writelines(header)
+        f.writelines(body)
+    return out_path
+
+
+def filter_gt_correct(bam_file, out_dir, chr_num, sigdir, data_type='Hifi'):
+    """FocalSV_Filter_GT_Correct.py for HiFi data with pre-extracted read signatures: reads
+    <out_dir>/SV/chr<N>/final_vcf/dippav_variant_no_redundancy.vcf, works in <out_dir>/post_processing/, writes
+    <out_dir>/FocalSV_Final_SV.vcf"""
+    if data_type != 'Hifi':
+        raise NotImplementedError("the CLR / ONT branch needs Reads_Based_Scan's draft VCF (gt_impute), which is not built")
+    if not sigdir:
+        raise NotImplementedError("pass sigdir= with DEL.sigs / INS.sigs: extracting them is the reference's Reads_Based_Scan, not built here")
+    wdir = os.path.join(os.path.realpath(out_dir), "post_processing")
+    vcffile = os.path.realpath(os.path.join(out_dir, "SV", "chr%s" % chr_num, "final_vcf", "dippav_variant_no_redundancy.vcf"))
+    for p in (bam_file, vcffile):
+        if not os.path.isfile(p):
+            raise FileNotFoundError(p)
+    gtdir = os.path.join(wdir, "GT_Correction")
+    os.makedirs(gtdir, exist_ok=True)
+    signature_support(vcffile, sigdir, wdir)
+    filtered = filter_by_support(vcffile, wdir, data_type.lower(), 'volcano', 'DEL')
+    spans = SpanCounter(bam_file)
+    try:
+        d = correct_gt(filtered, os.path.join(gtdir, "bnd_del_real.tsv"), bam_file, os.path.join(sigdir, "DEL.sigs"), data_type, 'DEL', spans)
+        i = correct_gt(filtered, os.path.join(gtdir, "bnd_ins_real.tsv"), bam_file, os.path.join(sigdir, "INS.sigs"), data_type, 'INS', spans)
+    finally:
+        spans.close()
+    return final_vcf(filtered, [d, i], os.path.realpath(os.path.join(out_dir, "FocalSV_Final_SV.vcf")))
