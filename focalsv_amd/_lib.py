@@ -76,9 +76,9 @@ assert ALN_REC_DTYPE.itemsize == 40
 
 class BamRecords(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("pos", "ref_end", "flag", "mapq", "cigar_off", "n_cigar_op", "qname_off", "l_seq", "cigar", "qname",
-                                          "seq_word_off", "seq_words_buf", "seq_ascii", "seq_ascii_off", "ref_id", "ps", "hp")] + \
-               [(n, C.c_uint64) for n in ("rec_cap", "cigar_cap", "qname_cap", "seq_cap", "seq_ascii_cap", "n_rec", "n_cigar", "qname_bytes",
-                                          "seq_words", "seq_ascii_bytes")]
+                                          "seq_word_off", "seq_words_buf", "seq_ascii", "seq_ascii_off", "ref_id", "sa", "sa_off", "ps", "hp")] + \
+               [(n, C.c_uint64) for n in ("rec_cap", "cigar_cap", "qname_cap", "seq_cap", "seq_ascii_cap", "sa_cap", "n_rec", "n_cigar", "qname_bytes",
+                                          "seq_words", "seq_ascii_bytes", "sa_bytes")]
 
 
 READ_SIG_DTYPE = np.dtype([("rec", "<u4"), ("type", "<u4"), ("ref_pos", "<i4"), ("len", "<i4"), ("read_off", "<i4"), ("pad", "<u4")])

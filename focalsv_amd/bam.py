@@ -16,7 +16,9 @@ NO_TAG = -(1 << 31)
 class FetchedRecords:
     """records of one fetch as flat arrays (record r owns cigar[cigar_off[r] : cigar_off[r] + n_cigar_op[r]])"""
 
-    def __init__(self, chrom, n, n_cig, qbytes, seq_words, seq_bytes=None, ref_names=None):
+    def __init__(self, chrom, n, n_cig, qbytes, seq_words, seq_bytes=None, ref_names=None, sa_bytes=None):
+        self.sa_off = np.zeros(n if sa_bytes is not None else 0, np.uint64)
+        self.sa_buf = np.zeros(sa_bytes if sa_bytes else 0, np.uint8)
         self.chrom = chrom               # None for a whole-file fetch: the record's own reference (ref_id) names it
         self.ref_names = ref_names or []
         self.ref_id = np.full(n, -1, np.int32)
@@ -52,6 +54,10 @@ class FetchedRecords:
             r.seq_ascii = self.seq_ascii.ctypes.data if len(self.seq_ascii) else None
         r.rec_cap, r.cigar_cap, r.qname_cap, r.seq_cap = len(self.pos), len(self.cigar), len(self.qname_buf), len(self.seq_words)
         r.seq_ascii_cap = len(self.seq_ascii)
+        if want_seq & 4:
+            r.sa_off = self.sa_off.ctypes.data
+            r.sa = self.sa_buf.ctypes.data if len(self.sa_buf) else None
+            r.sa_cap = len(self.sa_buf)
         r.n_rec, r.n_cigar = len(self.pos), int(self.n_cigar_op.sum())
         return r
 
@@ -76,6 +82,14 @@ class FetchedRecords:
         """integer PS / HP tag of record r, None when the record has none (pysam's get_tag raises KeyError there)"""
         v = int((self.ps if name == "PS" else self.hp)[r])
         return None if v == NO_TAG else v
+
+    def sa_tag(self, r) -> str:
+        """text of the SA tag ('' when the record has none; needs want_seq & 4)"""
+        o = int(self.sa_off[r])
+        e = o
+        while self.sa_buf[e]:
+            e += 1
+        return self.sa_buf[o:e].tobytes().decode()
 
     def seq_text(self, r) -> str:
         """read.seq: the bases as the BAM stores them, ambiguity codes kept (needs want_seq & 2)"""
@@ -120,7 +134,7 @@ class BamFile:
         return bool(self._lib.fsv_bam_has_index(self._h))
 
     def fetch(self, chrom=None, start=0, end=0, want_seq=0, until_eof=False) -> FetchedRecords:
-        """want_seq: 0 none, 1 the 2-bit words, 2 the text, 3 both.  until_eof (chrom None): every record of the file"""
+        """want_seq bits: 1 the 2-bit words, 2 the text, 4 the SA tags.  until_eof (chrom None): every record of the file"""
         want_seq = int(want_seq)
         if until_eof or chrom is None:
             rid, chrom = -1, None
@@ -133,7 +147,7 @@ class BamFile:
         if rc != 0:
             raise _lib.FsvError(rc, "fsv_bam_fetch", self.path)
         out = FetchedRecords(chrom, int(cnt.n_rec), int(cnt.n_cigar), int(cnt.qname_bytes), int(cnt.seq_words) if want_seq & 1 else None,
-                             int(cnt.seq_ascii_bytes) if want_seq & 2 else None, self.references)
+                             int(cnt.seq_ascii_bytes) if want_seq & 2 else None, self.references, int(cnt.sa_bytes) if want_seq & 4 else None)
         if len(out):
             st = out.struct(want_seq)
             rc = self._lib.fsv_bam_fetch(self._h, rid, start, end, C.byref(st), int(want_seq))

@@ -172,6 +172,34 @@ bool aux_int(const uint8_t *p, const uint8_t *end, char t0, char t1, int32_t *ou
     return false;
 }
 
+// value of a two-letter string (Z) tag: pointer into the record and its length; false when absent
+bool aux_str(const uint8_t *p, const uint8_t *end, char t0, char t1, const char **out, size_t *len)
+{
+    while (p + 3 <= end) {
+        const char a = (char)p[0], b = (char)p[1], ty = (char)p[2];
+        p += 3;
+        size_t sz = 0;
+        switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': { const uint8_t *q = p; while (q < end && *q) q++; sz = (size_t)(q - p) + 1; break; }
+        case 'B': {
+            if (p + 5 > end) return false;
+            uint32_t cnt; memcpy(&cnt, p + 1, 4);
+            const char st = (char)p[0];
+            sz = 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4);
+            break;
+        }
+        default: return false;
+        }
+        if (p + sz > end) return false;
+        if (a == t0 && b == t1) { if (ty != 'Z') return false; *out = (const char *)p; *len = sz - 1; return true; }
+        p += sz;
+    }
+    return false;
+}
+
 } // namespace
 
 extern "C" int fsv_bam_open(const char *path, fsv_bam **out)
@@ -237,7 +265,7 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
         const auto &lin = b->linear[(size_t)ref_id];
         const size_t w = (size_t)(beg >> 14);
         if (w < lin.size() && lin[w] != 0 && (v == ~0ull || lin[w] > v)) v = lin[w];
-        if (v == ~0ull) { out->n_rec = 0; out->n_cigar = 0; out->qname_bytes = 0; out->seq_words = 0; out->seq_ascii_bytes = 0; return FSV_OK; }   // no records on this reference
+        if (v == ~0ull) { out->n_rec = 0; out->n_cigar = 0; out->qname_bytes = 0; out->seq_words = 0; out->seq_ascii_bytes = 0; out->sa_bytes = 0; return FSV_OK; }   // no records on this reference
         start = v; seeked = true;
     }
     if (seeked) { if (!bgzf_seek(b, start)) return FSV_EINVAL; }
@@ -256,7 +284,7 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
             if (!bgzf_read(b, skip.data(), (size_t)l_name) || !bgzf_read(b, &l_ref, 4)) return FSV_EINVAL;
         }
     }
-    uint64_t n_rec = 0, n_cig = 0, qbytes = 0, seq_words = 0, abytes = 0;
+    uint64_t n_rec = 0, n_cig = 0, qbytes = 0, seq_words = 0, abytes = 0, sbytes = 0;
     std::vector<uint8_t> rec;
     for (;;) {
         int32_t bs = 0;
@@ -302,6 +330,16 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
             memcpy(out->cigar + n_cig, p, (size_t)n_cigar_op * 4);
             memcpy(out->qname + qbytes, qname, l_read_name);
             if (out->ref_id) out->ref_id[n_rec] = refID;
+            if ((want_seq & 4) && out->sa_off) {
+                const uint8_t *aux = p + (size_t)n_cigar_op * 4 + (size_t)(l_seq + 1) / 2 + (size_t)l_seq, *aend = rec.data() + rec.size();
+                const char *sv = nullptr; size_t sl = 0;
+                out->sa_off[n_rec] = sbytes;
+                if (aux <= aend && aux_str(aux, aend, 'S', 'A', &sv, &sl)) {
+                    if (sbytes + sl + 1 > out->sa_cap) return FSV_ECAP;
+                    memcpy(out->sa + sbytes, sv, sl);
+                    out->sa[sbytes + sl] = 0;
+                }
+            }
             if ((want_seq & 2) && out->seq_ascii) {
                 if (abytes + (uint64_t)l_seq > out->seq_ascii_cap) return FSV_ECAP;
                 out->seq_ascii_off[n_rec] = abytes;
@@ -325,8 +363,15 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
         n_rec++; n_cig += n_cigar_op; qbytes += l_read_name;
         if (want_seq & 1) seq_words += (uint64_t)(l_seq + 15) / 16;
         if (want_seq & 2) abytes += (uint64_t)l_seq;
+        if (want_seq & 4) {   // the SA tag's text + NUL; a record without one takes the NUL alone
+            const uint8_t *aux = p + (size_t)n_cigar_op * 4 + (size_t)(l_seq + 1) / 2 + (size_t)l_seq, *aend = rec.data() + rec.size();
+            const char *sv = nullptr; size_t sl = 0;
+            if (aux <= aend && aux_str(aux, aend, 'S', 'A', &sv, &sl)) sbytes += sl;
+            if (fill && out->sa && !sv) { if (sbytes + 1 > out->sa_cap) return FSV_ECAP; out->sa[sbytes] = 0; }
+            sbytes += 1;
+        }
     }
-    out->n_rec = n_rec; out->n_cigar = n_cig; out->qname_bytes = qbytes; out->seq_words = seq_words; out->seq_ascii_bytes = abytes;
+    out->n_rec = n_rec; out->n_cigar = n_cig; out->qname_bytes = qbytes; out->seq_words = seq_words; out->seq_ascii_bytes = abytes; out->sa_bytes = sbytes;
     return FSV_OK;
 }
 

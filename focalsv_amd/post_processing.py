@@ -1,6 +1,6 @@
 """Read-support filter and genotype correction: the HiFi branch of focalsv/5_post_processing/FocalSV_Filter_GT_Correct.py:163-214
-(SURVEY.md 8f, row N1), given the read-level signature files DEL.sigs / INS.sigs (`--sigdir`; producing them is the reference's
-Reads_Based_Scan, a separate read-based caller that is not restated here).
+ on the read-level signature files DEL.sigs / INS.sigs -- handed in (`--sigdir`) or extracted from the BAM by
+focalsv_amd.reads_scan (the signature collection of the reference's Reads_Based_Scan).
 
   step 1  signature_support   calculate_signature_support.py     signature bases within 1 kb of every call -> <vcf>_cutesv_sig_support_mins30_fl1000.csv
   step 2  filter_by_support   filter_vcf_by_sig_cov_insdel.py    calls whose support per SV base is far from the median are dropped (filter_para.csv)
@@ -357,14 +357,15 @@ def filter_gt_correct(bam_file, out_dir, chr_num, sigdir, data_type='Hifi'):
     <out_dir>/SV/chr<N>/final_vcf/dippav_variant_no_redundancy.vcf, works in <out_dir>/post_processing/, writes
     <out_dir>/FocalSV_Final_SV.vcf"""
     if data_type != 'Hifi':
-        raise NotImplementedError("the CLR / ONT branch needs Reads_Based_Scan's draft VCF (gt_impute), which is not built")
-    if not sigdir:
-        raise NotImplementedError("pass sigdir= with DEL.sigs / INS.sigs: extracting them is the reference's Reads_Based_Scan, not built here")
+        raise NotImplementedError("the CLR / ONT branch needs Reads_Based_Scan's clustered draft VCF (gt_impute), which is not built")
     wdir = os.path.join(os.path.realpath(out_dir), "post_processing")
     vcffile = os.path.realpath(os.path.join(out_dir, "SV", "chr%s" % chr_num, "final_vcf", "dippav_variant_no_redundancy.vcf"))
     for p in (bam_file, vcffile):
         if not os.path.isfile(p):
             raise FileNotFoundError(p)
+    if not sigdir:      # call_sig (FocalSV_Filter_GT_Correct.py:116-151): the read signatures come from the BAM
+        from . import reads_scan
+        sigdir = reads_scan.call_sig(bam_file, os.path.join(wdir, "reads_sig"), chr_num)
     gtdir = os.path.join(wdir, "GT_Correction")
     os.makedirs(gtdir, exist_ok=True)
     signature_support(vcffile, sigdir, wdir)

@@ -325,13 +325,15 @@ typedef struct fsv_bam_records {
     char     *seq_ascii;          /* want_seq & 2: bases of record r as text (pysam read.seq), l_seq[r] bytes from seq_ascii + seq_ascii_off[r] */
     uint64_t *seq_ascii_off;
     int32_t  *ref_id;             /* optional: reference sequence of the record (-1 unmapped) */
+    char     *sa;                 /* want_seq & 4: NUL-terminated text of the record's SA tag ("" when it has none) at sa + sa_off[r] */
+    uint64_t *sa_off;
     int32_t  *ps, *hp;            /* optional (both or neither): integer PS / HP tags of the record, FSV_BAM_NO_TAG when absent (output_fas.py:31-33) */
-    uint64_t rec_cap, cigar_cap, qname_cap, seq_cap, seq_ascii_cap;
-    uint64_t n_rec, n_cigar, qname_bytes, seq_words, seq_ascii_bytes;   /* out */
+    uint64_t rec_cap, cigar_cap, qname_cap, seq_cap, seq_ascii_cap, sa_cap;
+    uint64_t n_rec, n_cigar, qname_bytes, seq_words, seq_ascii_bytes, sa_bytes;   /* out */
 } fsv_bam_records;
 #define FSV_BAM_NO_TAG (-2147483647 - 1)
 /* mapped records of reference ref_id that overlap [beg, end) (end <= 0: to the end), in file order; ref_id -1: every record of the
- * file (pysam fetch(until_eof=True), output_fas.py:26).  want_seq: bit 0 the 2-bit words, bit 1 the text */
+ * file (pysam fetch(until_eof=True), output_fas.py:26).  want_seq: bit 0 the 2-bit words, bit 1 the text, bit 2 the SA tags (supplementary alignments, Reads_Based_Scan.py:527-531) */
 int fsv_bam_fetch(fsv_bam *bam, int ref_id, int64_t beg, int64_t end, fsv_bam_records *out, int want_seq);
 
 typedef struct fsv_read_sig {

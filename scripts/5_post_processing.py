@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Drop-in for focalsv/5_post_processing/FocalSV_Filter_GT_Correct.py (same flags) for HiFi data with pre-extracted read
-signatures (--sigdir holding DEL.sigs / INS.sigs): signature support per call, empirical support filter, genotype correction
+"""Drop-in for focalsv/5_post_processing/FocalSV_Filter_GT_Correct.py (same flags) for HiFi data: read signatures (extracted from
+the BAM, or --sigdir holding DEL.sigs / INS.sigs), signature support per call, empirical support filter, genotype correction
 -> <out_dir>/FocalSV_Final_SV.vcf.  The read BAM is read with the library's own reader (no pysam / samtools)."""
 import os
 import sys
@@ -16,7 +16,7 @@ parser.add_argument("--ref_file", '-r', type=str, help="reference FASTA (only th
 parser.add_argument("--chr_num", '-chr', type=str, choices=[str(i) for i in range(1, 23)] + ['wgs'], required=True)
 parser.add_argument("--out_dir", '-o', type=str, default="./FocalSV_Result")
 parser.add_argument("--num_threads", '-thread', type=int, default=10)
-parser.add_argument("--sigdir", '-sig', type=str, help="pre-extracted reads signature directory (DEL.sigs, INS.sigs)")
+parser.add_argument("--sigdir", '-sig', type=str, help="pre-extracted reads signature directory (DEL.sigs, INS.sigs); extracted from the BAM when absent")
 
 if __name__ == "__main__":
     args = parser.parse_args()

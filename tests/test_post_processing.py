@@ -71,5 +71,5 @@ def test_span_counter_equals_plain_count(cases, tmp_path):
 def test_unsupported_branches_say_so(tmp_path):
     with pytest.raises(NotImplementedError):
         PP.filter_gt_correct("x.bam", str(tmp_path), 21, "sig", "ONT")
-    with pytest.raises(NotImplementedError):
-        PP.filter_gt_correct("x.bam", str(tmp_path), 21, None, "Hifi")
+    with pytest.raises(FileNotFoundError):
+        PP.filter_gt_correct(str(tmp_path / "missing.bam"), str(tmp_path), 21, "sig", "Hifi")
