@@ -137,6 +137,7 @@ def load():
         "fsv_bam_ref_name": (C.c_char_p, [vp, C.c_int]),
         "fsv_bam_ref_id": (C.c_int, [vp, C.c_char_p]),
         "fsv_bam_has_index": (C.c_int, [vp]),
+        "fsv_bam_set_threads": (None, [vp, C.c_int]),
         "fsv_bam_fetch": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int64, C.POINTER(BamRecords), C.c_int]),
         "fsv_read_signatures": (C.c_int, [vp, C.POINTER(BamRecords), C.c_int, C.c_int, vp, C.c_uint32, u32p]),
         "fsv_nw": (C.c_int, [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnParams), C.POINTER(C.c_int32), vp, C.c_uint32,

@@ -105,7 +105,7 @@ class FetchedRecords:
 
 
 class BamFile:
-    def __init__(self, path):
+    def __init__(self, path, threads=None):
         self._lib = _lib.load()
         h = C.c_void_p()
         rc = self._lib.fsv_bam_open(str(path).encode(), C.byref(h))
@@ -113,6 +113,8 @@ class BamFile:
             raise _lib.FsvError(rc, "fsv_bam_open", str(path))
         self._h = h
         self.path = str(path)
+        if threads:
+            self._lib.fsv_bam_set_threads(self._h, int(threads))
 
     def close(self):
         if self._h:

@@ -12,6 +12,35 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <future>
+
+struct BgzfBlock {
+    std::vector<uint8_t> comp, data;
+    uint32_t clen = 0, isize = 0;
+    int64_t addr = 0;
+    int bsize = 0;
+};
+
+struct BgzfWindow {
+    std::vector<BgzfBlock> blk;
+    int64_t next_addr = 0;           // file offset following the run
+    std::string err;
+};
+
+struct BamCache {
+    bool valid = false;
+    int ref_id = 0, want = 0;
+    int64_t beg = 0, end = 0;
+    std::vector<int32_t> pos, ref_end, l_seq, ref, ps, hp;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<uint64_t> cigar_off, qname_off, seq_word_off, seq_ascii_off, sa_off;
+    std::vector<uint32_t> n_cigar_op, cigar, seq_words;
+    std::vector<char> qname, seq_ascii, sa;
+    void clear() { *this = BamCache(); }
+};
 
 struct fsv_bam {
     FILE *f = nullptr;
@@ -24,6 +53,12 @@ struct fsv_bam {
     int64_t block_addr = 0;          // file offset of the current block
     int64_t next_addr = 0;           // file offset of the next block
     bool eof = false;
+    BgzfWindow win;                  // blocks read ahead and inflated in parallel; win_i = the next one to hand out
+    size_t win_i = 0, run_blocks = 16;
+    std::future<BgzfWindow> pending; // the run after `win`, being read and inflated in the background
+    bool has_pending = false;
+    int n_threads = 1;
+    BamCache cache;                  // the records of the last sizing call, until the caller has taken them
     // .bai: per reference the smallest virtual offset of its chunks (where a scan of that reference starts), and the linear index
     bool have_index = false;
     std::vector<uint64_t> ref_first_voff;
@@ -32,43 +67,108 @@ struct fsv_bam {
 
 namespace {
 
+// one BGZF block: header parsed and compressed bytes read by the (serial) file scan, inflated by whichever thread takes it
+bool inflate_block(BgzfBlock &k)
+{
+    k.data.resize(k.isize);
+    if (!k.isize) return true;
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = k.comp.data(); zs.avail_in = (uInt)k.clen;
+    zs.next_out = k.data.data(); zs.avail_out = k.isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.total_out == k.isize;
+}
+
+// read a run of up to `want` blocks starting at file offset addr and inflate them on the reader's threads.  A malformed block behind
+// at least one good one ends the run: the next run starts at it and reports it.
+BgzfWindow load_window(fsv_bam *b, int64_t addr, size_t want)
+{
+    BgzfWindow w;
+    w.next_addr = addr;
+    if (fseeko(b->f, (off_t)addr, SEEK_SET) != 0) { w.err = "seek failed"; return w; }
+    while (w.blk.size() < want) {
+        const char *bad = nullptr;
+        uint8_t hdr[18];
+        const size_t got = fread(hdr, 1, 18, b->f);
+        if (got == 0) break;                       // end of file
+        BgzfBlock k;
+        int bsize = -1;
+        if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) bad = "not a BGZF block";
+        else {
+            const unsigned xlen = hdr[10] | hdr[11] << 8;
+            // the BC subfield is the first extra subfield in every BGZF writer; tolerate others in front of it
+            std::vector<uint8_t> extra(xlen);
+            memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
+            if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, b->f) != xlen - 6) bad = "truncated BGZF header";
+            for (size_t p = 0; !bad && p + 4 <= extra.size();) {
+                const unsigned slen = extra[p + 2] | extra[p + 3] << 8;
+                if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= extra.size()) bsize = (extra[p + 4] | extra[p + 5] << 8) + 1;
+                p += 4 + slen;
+            }
+            const int clen = bsize - 12 - (int)xlen - 8;   // block = 12-byte header + extra + deflate data + crc32 + isize
+            if (!bad && bsize < 0) bad = "BGZF block without BC subfield";
+            else if (!bad && clen < 0) bad = "bad BGZF block size";
+            if (!bad) {
+                k.comp.resize((size_t)clen + 8);
+                if (fread(k.comp.data(), 1, k.comp.size(), b->f) != k.comp.size()) bad = "truncated BGZF block";
+                else {
+                    k.clen = (uint32_t)clen;
+                    k.isize = k.comp[clen + 4] | k.comp[clen + 5] << 8 | k.comp[clen + 6] << 16 | (uint32_t)k.comp[clen + 7] << 24;
+                    if (k.isize > 65536) bad = "bad BGZF block size";
+                }
+            }
+        }
+        if (bad) { if (w.blk.empty()) w.err = bad; break; }
+        k.addr = w.next_addr;
+        k.bsize = bsize;
+        w.next_addr += bsize;
+        w.blk.push_back(std::move(k));
+    }
+    const size_t n = w.blk.size();
+    const unsigned nt = (unsigned)std::min<size_t>((size_t)std::max(1, b->n_threads), (n + 7) / 8);
+    std::atomic<bool> ok{true};
+    auto work = [&](unsigned t) { for (size_t i = t; i < n; i += nt) if (!inflate_block(w.blk[i])) ok = false; };
+    if (nt <= 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    if (!ok) { w.blk.clear(); w.err = "inflate failed"; }
+    return w;
+}
+
+void drop_pending(fsv_bam *b)
+{
+    if (b->has_pending) { (void)b->pending.get(); b->has_pending = false; }
+}
+
+// The run grows from 16 to 512 blocks as a scan goes on, so a region query touches little beyond its blocks while a chromosome scan
+// keeps every thread busy; from 64 blocks on the next run is read and inflated in the background while this one is parsed.
 bool bgzf_read_block(fsv_bam *b)
 {
-    uint8_t hdr[18];
-    if (fseeko(b->f, (off_t)b->next_addr, SEEK_SET) != 0) { b->err = "seek failed"; return false; }
-    const size_t got = fread(hdr, 1, 18, b->f);
-    if (got == 0) { b->eof = true; b->block.clear(); b->block_pos = 0; return true; }
-    if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { b->err = "not a BGZF block"; return false; }
-    const unsigned xlen = hdr[10] | hdr[11] << 8;
-    // the BC subfield is the first extra subfield in every BGZF writer; tolerate others in front of it
-    std::vector<uint8_t> extra(xlen);
-    memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
-    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, b->f) != xlen - 6) { b->err = "truncated BGZF header"; return false; }
-    int bsize = -1;
-    for (size_t p = 0; p + 4 <= extra.size();) {
-        const unsigned slen = extra[p + 2] | extra[p + 3] << 8;
-        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= extra.size()) bsize = (extra[p + 4] | extra[p + 5] << 8) + 1;
-        p += 4 + slen;
+    if (b->win_i == b->win.blk.size()) {
+        if (b->has_pending) { b->win = b->pending.get(); b->has_pending = false; }
+        else b->win = load_window(b, b->win.next_addr, b->run_blocks);
+        b->win_i = 0;
+        if (!b->win.err.empty()) { b->err = b->win.err; return false; }
+        if (b->win.blk.empty()) { b->eof = true; b->block.clear(); b->block_pos = 0; return true; }
+        b->run_blocks = std::min<size_t>(512, b->run_blocks * 2);
+        if (b->run_blocks >= 64 && b->n_threads > 1) {
+            const int64_t at = b->win.next_addr;
+            const size_t want = b->run_blocks;
+            b->pending = std::async(std::launch::async, [b, at, want] { return load_window(b, at, want); });
+            b->has_pending = true;
+        }
     }
-    if (bsize < 0) { b->err = "BGZF block without BC subfield"; return false; }
-    const int clen = bsize - 12 - (int)xlen - 8;   // block = 12-byte header + extra + deflate data + crc32 + isize
-    if (clen < 0) { b->err = "bad BGZF block size"; return false; }
-    std::vector<uint8_t> comp((size_t)clen + 8);
-    if (fread(comp.data(), 1, comp.size(), b->f) != comp.size()) { b->err = "truncated BGZF block"; return false; }
-    const uint32_t isize = comp[clen + 4] | comp[clen + 5] << 8 | comp[clen + 6] << 16 | (uint32_t)comp[clen + 7] << 24;
-    b->block.resize(isize);
-    if (isize) {
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, -15) != Z_OK) { b->err = "zlib init failed"; return false; }
-        zs.next_in = comp.data(); zs.avail_in = (uInt)clen;
-        zs.next_out = b->block.data(); zs.avail_out = isize;
-        const int rc = inflate(&zs, Z_FINISH);
-        inflateEnd(&zs);
-        if (rc != Z_STREAM_END || zs.total_out != isize) { b->err = "inflate failed"; return false; }
-    }
-    b->block_addr = b->next_addr;
-    b->next_addr += bsize;
+    BgzfBlock &k = b->win.blk[b->win_i++];
+    b->block.swap(k.data);
+    b->block_addr = k.addr;
+    b->next_addr = k.addr + k.bsize;
     b->block_pos = 0;
     return true;
 }
@@ -93,9 +193,13 @@ bool bgzf_read(fsv_bam *b, void *dst, size_t n)
 
 bool bgzf_seek(fsv_bam *b, uint64_t voff)
 {
-    b->next_addr = (int64_t)(voff >> 16);
+    drop_pending(b);
+    b->win = BgzfWindow();
+    b->win.next_addr = (int64_t)(voff >> 16);
+    b->win_i = 0; b->run_blocks = 16;
     b->eof = false;
     if (!bgzf_read_block(b)) return false;
+    if (b->eof) { b->block_pos = 0; return (voff & 0xffff) == 0; }
     if ((voff & 0xffff) > b->block.size()) { b->err = "virtual offset past the block"; return false; }
     b->block_pos = (size_t)(voff & 0xffff);
     return true;
@@ -202,6 +306,37 @@ bool aux_str(const uint8_t *p, const uint8_t *end, char t0, char t1, const char 
 
 } // namespace
 
+// counts to the caller; with buffers (pos != NULL) also the arrays, after which the reader lets go of them
+static int copy_out(fsv_bam *b, fsv_bam_records *out, int want_seq)
+{
+    BamCache &c = b->cache;
+    const size_t n = c.pos.size();
+    out->n_rec = n; out->n_cigar = c.cigar.size(); out->qname_bytes = c.qname.size(); out->seq_words = c.seq_words.size();
+    out->seq_ascii_bytes = c.seq_ascii.size(); out->sa_bytes = c.sa.size();
+    if (!out->pos) return FSV_OK;
+    if (n > out->rec_cap || c.cigar.size() > out->cigar_cap || c.qname.size() > out->qname_cap) return FSV_ECAP;
+    auto put = [](void *dst, const void *src, size_t bytes) { if (dst && bytes) memcpy(dst, src, bytes); };
+    put(out->pos, c.pos.data(), n * 4); put(out->ref_end, c.ref_end.data(), n * 4); put(out->flag, c.flag.data(), n * 2); put(out->mapq, c.mapq.data(), n);
+    put(out->cigar_off, c.cigar_off.data(), n * 8); put(out->n_cigar_op, c.n_cigar_op.data(), n * 4); put(out->qname_off, c.qname_off.data(), n * 8);
+    put(out->l_seq, c.l_seq.data(), n * 4); put(out->cigar, c.cigar.data(), c.cigar.size() * 4); put(out->qname, c.qname.data(), c.qname.size());
+    put(out->ref_id, c.ref.data(), n * 4);
+    if (out->ps && out->hp) { put(out->ps, c.ps.data(), n * 4); put(out->hp, c.hp.data(), n * 4); }
+    if ((want_seq & 1) && out->seq_word_off) {
+        if (c.seq_words.size() > out->seq_cap) return FSV_ECAP;
+        put(out->seq_word_off, c.seq_word_off.data(), n * 8); put(out->seq_words_buf, c.seq_words.data(), c.seq_words.size() * 4);
+    }
+    if ((want_seq & 2) && out->seq_ascii_off) {
+        if (c.seq_ascii.size() > out->seq_ascii_cap) return FSV_ECAP;
+        put(out->seq_ascii_off, c.seq_ascii_off.data(), n * 8); put(out->seq_ascii, c.seq_ascii.data(), c.seq_ascii.size());
+    }
+    if ((want_seq & 4) && out->sa_off) {
+        if (c.sa.size() > out->sa_cap) return FSV_ECAP;
+        put(out->sa_off, c.sa_off.data(), n * 8); put(out->sa, c.sa.data(), c.sa.size());
+    }
+    c.clear();
+    return FSV_OK;
+}
+
 extern "C" int fsv_bam_open(const char *path, fsv_bam **out)
 {
     if (!path || !out) return FSV_EINVAL;
@@ -209,6 +344,7 @@ extern "C" int fsv_bam_open(const char *path, fsv_bam **out)
     b->path = path;
     b->f = fopen(path, "rb");
     if (!b->f) { delete b; return FSV_EINVAL; }
+    b->n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     char magic[4]; int32_t l_text = 0, n_ref = 0;
     bool ok = bgzf_read(b, magic, 4) && !memcmp(magic, "BAM\1", 4) && bgzf_read(b, &l_text, 4) && l_text >= 0;
     if (ok) { std::vector<char> text((size_t)l_text); ok = l_text == 0 || bgzf_read(b, text.data(), (size_t)l_text); }
@@ -229,6 +365,7 @@ extern "C" int fsv_bam_open(const char *path, fsv_bam **out)
 extern "C" void fsv_bam_close(fsv_bam *b)
 {
     if (!b) return;
+    if (b->has_pending) { (void)b->pending.get(); b->has_pending = false; }
     if (b->f) fclose(b->f);
     delete b;
 }
@@ -242,6 +379,7 @@ extern "C" int fsv_bam_ref_id(const fsv_bam *b, const char *name)
 
 extern "C" int fsv_bam_n_refs(const fsv_bam *b) { return b ? (int)b->ref_name.size() : 0; }
 extern "C" const char *fsv_bam_ref_name(const fsv_bam *b, int id) { return b && id >= 0 && id < (int)b->ref_name.size() ? b->ref_name[(size_t)id].c_str() : nullptr; }
+extern "C" void fsv_bam_set_threads(fsv_bam *b, int n) { if (b) b->n_threads = n < 1 ? 1 : n; }
 extern "C" int fsv_bam_has_index(const fsv_bam *b) { return b && b->have_index ? 1 : 0; }
 
 // Records of reference ref_id overlapping [beg, end) (end <= 0: to the end of the reference), in file order -- the iteration
@@ -256,7 +394,9 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
     if (all) { beg = 0; end = INT64_MAX; }
     else if (end <= 0) end = b->ref_len[(size_t)ref_id];
     if (beg < 0) beg = 0;
-    const bool fill = out->pos != nullptr;
+    // one parse per query: the sizing call (pos == NULL) decodes into the reader's own arrays, the call with buffers copies them out
+    BamCache &c = b->cache;
+    if (c.valid && c.ref_id == ref_id && c.beg == beg && c.end == end && c.want == want_seq) return copy_out(b, out, want_seq);
     // where to start: with an index, the linear-index entry of the window that holds beg (or the reference's first chunk)
     uint64_t start = 0;
     bool seeked = false;
@@ -265,13 +405,13 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
         const auto &lin = b->linear[(size_t)ref_id];
         const size_t w = (size_t)(beg >> 14);
         if (w < lin.size() && lin[w] != 0 && (v == ~0ull || lin[w] > v)) v = lin[w];
-        if (v == ~0ull) { out->n_rec = 0; out->n_cigar = 0; out->qname_bytes = 0; out->seq_words = 0; out->seq_ascii_bytes = 0; out->sa_bytes = 0; return FSV_OK; }   // no records on this reference
+        if (v == ~0ull) { c.clear(); return copy_out(b, out, want_seq); }   // no records on this reference
         start = v; seeked = true;
     }
     if (seeked) { if (!bgzf_seek(b, start)) return FSV_EINVAL; }
     else {
         // no index: from the first record (skip the header again)
-        b->next_addr = 0; b->eof = false; b->block.clear(); b->block_pos = 0;
+        if (!bgzf_seek(b, 0)) return FSV_EINVAL;
         char magic[4]; int32_t l_text = 0, n_ref = 0;
         if (!bgzf_read(b, magic, 4) || !bgzf_read(b, &l_text, 4)) return FSV_EINVAL;
         std::vector<char> skip((size_t)l_text);
@@ -284,14 +424,30 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
             if (!bgzf_read(b, skip.data(), (size_t)l_name) || !bgzf_read(b, &l_ref, 4)) return FSV_EINVAL;
         }
     }
-    uint64_t n_rec = 0, n_cig = 0, qbytes = 0, seq_words = 0, abytes = 0, sbytes = 0;
+    c.clear();
     std::vector<uint8_t> rec;
+    // =ACMGRSVTWYHKDBN -> A C G T (the rest A), two bases per packed byte -> 4 bits; and the same byte as two letters
+    struct Tabs {
+        uint8_t pair2[256];
+        uint16_t pairc[256];
+        Tabs() {
+            static const uint8_t code[16] = {0, 0, 1, 0, 2, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0};
+            for (int v = 0; v < 256; v++) {
+                pair2[v] = (uint8_t)(code[v >> 4] | code[v & 15] << 2);
+                pairc[v] = (uint16_t)((uint8_t)"=ACMGRSVTWYHKDBN"[v >> 4] | (uint16_t)(uint8_t)"=ACMGRSVTWYHKDBN"[v & 15] << 8);
+            }
+        }
+    };
+    static const Tabs tabs;
+    const uint8_t *pair2 = tabs.pair2;
+    const uint16_t *pairc = tabs.pairc;
     for (;;) {
         int32_t bs = 0;
         if (!bgzf_read(b, &bs, 4)) { if (!b->err.empty()) return FSV_EINVAL; break; }   // clean end of file
         if (bs < 32) return FSV_EINVAL;
-        rec.resize((size_t)bs);
+        rec.resize((size_t)bs + 8);
         if (!bgzf_read(b, rec.data(), (size_t)bs)) return FSV_EINVAL;
+        const uint8_t *rend = rec.data() + bs;
         int32_t refID, pos, l_seq; uint8_t l_read_name, mapq; uint16_t n_cigar_op, flag;
         memcpy(&refID, rec.data(), 4); memcpy(&pos, rec.data() + 4, 4);
         l_read_name = rec[8]; mapq = rec[9];
@@ -306,10 +462,10 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
         const uint8_t *p = rec.data() + 32;
         const char *qname = (const char *)p;
         p += l_read_name;
-        if ((size_t)(p - rec.data()) + (size_t)n_cigar_op * 4 + (size_t)(l_seq + 1) / 2 > rec.size()) return FSV_EINVAL;
+        if (l_seq < 0 || (size_t)(p - rec.data()) + (size_t)n_cigar_op * 4 + (size_t)(l_seq + 1) / 2 > (size_t)bs) return FSV_EINVAL;
         int64_t ref_end = pos;
-        for (uint32_t c = 0; c < n_cigar_op; c++) {
-            uint32_t v; memcpy(&v, p + 4 * c, 4);
+        for (uint32_t k = 0; k < n_cigar_op; k++) {
+            uint32_t v; memcpy(&v, p + 4 * k, 4);
             const uint32_t op = v & 0xf;
             if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_end += v >> 4;
         }
@@ -317,62 +473,48 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
             if (ref_end <= beg && !(n_cigar_op == 0 && pos >= beg)) continue;   // ends before the window
             if (flag & 4) continue;                                               // unmapped but placed: fetch() skips it too
         }
-        if (fill) {
-            if (n_rec >= out->rec_cap || n_cig + n_cigar_op > out->cigar_cap || qbytes + l_read_name > out->qname_cap) return FSV_ECAP;
-            out->pos[n_rec] = pos; out->ref_end[n_rec] = (int32_t)ref_end; out->flag[n_rec] = flag; out->mapq[n_rec] = mapq;
-            out->cigar_off[n_rec] = n_cig; out->n_cigar_op[n_rec] = n_cigar_op; out->qname_off[n_rec] = qbytes; out->l_seq[n_rec] = l_seq;
-            if (out->ps && out->hp) {
-                const uint8_t *aux = p + (size_t)n_cigar_op * 4 + (size_t)(l_seq + 1) / 2 + (size_t)l_seq, *aend = rec.data() + rec.size();
-                int32_t v;
-                out->ps[n_rec] = aux <= aend && aux_int(aux, aend, 'P', 'S', &v) ? v : FSV_BAM_NO_TAG;
-                out->hp[n_rec] = aux <= aend && aux_int(aux, aend, 'H', 'P', &v) ? v : FSV_BAM_NO_TAG;
-            }
-            memcpy(out->cigar + n_cig, p, (size_t)n_cigar_op * 4);
-            memcpy(out->qname + qbytes, qname, l_read_name);
-            if (out->ref_id) out->ref_id[n_rec] = refID;
-            if ((want_seq & 4) && out->sa_off) {
-                const uint8_t *aux = p + (size_t)n_cigar_op * 4 + (size_t)(l_seq + 1) / 2 + (size_t)l_seq, *aend = rec.data() + rec.size();
-                const char *sv = nullptr; size_t sl = 0;
-                out->sa_off[n_rec] = sbytes;
-                if (aux <= aend && aux_str(aux, aend, 'S', 'A', &sv, &sl)) {
-                    if (sbytes + sl + 1 > out->sa_cap) return FSV_ECAP;
-                    memcpy(out->sa + sbytes, sv, sl);
-                    out->sa[sbytes + sl] = 0;
-                }
-            }
-            if ((want_seq & 2) && out->seq_ascii) {
-                if (abytes + (uint64_t)l_seq > out->seq_ascii_cap) return FSV_ECAP;
-                out->seq_ascii_off[n_rec] = abytes;
-                const uint8_t *sq = p + (size_t)n_cigar_op * 4;
-                char *w = out->seq_ascii + abytes;
-                for (int32_t i = 0; i < l_seq; i++) w[i] = "=ACMGRSVTWYHKDBN"[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xf];
-            }
-            if ((want_seq & 1) && out->seq_words_buf) {
-                if (seq_words + (uint64_t)(l_seq + 15) / 16 > out->seq_cap) return FSV_ECAP;
-                out->seq_word_off[n_rec] = seq_words;
-                const uint8_t *sq = p + (size_t)n_cigar_op * 4;
-                uint32_t *w = out->seq_words_buf + seq_words;
-                for (int32_t i = 0; i < (l_seq + 15) / 16; i++) w[i] = 0;
-                static const uint8_t code[16] = {0, 0, 1, 0, 2, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0};   // =ACMGRSVTWYHKDBN -> A C G T, the rest A
-                for (int32_t i = 0; i < l_seq; i++) {
-                    const uint8_t nib = (sq[i >> 1] >> ((~i & 1) << 2)) & 0xf;
-                    w[i >> 4] |= (uint32_t)code[nib] << ((i & 15) << 1);
-                }
-            }
-        }
-        n_rec++; n_cig += n_cigar_op; qbytes += l_read_name;
-        if (want_seq & 1) seq_words += (uint64_t)(l_seq + 15) / 16;
-        if (want_seq & 2) abytes += (uint64_t)l_seq;
+        const uint8_t *sq = p + (size_t)n_cigar_op * 4;
+        const uint8_t *aux = sq + (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+        c.pos.push_back(pos); c.ref_end.push_back((int32_t)ref_end); c.flag.push_back(flag); c.mapq.push_back(mapq); c.ref.push_back(refID);
+        c.cigar_off.push_back(c.cigar.size()); c.n_cigar_op.push_back(n_cigar_op); c.qname_off.push_back(c.qname.size()); c.l_seq.push_back(l_seq);
+        int32_t v;
+        c.ps.push_back(aux <= rend && aux_int(aux, rend, 'P', 'S', &v) ? v : FSV_BAM_NO_TAG);
+        c.hp.push_back(aux <= rend && aux_int(aux, rend, 'H', 'P', &v) ? v : FSV_BAM_NO_TAG);
+        const size_t c0 = c.cigar.size();
+        c.cigar.resize(c0 + n_cigar_op);
+        if (n_cigar_op) memcpy(c.cigar.data() + c0, p, (size_t)n_cigar_op * 4);
+        c.qname.insert(c.qname.end(), qname, qname + l_read_name);
         if (want_seq & 4) {   // the SA tag's text + NUL; a record without one takes the NUL alone
-            const uint8_t *aux = p + (size_t)n_cigar_op * 4 + (size_t)(l_seq + 1) / 2 + (size_t)l_seq, *aend = rec.data() + rec.size();
             const char *sv = nullptr; size_t sl = 0;
-            if (aux <= aend && aux_str(aux, aend, 'S', 'A', &sv, &sl)) sbytes += sl;
-            if (fill && out->sa && !sv) { if (sbytes + 1 > out->sa_cap) return FSV_ECAP; out->sa[sbytes] = 0; }
-            sbytes += 1;
+            c.sa_off.push_back(c.sa.size());
+            if (aux <= rend && aux_str(aux, rend, 'S', 'A', &sv, &sl)) c.sa.insert(c.sa.end(), sv, sv + sl);
+            c.sa.push_back(0);
+        }
+        const size_t nb = (size_t)(l_seq + 1) / 2;
+        if (want_seq & 2) {
+            const size_t a0 = c.seq_ascii.size();
+            c.seq_ascii_off.push_back(a0);
+            c.seq_ascii.resize(a0 + nb * 2);
+            char *w = c.seq_ascii.data() + a0;
+            for (size_t i = 0; i < nb; i++) memcpy(w + 2 * i, &pairc[sq[i]], 2);
+            c.seq_ascii.resize(a0 + (size_t)l_seq);
+        }
+        if (want_seq & 1) {
+            const size_t w0 = c.seq_words.size(), nw = (size_t)(l_seq + 15) / 16;
+            c.seq_word_off.push_back(w0);
+            c.seq_words.resize(w0 + nw);
+            uint32_t *w = c.seq_words.data() + w0;
+            for (size_t i = 0; i < nw; i++) {
+                uint32_t x = 0;
+                const size_t k1 = std::min<size_t>(8, nb - i * 8);
+                for (size_t k = 0; k < k1; k++) x |= (uint32_t)pair2[sq[i * 8 + k]] << (4 * k);
+                w[i] = x;
+            }
+            if (l_seq & 1) w[nw - 1] &= ~(3u << ((l_seq & 15) << 1));   // the padding nibble of an odd-length read is not a base
         }
     }
-    out->n_rec = n_rec; out->n_cigar = n_cig; out->qname_bytes = qbytes; out->seq_words = seq_words; out->seq_ascii_bytes = abytes; out->sa_bytes = sbytes;
-    return FSV_OK;
+    c.valid = true; c.ref_id = ref_id; c.beg = beg; c.end = end; c.want = want_seq;
+    return copy_out(b, out, want_seq);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

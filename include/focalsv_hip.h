@@ -308,6 +308,7 @@ int  fsv_bam_n_refs(const fsv_bam *bam);
 const char *fsv_bam_ref_name(const fsv_bam *bam, int ref_id);
 int  fsv_bam_ref_id(const fsv_bam *bam, const char *name);   /* -1: no such reference sequence */
 int  fsv_bam_has_index(const fsv_bam *bam);
+void fsv_bam_set_threads(fsv_bam *bam, int n);   /* host threads inflating BGZF blocks (default: the machine's, at most 16) */
 
 typedef struct fsv_bam_records {
     /* all host; caller-allocated with the capacities below (a first call with pos == NULL only counts) */

@@ -280,3 +280,17 @@ def test_gpu_cigar_signatures_random(tmp_path):
                     ed += d
                     ei += i
             assert dels == ed and inss == ei and len(ed) > 50 and len(ei) > 50
+
+
+def test_thread_count_does_not_change_the_result(tmp_path):
+    """many small blocks: the read-ahead runs grow to their full length and are inflated in the background, by 1, 3 or 8 threads"""
+    import numpy as np
+    recs = make_records(9, n=150)
+    path = W.write_bam(str(tmp_path / "t.bam"), [("chr1", 200000), ("chr2", 150000), ("chrX", 90000)], recs, block=900)
+    out = []
+    for th in (1, 3, 8):
+        with B.BamFile(path, threads=th) as bam:
+            a = bam.fetch("chr2", want_seq=3)
+            b = bam.fetch("chr1", 30000, 90000)        # a second query on the same handle, while a read-ahead may still be in flight
+            out.append((a.names, a.pos.tolist(), a.cigar.tolist(), a.seq_words.tolist(), a.seq_ascii.tobytes(), b.names))
+    assert out[0] == out[1] == out[2] and len(out[0][0]) == 150
