@@ -112,15 +112,26 @@ def upload_regions(ctx: _lib.Context, regions: Sequence[RegionInput]) -> DeviceB
     return DeviceBatch(list(regions), packed, ctx.upload(packed.words), _lib.join_refs([r.ref for r in regions]), set_region, set_kind)
 
 
-def upload_bam_regions(ctx: _lib.Context, bam_path: str, regions: Sequence[Tuple[str, int, int]], windows: Sequence[Tuple[int, bytes]]) -> DeviceBatch:
-    """K0 straight from a haplotagged BAM: crop (1_crop_bam.py:74 -- the records `samtools view bam chr:s-e` keeps), group by the
-    PS / HP tags (2_phasing/output_fas.py:28-73) and gather the reads' bases as 2-bit words into the store, without a region.bam, a
-    FASTA or the reads' text in between.  regions[i] = (chrom, start, end) as in the BED line (1-based inclusive, like the samtools
-    region string); windows[i] = (chromosome coordinate of ref[0], reference window)."""
+@dataclass
+class HostBatch:
+    """a batch read and packed on the host, ready for upload_host_batch (the decode can run ahead of the GPU on other threads)"""
+    regions: List[RegionInput]
+    packed: PackedBatch
+    set_region: List[int]
+    set_kind: List[int]
+
+
+def read_bam_regions(bam_path: str, regions: Sequence[Tuple[str, int, int]], windows: Sequence[Tuple[int, bytes]], bam=None) -> HostBatch:
+    """K0 straight from a haplotagged BAM, host half: crop (1_crop_bam.py:74 -- the records `samtools view bam chr:s-e` keeps), group
+    by the PS / HP tags (2_phasing/output_fas.py:28-73) and gather the reads' bases as 2-bit words, without a region.bam, a FASTA or
+    the reads' text in between.  regions[i] = (chrom, start, end) as in the BED line (1-based inclusive, like the samtools region
+    string); windows[i] = (chromosome coordinate of ref[0], reference window).  Only the records the read-level signatures can use
+    (a 30 bp indel in the CIGAR, or a read with several records; extract_reads_signature.py:68-209) are turned into record objects."""
     from . import bam as B, output_fas as OF
     from .readsets import concat_packed
     inputs, packs, set_region, set_kind = [], [], [], []
-    with B.BamFile(bam_path) as f:
+    f = bam or B.BamFile(bam_path)
+    try:
         for ri, ((chrom, start, end), (wstart, ref)) in enumerate(zip(regions, windows)):
             recs = f.fetch(chrom, start - 1, end, want_seq=1)
             files = OF.read_set_files(recs)
@@ -129,10 +140,39 @@ def upload_bam_regions(ctx: _lib.Context, bam_path: str, regions: Sequence[Tuple
                 kind = 0 if fn == "unphased.fa" else int(fn[:-3].rsplit("_hp", 1)[1])
                 sets.append(files[fn]); set_region.append(ri); set_kind.append(kind)
             packs.append(OF.pack_record_sets(recs, sets))
-            r = RegionInput(chrom, wstart, ref, [], [], [recs.segment(k) for k in range(len(recs))], "Region_%s_S%d_E%d" % (chrom, start, end))
-            inputs.append(r)
-    packed = concat_packed(packs)
-    return DeviceBatch(inputs, packed, ctx.upload(packed.words), _lib.join_refs([r.ref for r in inputs]), set_region, set_kind)
+            inputs.append(RegionInput(chrom, wstart, ref, [], [], _signature_records(recs), "Region_%s_S%d_E%d" % (chrom, start, end)))
+    finally:
+        if bam is None:
+            f.close()
+    return HostBatch(inputs, concat_packed(packs), set_region, set_kind)
+
+
+def _signature_records(recs) -> List[S.AlignedSegment]:
+    """the records of a fetch that can yield a read-level signature, in file order"""
+    n = len(recs)
+    if n == 0:
+        return []
+    k = int(recs.n_cigar_op.sum())
+    ops, lens = recs.cigar[:k] & 0xf, recs.cigar[:k] >> 4
+    long_op = np.nonzero(((ops == 1) | (ops == 2)) & (lens >= 30))[0]
+    use = np.zeros(n, bool)
+    use[np.searchsorted(recs.cigar_off, long_op, 'right') - 1] = True
+    names = recs.names
+    if len(set(names)) != n:
+        seen: Dict[str, int] = {}
+        for i, nm in enumerate(names):
+            seen[nm] = seen.get(nm, 0) + 1
+        use |= np.fromiter((seen[nm] > 1 for nm in names), bool, n)
+    return [recs.segment(int(i)) for i in np.nonzero(use)[0]]
+
+
+def upload_host_batch(ctx: _lib.Context, hb: HostBatch) -> DeviceBatch:
+    return DeviceBatch(hb.regions, hb.packed, ctx.upload(hb.packed.words), _lib.join_refs([r.ref for r in hb.regions]), hb.set_region, hb.set_kind)
+
+
+def upload_bam_regions(ctx: _lib.Context, bam_path: str, regions: Sequence[Tuple[str, int, int]], windows: Sequence[Tuple[int, bytes]]) -> DeviceBatch:
+    """read_bam_regions + upload: haplotagged BAM -> read store in HBM"""
+    return upload_host_batch(ctx, read_bam_regions(bam_path, regions, windows))
 
 
 def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> CallResult:
@@ -256,52 +296,183 @@ def run_hot_path_lanes(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBat
     return out, sorted((l for o in out for l in o.lines), key=_vcf_key)
 
 
-def run_stream(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBatch], on_result=None, static: bool = False, **kw) -> List[CallResult]:
+def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, **kw) -> List[CallResult]:
     """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
     next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
     host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
-    MI355X).  The read store is only read, so several entries of `batches` may be the same DeviceBatch.  on_result(i, result) is
-    called on the calling thread in batch order (the place for an ordered collective such as gather_vcf); static deals batch i to
-    lane i % len(ctxs).  -> results in batch order"""
-    import itertools
-    count, lanes = len(batches), len(ctxs)
-    results: List[Optional[CallResult]] = [None] * count
-    done = [threading.Event() for _ in range(count)]
+    MI355X).  `batches` is any iterable of DeviceBatch (the read store is only read, so the same one may come several times) or
+    HostBatch (uploaded by the lane that takes it and freed after its run); an iterator is pulled as lanes come free, so a producer
+    such as bam_batches stays a bounded distance ahead.  on_result(i, result) is called on the calling thread in batch order (the
+    place for an ordered collective such as gather_vcf); static deals batch i to lane i % len(ctxs) (needs a sequence).
+    -> results in batch order"""
+    lanes = len(ctxs)
+    if static:
+        batches = list(batches)
+    results: Dict[int, CallResult] = {}
     errs: List[BaseException] = []
-    nxt, lock = itertools.count(), threading.Lock()
+    source = enumerate(batches)
+    lock, ready = threading.Lock(), threading.Condition()
+    state = {"taken": 0, "exhausted": False}
+
+    def take(k):
+        if static:
+            i = k + lanes * take.round[k]
+            take.round[k] += 1
+            return (i, batches[i]) if i < len(batches) else None
+        with lock:
+            if state["exhausted"]:
+                return None
+            item = next(source, None)
+            if item is None:
+                state["exhausted"] = True
+            else:
+                state["taken"] += 1
+            return item
+    take.round = [0] * lanes
 
     def work(k):
-        mine = iter(range(k, count, lanes))
         while not errs:
-            if static:
-                i = next(mine, count)
-            else:
-                with lock:
-                    i = next(nxt)
-            if i >= count:
-                return
             try:
-                results[i] = run_hot_path(ctxs[k], batches[i], **kw)
+                item = take(k)
+                if item is None:
+                    return
+                i, b = item
+                if isinstance(b, HostBatch):
+                    db = upload_host_batch(ctxs[k], b)
+                    try:
+                        r = run_hot_path(ctxs[k], db, **kw)
+                    finally:
+                        db.free(ctxs[k])
+                else:
+                    r = run_hot_path(ctxs[k], b, **kw)
             except BaseException as e:
                 errs.append(e)
-            done[i].set()
+                with ready:
+                    ready.notify_all()
+                return
+            with ready:
+                results[i] = r
+                ready.notify_all()
 
-    th = [threading.Thread(target=work, args=(k,), name="fsv-lane-%d" % k) for k in range(min(lanes, count))]
+    th = [threading.Thread(target=work, args=(k,), name="fsv-lane-%d" % k) for k in range(lanes)]
     for t in th:
         t.start()
-    for i in range(count):
-        while not done[i].wait(0.05):
-            if errs:
-                break
-        if errs:
+    out: List[CallResult] = []
+    while True:
+        with ready:
+            while len(out) not in results and not errs and any(t.is_alive() for t in th):
+                ready.wait(0.05)
+            r = None if errs else results.pop(len(out), None)
+        if r is None:       # a lane failed, or every lane has finished and there is nothing further
             break
         if on_result is not None:
-            on_result(i, results[i])
+            on_result(len(out), r)
+        out.append(r)
     for t in th:
         t.join()
     if errs:
         raise errs[0]
-    return results
+    return out, sorted((l for o in out for l in o.lines), key=_vcf_key)
+
+
+def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, **kw) -> List[CallResult]:
+    """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
+    next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
+    host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
+    MI355X).  `batches` is any iterable of DeviceBatch (the read store is only read, so the same one may come several times) or
+    HostBatch (uploaded by the lane that takes it and freed after its run); an iterator is pulled as lanes come free, so a producer
+    such as bam_batches stays a bounded distance ahead.  on_result(i, result) is called on the calling thread in batch order (the
+    place for an ordered collective such as gather_vcf); static deals batch i to lane i % len(ctxs) (needs a sequence).
+    -> results in batch order"""
+    lanes = len(ctxs)
+    if static:
+        batches = list(batches)
+    results: Dict[int, CallResult] = {}
+    errs: List[BaseException] = []
+    source = enumerate(batches)
+    lock, ready = threading.Lock(), threading.Condition()
+    state = {"taken": 0, "exhausted": False}
+
+    def take(k):
+        if static:
+            i = k + lanes * take.round[k]
+            take.round[k] += 1
+            return (i, batches[i]) if i < len(batches) else None
+        with lock:
+            if state["exhausted"]:
+                return None
+            item = next(source, None)
+            if item is None:
+                state["exhausted"] = True
+            else:
+                state["taken"] += 1
+            return item
+    take.round = [0] * lanes
+
+    def work(k):
+        while not errs:
+            try:
+                item = take(k)
+                if item is None:
+                    return
+                i, b = item
+                if isinstance(b, HostBatch):
+                    db = upload_host_batch(ctxs[k], b)
+                    try:
+                        r = run_hot_path(ctxs[k], db, **kw)
+                    finally:
+                        db.free(ctxs[k])
+                else:
+                    r = run_hot_path(ctxs[k], b, **kw)
+            except BaseException as e:
+                errs.append(e)
+                with ready:
+                    ready.notify_all()
+                return
+            with ready:
+                results[i] = r
+                ready.notify_all()
+
+    th = [threading.Thread(target=work, args=(k,), name="fsv-lane-%d" % k) for k in range(lanes)]
+    for t in th:
+        t.start()
+    out: List[CallResult] = []
+    while not errs:
+        with ready:
+            while len(out) not in results and not errs and any(t.is_alive() for t in th):
+                ready.wait(0.05)
+            r = results.pop(len(out), None)
+        if r is None:
+            if errs or not any(t.is_alive() for t in th):
+                with ready:
+                    r = results.pop(len(out), None)
+                if r is None:
+                    break
+            else:
+                continue
+        if on_result is not None:
+            on_result(len(out), r)
+        out.append(r)
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    return out
+
+
+def bam_batches(bam_path: str, regions: Sequence[Tuple[str, int, int]], windows: Sequence[Tuple[int, bytes]], batch: int = 256, readers: int = 4):
+    """HostBatches of `batch` regions each, in order, decoded by `readers` host threads (each with its own BAM handle) a bounded
+    distance ahead of the consumer: the BAM decode of the next batches overlaps the GPU work on the current ones"""
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = [(regions[i:i + batch], windows[i:i + batch]) for i in range(0, len(regions), batch)]
+    with ThreadPoolExecutor(max_workers=max(1, readers), thread_name_prefix="fsv-bam") as pool:
+        pending = []
+        nxt = 0
+        while nxt < len(chunks) or pending:
+            while nxt < len(chunks) and len(pending) < max(1, readers):
+                pending.append(pool.submit(read_bam_regions, bam_path, chunks[nxt][0], chunks[nxt][1]))
+                nxt += 1
+            yield pending.pop(0).result()
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU

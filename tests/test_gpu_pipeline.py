@@ -173,3 +173,42 @@ def test_run_stream_equals_sequential(ctx):
         for c in lanes[1:]:
             c.close()
         ba.free(ctx); bb.free(ctx)
+
+
+def test_bam_batches_through_the_lanes(ctx, tmp_path):
+    """BAM + regions -> reader threads (bam_batches) -> lanes (run_stream uploads, runs and frees each HostBatch) -> the calls of the
+    in-memory path, batch by batch in order"""
+    from tests import bam_writer as W
+    rs = _regions([1, 2, 4, 6, 7])
+    recs = []
+    for r in rs:
+        for h in (0, 1):
+            for j, (pos, ops, rev) in enumerate(r.read_aln[h]):
+                seq = r.reads[h][j]
+                recs.append({"ref": 0, "pos": r.start + pos, "mapq": 60, "flag": 16 if rev else 0, "qname": "r%d_h%d_%d" % (r.index, h + 1, j),
+                             "cigar": ops, "seq": (synth.revcomp(seq) if rev else seq).decode(), "tags": [("PS", "I", r.start + 1), ("HP", "C", h + 1)]})
+    recs.sort(key=lambda x: x["pos"])
+    path = W.write_bam(str(tmp_path / "wgs.bam"), [("chr21", 46_000_000)], recs)
+    regions = [(r.chrom, r.start + 1, r.start + len(r.ref)) for r in rs]
+    wins = [(r.start, r.ref) for r in rs]
+    lanes = [ctx, _lib.Context(0)]
+    try:
+        seen = []
+        got = pipeline.run_stream(lanes, pipeline.bam_batches(path, regions, wins, batch=2, readers=2), on_result=lambda i, r: seen.append(i))
+        assert seen == [0, 1, 2] and len(got) == 3
+        for k, res in enumerate(got):
+            part = rs[2 * k: 2 * k + 2]
+            mem = pipeline.upload_regions(ctx, [pipeline.region_from_synth(r) for r in part])
+            try:
+                exp = pipeline.run_hot_path(ctx, mem)
+            finally:
+                mem.free(ctx)
+            assert pipeline.parse_calls(res.lines) == pipeline.parse_calls(exp.lines) and len(res.lines) >= 2 * len(part)
+
+        def failing():
+            yield pipeline.read_bam_regions(path, regions[:1], wins[:1])
+            raise RuntimeError("reader failed")
+        with pytest.raises(RuntimeError):
+            pipeline.run_stream(lanes, failing())
+    finally:
+        lanes[1].close()
