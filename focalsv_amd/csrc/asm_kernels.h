@@ -405,18 +405,23 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         if (i < nq) {
             const uint64_t ah = (uint64_t)av.x | (uint64_t)av.y << 32;
             const uint32_t arev = av.w & 0xffu;
+            // a reverse-strand anchor is kept as hifiasm chains such a pair (Hash_Table.cpp:619-676, x_pos_strand = 1): the query on its
+            // reverse strand -- the k-mer's last base there -- and the target forward; the chain's indel budget runs from that end
+            const uint32_t qrev = (uint32_t)(lenq - 1) - (av.z - ((av.w >> 8) & 0xffu) + 1);
             int l2 = 0, h2 = nt;
             if (t_in_lds) {
                 while (l2 < h2) { int mid = (l2 + h2) >> 1; if (s_th[mid] < ah) l2 = mid + 1; else h2 = mid; }
                 if (l2 < nt && s_th[l2] == ah) {
                     const uint32_t tp = s_tp[l2];
-                    hit = true; key = (uint64_t)av.z << 32 | (tp & 0x7fffffu); aux = (uint16_t)(((tp >> 23) & 0xffu) | ((arev ^ (tp >> 31)) << 8));
+                    const uint32_t srev = arev ^ (tp >> 31);
+                    hit = true; key = (uint64_t)(srev ? qrev : av.z) << 32 | (tp & 0x7fffffu); aux = (uint16_t)(((tp >> 23) & 0xffu) | (srev << 8));
                 }
             } else {
                 while (l2 < h2) { int mid = (l2 + h2) >> 1; if (mt[mid].hash < ah) l2 = mid + 1; else h2 = mid; }
                 if (l2 < nt && mt[l2].hash == ah) {
                     fsv_mz b = mt[l2];
-                    hit = true; key = (uint64_t)av.z << 32 | b.pos; aux = (uint16_t)(b.span | ((arev ^ b.rev) << 8));
+                    const uint32_t srev = arev ^ b.rev;
+                    hit = true; key = (uint64_t)(srev ? qrev : av.z) << 32 | b.pos; aux = (uint16_t)(b.span | (srev << 8));
                 }
             }
         }
@@ -434,19 +439,15 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         for (int base = 0; base < nq; base += 64) { const int i = base + lane; lookup(i, i < nq ? mq4[i] : make_uint4(0, 0, 0, 0)); }
     if (n > AMAX) { if (lane == 0) atomicOr(&A.warn[rq], (uint32_t)FSV_W_ANCHOR_TRUNC); n = AMAX; }
     __syncthreads();
-    // 2. majority strand, strand-corrected te, compaction
+    // 2. majority strand, compaction
     const int rev = nrev > nfwd;
     int m2 = 0;
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         bool keep = false; uint64_t key = 0;
         if (i < n) {
-            uint16_t aux = s_aux[i];
             key = s_key[i];
-            if ((aux >> 8) == rev) {
-                keep = true;
-                if (rev) { int te = (int)(uint32_t)key, span = aux & 0xff; te = (lent - 1) - (te - span + 1); key = (key & 0xffffffff00000000ull) | (uint32_t)te; }
-            }
+            keep = (s_aux[i] >> 8) == rev;
         }
         uint64_t m = __ballot(keep);
         int at = m2 + __popcll(m & ((1ull << lane) - 1));
@@ -457,8 +458,13 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     }
     n = m2;
     if (n < A.min_anchors) { PUT_BOTH(); return; }
-    // 3. anchors are already in query order: q's minimizers were walked by position and both compactions keep the order
-    //    (query positions are distinct, so (qe, te) order == qe order)
+    // 3. anchors are in query order: q's minimizers were walked by position and both compactions keep the order (query positions
+    //    are distinct, so (qe, te) order == qe order) -- for a reverse-strand pair that is decreasing order on the query's reverse
+    //    strand, so the list is turned around
+    if (rev) {
+        for (int i = lane; i < n / 2; i += 64) { const uint64_t a0 = s_key[i], a1 = s_key[n - 1 - i]; s_key[i] = a1; s_key[n - 1 - i] = a0; }
+        __syncthreads();
+    }
     // 4. chain DP: lane l examines predecessor i-1-l (nearest first on ties).
     //    Fast path: when every anchor sits on one diagonal (error-free reads: correction rounds 2, 3 and the final pass)
     //    the DP provably links each anchor to its nearest predecessor -- gap 0 means no indel penalty, and
@@ -567,7 +573,21 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     int xe = (int)(s_key[best] >> 32), ye = (int)(uint32_t)s_key[best];
     { int m = min(xs, ys); xs -= m; ys -= m; int r = min(lenq - 1 - xe, lent - 1 - ye); xe += r; ye += r; }
     if (xe - xs + 1 < A.min_ovlp) { PUT_BOTH(); return; }
-    o.x_s = xs; o.x_e = xe; o.y_s = ys; o.y_e = ye; o.rev = (uint8_t)rev; o.score = s_f[best]; o.n_chain = cnt; o.valid = 1;
+    const int score_best = s_f[best];
+    if (rev) {
+        // everything downstream works with the query forward and the target on its reverse strand: mirror the overlap and every
+        // anchor, and turn the chain list around so that it still runs end-to-start in query order
+        { const int t0 = xs; xs = (lenq - 1) - xe; xe = (lenq - 1) - t0; }
+        { const int t0 = ys; ys = (lent - 1) - ye; ye = (lent - 1) - t0; }
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) {
+            const uint64_t kk = s_key[i];
+            s_key[i] = (uint64_t)(uint32_t)((lenq - 1) - (int)(kk >> 32)) << 32 | (uint32_t)((lent - 1) - (int)(uint32_t)kk);
+        }
+        for (int e = lane; e < cnt / 2; e += 64) { const uint16_t c0 = s_chain[e], c1 = s_chain[cnt - 1 - e]; s_chain[e] = c1; s_chain[cnt - 1 - e] = c0; }
+        __syncthreads();
+    }
+    o.x_s = xs; o.x_e = xe; o.y_s = ys; o.y_e = ye; o.rev = (uint8_t)rev; o.score = score_best; o.n_chain = cnt; o.valid = 1;
     o.n_win = xe / FSV_WINDOW - xs / FSV_WINDOW + 1;
     // mirror: same anchors seen from t; on the reverse strand both coordinates are measured from the other read end
     om.rev = (uint8_t)rev; om.score = o.score; om.n_chain = cnt; om.valid = 1;

@@ -115,6 +115,7 @@ int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, i
         uint8_t *srev = (uint8_t *)malloc((size_t)cap);
         anchor_t *raw = a + cap;
         int32_t *tspan = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+        int32_t *qspan = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
         i = j = 0;
         while (i < nq && j < nt) {
             if (q[i].hash < t[j].hash) i++;
@@ -124,6 +125,7 @@ int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, i
                 raw[n].qe = (int32_t)q[i].pos;
                 raw[n].te = (int32_t)t[j].pos;
                 tspan[n] = t[j].span;
+                qspan[n] = q[i].span;
                 if (srev[n]) nr++; else nf++;
                 n++; i++; j++;
             }
@@ -133,10 +135,15 @@ int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, i
             if (srev[i] != rev) continue;
             a[j].qe = raw[i].qe;
             a[j].te = rev ? (lent - 1) - (raw[i].te - tspan[i] + 1) : raw[i].te;
+            if (rev) {   /* as hifiasm chains a reverse-strand pair: the query on its reverse strand (k-mer ends there), the target
+                          * forward (Hash_Table.cpp:619-676, x_pos_strand = 1) -- the chain's indel budget runs from that end */
+                a[j].qe = (lenq - 1) - (raw[i].qe - qspan[i] + 1);
+                a[j].te = raw[i].te;
+            }
             j++;
         }
         n = j;
-        free(srev); free(tspan);
+        free(srev); free(tspan); free(qspan);
     }
     if (n < P->min_anchors) { free(a); return 0; }
     qsort(a, (size_t)n, sizeof(anchor_t), anchor_cmp);
@@ -165,13 +172,23 @@ int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, i
         int cnt = 0, c;
         for (c = best; c >= 0; c = pre[c]) cnt++;
         if (cnt >= P->min_anchors && cnt <= chain_cap) {
-            int first = best, k2 = cnt;
-            for (c = best; c >= 0; c = pre[c]) { k2--; chain_qe[k2] = a[c].qe; chain_te[k2] = a[c].te; first = c; }
+            int k2 = cnt;
+            for (c = best; c >= 0; c = pre[c]) { k2--; chain_qe[k2] = a[c].qe; chain_te[k2] = a[c].te; }
             {
-                int32_t xs = a[first].qe, ys = a[first].te, xe = a[best].qe, ye = a[best].te, m, r;
+                int32_t xs = chain_qe[0], ys = chain_te[0], xe = chain_qe[cnt - 1], ye = chain_te[cnt - 1], m, r;
                 m = xs < ys ? xs : ys; xs -= m; ys -= m;
                 r = (lenq - 1 - xe) < (lent - 1 - ye) ? (lenq - 1 - xe) : (lent - 1 - ye);
                 xe += r; ye += r;
+                if (rev) {   /* back to the query forward / target on its reverse strand; anchors in query order */
+                    int32_t t0;
+                    t0 = xs; xs = (lenq - 1) - xe; xe = (lenq - 1) - t0;
+                    t0 = ys; ys = (lent - 1) - ye; ye = (lent - 1) - t0;
+                    for (c = 0; c < cnt; c++) { chain_qe[c] = (lenq - 1) - chain_qe[c]; chain_te[c] = (lent - 1) - chain_te[c]; }
+                    for (c = 0; c < cnt / 2; c++) {
+                        t0 = chain_qe[c]; chain_qe[c] = chain_qe[cnt - 1 - c]; chain_qe[cnt - 1 - c] = t0;
+                        t0 = chain_te[c]; chain_te[c] = chain_te[cnt - 1 - c]; chain_te[cnt - 1 - c] = t0;
+                    }
+                }
                 if (xe - xs + 1 >= P->min_ovlp) {
                     memset(o, 0, sizeof(*o));
                     o->x_s = xs; o->x_e = xe; o->y_s = ys; o->y_e = ye; o->rev = (uint8_t)rev;
@@ -769,6 +786,10 @@ int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const o
     }
     n_hit = final_overlaps(&R, P, prev, n_prev, &hits);
     free(prev);
+    if (getenv("ORC_DEBUG_HITS")) {
+        for (i = 0; i < n_hit; i++) fprintf(stderr, "HIT %u %u %d %d %d %d %d %d\n", hits[i].q, hits[i].t, hits[i].x_s, hits[i].x_e + 1,
+            hits[i].rev ? R.len[hits[i].t] - 1 - hits[i].y_e : hits[i].y_s, hits[i].rev ? R.len[hits[i].t] - hits[i].y_s : hits[i].y_e + 1, hits[i].rev, hits[i].exact);
+    }
     piece_read = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 1));
     piece_len = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 1));
     piece_rev = (uint8_t *)malloc((size_t)n_reads + 1);

@@ -27,7 +27,7 @@ def _gold_ids(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
 # 8x per haplotype: some reads keep errors, hifiasm's graph cleaning prefers exact edges around them
 # (asg_arc_del_short_diploid_by_exact and friends, Overlaps.cpp:7179) and this restatement does not: the contig is whole but
 # differs from hifiasm's by a few bases at a junction (561/1: hifiasm drops 10 kb that we keep).  Corrected reads are identical.
-KNOWN_LAYOUT_DEVIATIONS = {(530, 1), (531, 1), (561, 1), (590, 1), (591, 1), (591, 2)}
+KNOWN_LAYOUT_DEVIATIONS = {(531, 1), (561, 1), (590, 1), (591, 2)}
 
 
 # 580/2: one of 96 corrected reads ends one base earlier than hifiasm's (a deletion among the last bases of a read at the window
