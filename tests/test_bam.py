@@ -294,3 +294,59 @@ def test_thread_count_does_not_change_the_result(tmp_path):
             b = bam.fetch("chr1", 30000, 90000)        # a second query on the same handle, while a read-ahead may still be in flight
             out.append((a.names, a.pos.tolist(), a.cigar.tolist(), a.seq_words.tolist(), a.seq_ascii.tobytes(), b.names))
     assert out[0] == out[1] == out[2] and len(out[0][0]) == 150
+
+
+def test_corrupted_records_fail_cleanly(tmp_path):
+    """damage inside the (validly BGZF-wrapped) record stream -- flipped bytes, cut-offs, absurd length fields -- must end in an
+    FsvError or in records, never in a crash: the cases run in a child process so that a fault would show as its exit status"""
+    import struct
+    import subprocess
+    import sys
+    import zlib
+    recs = make_records(5, n=40, ref_lens=(200000,))
+    for r in recs:
+        r["tags"] = [("SA", "Z", "chr1,5,+,100M,60,0;"), ("HP", "C", 1), ("PS", "i", 77), ("xx", "B", ("S", [1, 2, 3]))]
+    base = W.write_bam(str(tmp_path / "base.bam"), [("chr1", 200000)], recs, index=False)
+    raw, stream, p = open(base, "rb").read(), bytearray(), 0
+    while p < len(raw):
+        bs = struct.unpack("<H", raw[p + 16:p + 18])[0] + 1
+        stream += zlib.decompress(raw[p + 18:p + bs - 8], -15)
+        p += bs
+    rng = random.Random(3)
+    paths = []
+    for it in range(40):
+        s = bytearray(stream)
+        mode = rng.random()
+        if mode < 0.6:
+            for _ in range(rng.choice([1, 2, 5, 20])):
+                s[rng.randrange(len(s))] = rng.randrange(256)
+        elif mode < 0.8:
+            s = s[:rng.randrange(1, len(s))]
+        else:
+            i = rng.randrange(len(s) - 8)
+            s[i:i + 4] = struct.pack("<i", rng.choice([-1, 0, 2 ** 31 - 1, -2 ** 31, 70000, 1 << 24]))
+        out = bytearray()
+        for o in range(0, len(s), 0xff00):
+            out += W._bgzf_block(bytes(s[o:o + 0xff00]))
+        out += W._bgzf_block(b"")
+        fn = str(tmp_path / ("c%d.bam" % it))
+        open(fn, "wb").write(bytes(out))
+        paths.append(fn)
+    child = (
+        "import sys\n"
+        "from focalsv_amd import _lib, bam as B\n"
+        "for fn in sys.argv[1:]:\n"
+        "    try:\n"
+        "        with B.BamFile(fn, threads=2) as f:\n"
+        "            for rid in [None] + f.references[:1]:\n"
+        "                r = f.fetch(rid, want_seq=7) if rid else f.fetch(until_eof=True, want_seq=7)\n"
+        "                r.names\n"
+        "                for k in range(min(len(r), 3)):\n"
+        "                    r.segment(k); r.sa_tag(k); r.seq_text(k)\n"
+        "    except (_lib.FsvError, KeyError, ValueError, UnicodeDecodeError, IndexError):\n"
+        "        pass\n"
+        "print('survived')\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", child] + paths, capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
+    assert res.returncode == 0 and "survived" in res.stdout, res.stderr[-500:]
