@@ -18,8 +18,11 @@ def write_reads_bam(path, rs, total):
     for r in rs:
         for h in (0, 1):
             for j, (pos, ops, rev) in enumerate(r.read_aln[h]):
+                need = sum(n for op, n in ops if op in (0, 1, 4))   # the truth CIGAR ignores sequencing errors: fit the bases to it
+                seq = r.reads[h][j]
+                seq = ((synth.revcomp(seq) if rev else seq) + b"A" * need)[:need]
                 recs.append({"ref": 0, "pos": r.start + pos, "mapq": 60, "flag": 16 if rev else 0, "qname": "r%d_h%d_%d" % (r.index, h + 1, j),
-                             "cigar": ops, "seq": ""})
+                             "cigar": ops, "seq": seq.decode()})
     recs.sort(key=lambda x: x["pos"])
     return W.write_bam(path, [("chr21", total)], recs)
 
@@ -60,6 +63,15 @@ def test_region_directories_to_vcf(tmp_path):
     truth_all = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth]
     tp, fp, fn, gt = pipeline.match_truth(pipeline.parse_calls(raw), truth_all, bp_tol=1, len_tol=0.0)
     assert (tp, fp, fn) == (len(truth_all), 0, 0)
+    # step 5 on top: read signatures from the BAM, support filter, genotype correction -> FocalSV_Final_SV.vcf with the same calls
+    final = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "5_post_processing.py"), "-bam", bam, "-d", "Hifi", "-chr", "21", "-o", out],
+                                    env=env).decode().strip().splitlines()[-1]
+    assert final.endswith("FocalSV_Final_SV.vcf")
+    fbody = [l for l in open(final) if l[0] != '#']
+    assert sorted(l.split('\t')[2] for l in fbody) == sorted(l.split('\t')[2] for l in body)
+    assert all(l.split('\t')[-1].strip() in ("0/1", "1/1") for l in fbody)
+    sigs = open(os.path.join(out, "post_processing", "reads_sig", "DEL.sigs")).read().splitlines()
+    assert len(sigs) >= 10 and all(l.split('\t')[0] == "DEL" and l.split('\t')[1] == "chr21" for l in sigs)
 
 
 def test_unphased_region_goes_to_both_haplotypes(tmp_path):
