@@ -263,6 +263,21 @@ def main():
             "hbm_roofline_whole_path": {"GBps": round((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) * args.steps / dt / 1e9 * 1.0, 3), "frac": round((a.get("algo_bytes", 0) + l.get("algo_bytes", 0)) * args.steps / dt / 8e12, 6)},
             "roofline": roof,
         }
+        # the boundary takes host buffers: what the H2D copy of the read store adds when it is not overlapped (never part of `value`)
+        try:
+            words = batches[0].packed.words
+            ups = []
+            for _ in range(4):
+                t_u = time.perf_counter()
+                ptr = ctxs[0].upload(words)
+                ctxs[0].sync()
+                ups.append(time.perf_counter() - t_u)
+                ctxs[0].dev_free(ptr)
+            up_ms = min(ups) * 1e3 * (1 if by_steps or lanes == 1 else lanes)
+            out["h2d"] = {"store_MB": round(words.nbytes * (1 if by_steps or lanes == 1 else lanes) / 1e6, 1), "ms_per_step": round(up_ms, 2),
+                          "regions_per_s_with_serial_upload": round(world * n / (dt / args.steps + up_ms * 1e-3), 1)}
+        except Exception as e:   # a measurement extra: never let it take the bench line down
+            out["h2d"] = {"error": str(e)}
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 0)
         print(json.dumps(out))
