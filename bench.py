@@ -42,9 +42,9 @@ def cpu_baseline(n_regions, first_index):
     ref = WindowedRef()
     for r in regions:
         ref.add(r.start, r.ref.decode())
-    call_chromosome(recs, "chr21", ref, contig_seq, 'CCS')
+    _, cpu_body = call_chromosome(recs, "chr21", ref, contig_seq, 'CCS')
     dt = time.perf_counter() - t0
-    out = {"value": round(n_regions / dt, 4), "unit": "regions/s", "cores": 1, "kind": "port",
+    out = {"_raw_lines": cpu_body, "value": round(n_regions / dt, 4), "unit": "regions/s", "cores": 1, "kind": "port",
            "sample": f"{n_regions} of the bench's regions (indices {first_index}..{first_index + n_regions - 1}), oracle/ C restatement, {dt:.1f} s"}
     hifiasm = os.path.join(ROOT, "oracle", "_ref", "hifiasm-0.14")
     if os.path.exists(hifiasm):
@@ -279,7 +279,19 @@ def main():
         except Exception as e:   # a measurement extra: never let it take the bench line down
             out["h2d"] = {"error": str(e)}
         if args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 0)
+            cb = cpu_baseline(args.cpu_sample, 0)
+            # SV calls of the GPU path against the CPU path (oracle contigs + oracle alignments + the same host logic) on the sampled
+            # regions, before the read-support filter on both sides: +-1 bp breakpoint, +-2 % SVLEN, same type (north_star)
+            cpu_lines = cb.pop("_raw_lines")
+            cpu_calls = pipeline.parse_calls(cpu_lines)
+            lim = args.cpu_sample * 60000
+            gpu_calls = [c for c in pipeline.parse_calls(res.raw_lines) if c["pos"] < lim] if rank == 0 and idx0 == 0 else []
+            as_truth = [(c["chrom"], c["type"], c["pos"], c["svlen"], c["gt"]) for c in cpu_calls]
+            tpc, fpc, fnc, gtc = pipeline.match_truth(gpu_calls, as_truth, bp_tol=1, len_tol=0.02, left_shift_ok=0)
+            out["sv_vs_cpu_path"] = {"regions": args.cpu_sample, "cpu_calls": len(cpu_calls), "gpu_calls": len(gpu_calls), "tp": tpc, "fp": fpc, "fn": fnc,
+                                     "gt_ok": gtc, "f1": round(2 * tpc / max(1, 2 * tpc + fpc + fnc), 4),
+                                     "identical_vcf_text": [l for l in res.raw_lines if int(l.split('\t')[1]) < lim] == cpu_lines}
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
     fence()
     for b_ in batches:
