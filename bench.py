@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "3")), help="concurrent lanes per GPU (contexts / streams / host threads)")
     ap.add_argument("--lane-mode", choices=["split", "steps"], default=os.environ.get("FSV_BENCH_LANE_MODE", "steps"),
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
+    ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
     ap.add_argument("--cpu-sample", type=int, default=8, help="regions the CPU baseline runs (0 = skip)")
     args = ap.parse_args()
 
@@ -145,7 +146,7 @@ def main():
         def gathered(i, r):
             last[0] = pipeline.gather_vcf(list(r.lines)) if world > 1 else list(r.lines)
 
-        results = pipeline.run_stream(ctxs, [batches[0]] * count, on_result=gathered, static=static)
+        results = pipeline.run_stream(ctxs, [batches[0]] * count, on_result=gathered, static=static, stagger=0.0 if static else args.stagger)
         return results, last[0]
 
     def fence():

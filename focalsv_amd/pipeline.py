@@ -175,7 +175,8 @@ def upload_bam_regions(ctx: _lib.Context, bam_path: str, regions: Sequence[Tuple
     return upload_host_batch(ctx, read_bam_regions(bam_path, regions, windows))
 
 
-def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> CallResult:
+def launch_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> "PendingCall":
+    """the GPU half of run_hot_path; .finish() on the result gives the CallResult"""
     regions, pk = batch.regions, batch.packed
     chroms = sorted({r.chrom for r in regions}, key=lambda c: (len(c), c))
     # the read-side evidence (reads_signature) does not depend on the contigs: a host thread extracts it while the GPU
@@ -202,16 +203,38 @@ def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', 
     t_enter = time.perf_counter()
     side = threading.Thread(target=_read_side, name="fsv-read-signatures")
     side.start()
+    stages = _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err)
     try:
-        res = _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err)
-        res.host_ms["total"] = round((time.perf_counter() - t_enter) * 1e3, 2)
-        return res
-        return _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err)
-    finally:
+        next(stages)          # the GPU half: assembly and contig alignment
+    except BaseException:
         side.join()
+        raise
+    return PendingCall(stages, side, t_enter)
 
 
-def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err) -> CallResult:
+class PendingCall:
+    """a batch whose GPU half (assembly, contig alignment) is done; finish() runs the host half -- alignment records, signatures,
+    VCF, read-support filter, redundancy -- on whatever thread calls it, so a lane can go on with its next batch meanwhile"""
+
+    def __init__(self, stages, side, t_enter):
+        self._stages, self._side, self._t_enter = stages, side, t_enter
+
+    def finish(self) -> CallResult:
+        try:
+            res = next(self._stages)
+            res.host_ms["total"] = round((time.perf_counter() - self._t_enter) * 1e3, 2)
+            return res
+        finally:
+            self._stages.close()
+            self._side.join()
+
+
+def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> CallResult:
+    return launch_hot_path(ctx, batch, data_type, asm_params, aln_params).finish()
+
+
+def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err):
+    """generator of two stages: everything that needs the GPU context (then yields None), then the host logic (yields the CallResult)"""
     host_ms, t_prev = {}, [time.perf_counter()]
 
     def lap(name):
@@ -249,6 +272,8 @@ def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, ch
     rec, cigar, contig_status = ctx.align_batch(None, cref, batch.refs or [r.ref for r in regions], aln_params) if len(contigs) else (np.zeros(0, _lib.ALN_REC_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.int32))
     aln_stats = ctx.aln_stats() if len(contigs) else {}
     lap("align_call")
+    yield None
+    t_prev[0] = time.perf_counter()
     records = records_from_alignment(rec, cigar, names, [regions[i].chrom for i in cref], [regions[i].start for i in cref])
     contig_seq = _ContigText(names, contigs)
     raw, final = [], []
@@ -265,7 +290,7 @@ def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, ch
     lap("fp_filter")
     header, final, dropped = redundancy.collapse(vcf.HEADER_LINES, kept)
     lap("redundancy")
-    return CallResult(header, final, raw, contigs, cref, chp, set_status, contig_status, asm_stats, aln_stats, host_ms)
+    yield CallResult(header, final, raw, contigs, cref, chp, set_status, contig_status, asm_stats, aln_stats, host_ms)
 
 
 def run_hot_path_lanes(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBatch], **kw) -> Tuple[List[CallResult], List[str]]:
@@ -296,7 +321,8 @@ def run_hot_path_lanes(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBat
     return out, sorted((l for o in out for l in o.lines), key=_vcf_key)
 
 
-def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, **kw) -> List[CallResult]:
+def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, stagger: float = 0.0, host_workers: int = 1,
+               **kw) -> List[CallResult]:
     """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
     next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
     host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
@@ -304,7 +330,10 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     HostBatch (uploaded by the lane that takes it and freed after its run); an iterator is pulled as lanes come free, so a producer
     such as bam_batches stays a bounded distance ahead.  on_result(i, result) is called on the calling thread in batch order (the
     place for an ordered collective such as gather_vcf); static deals batch i to lane i % len(ctxs) (needs a sequence).
-    -> results in batch order"""
+    stagger: lane k waits k x stagger seconds before its first batch -- lanes started together run in lockstep (all in their GPU
+    stretch, then all in their host stretch, the GPU idle meanwhile); out of phase, one lane's host stretch falls into the others'
+    GPU stretches.  A lane only does the GPU half of a batch (launch_hot_path); the host half (PendingCall.finish: records, signatures,
+    VCF, filters) runs on `host_workers` other threads, so the lane is back on the GPU at once.  -> results in batch order"""
     lanes = len(ctxs)
     if static:
         batches = list(batches)
@@ -330,7 +359,12 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
             return item
     take.round = [0] * lanes
 
+    import queue
+    pend_q: "queue.Queue" = queue.Queue(maxsize=2 * lanes)
+
     def work(k):
+        if stagger > 0 and k:
+            time.sleep(k * stagger)
         while not errs:
             try:
                 item = take(k)
@@ -340,42 +374,79 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
                 if isinstance(b, HostBatch):
                     db = upload_host_batch(ctxs[k], b)
                     try:
-                        r = run_hot_path(ctxs[k], db, **kw)
+                        pend = launch_hot_path(ctxs[k], db, **kw)
                     finally:
                         db.free(ctxs[k])
                 else:
-                    r = run_hot_path(ctxs[k], b, **kw)
+                    pend = launch_hot_path(ctxs[k], b, **kw)
+                pend_q.put((i, pend))
             except BaseException as e:
                 errs.append(e)
                 with ready:
                     ready.notify_all()
                 return
+
+    def finisher():
+        # the host half of every batch, off the lanes' critical path: a lane is back on the GPU with its next batch meanwhile
+        while True:
+            item = pend_q.get()
+            if item is None:
+                return
+            i, pend = item
+            try:
+                r = pend.finish()
+            except BaseException as e:
+                errs.append(e)
+                r = None
             with ready:
-                results[i] = r
+                if r is not None:
+                    results[i] = r
                 ready.notify_all()
 
     th = [threading.Thread(target=work, args=(k,), name="fsv-lane-%d" % k) for k in range(lanes)]
-    for t in th:
+    fin = [threading.Thread(target=finisher, name="fsv-host-%d" % k) for k in range(max(1, host_workers))]
+    for t in th + fin:
         t.start()
+
+    def closer():   # when every lane is through, tell the finishers
+        for t in th:
+            t.join()
+        for _ in fin:
+            pend_q.put(None)
+    cl = threading.Thread(target=closer, name="fsv-closer")
+    cl.start()
     out: List[CallResult] = []
     while True:
         with ready:
-            while len(out) not in results and not errs and any(t.is_alive() for t in th):
+            while len(out) not in results and not errs and any(t.is_alive() for t in fin):
                 ready.wait(0.05)
             r = None if errs else results.pop(len(out), None)
-        if r is None:       # a lane failed, or every lane has finished and there is nothing further
+        if r is None:       # something failed, or every batch has been finished and handed out
             break
         if on_result is not None:
             on_result(len(out), r)
         out.append(r)
-    for t in th:
+    if errs:                # unblock lanes waiting on a full queue, then drain
+        while any(t.is_alive() for t in th + fin):
+            try:
+                item = pend_q.get(timeout=0.05)
+                if item is not None:
+                    try:
+                        item[1].finish()
+                    except BaseException:
+                        pass
+            except queue.Empty:
+                pass
+    cl.join()
+    for t in th + fin:
         t.join()
     if errs:
         raise errs[0]
     return out, sorted((l for o in out for l in o.lines), key=_vcf_key)
 
 
-def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, **kw) -> List[CallResult]:
+def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, stagger: float = 0.0, host_workers: int = 1,
+               **kw) -> List[CallResult]:
     """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
     next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
     host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
@@ -383,7 +454,10 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     HostBatch (uploaded by the lane that takes it and freed after its run); an iterator is pulled as lanes come free, so a producer
     such as bam_batches stays a bounded distance ahead.  on_result(i, result) is called on the calling thread in batch order (the
     place for an ordered collective such as gather_vcf); static deals batch i to lane i % len(ctxs) (needs a sequence).
-    -> results in batch order"""
+    stagger: lane k waits k x stagger seconds before its first batch -- lanes started together run in lockstep (all in their GPU
+    stretch, then all in their host stretch, the GPU idle meanwhile); out of phase, one lane's host stretch falls into the others'
+    GPU stretches.  A lane only does the GPU half of a batch (launch_hot_path); the host half (PendingCall.finish: records, signatures,
+    VCF, filters) runs on `host_workers` other threads, so the lane is back on the GPU at once.  -> results in batch order"""
     lanes = len(ctxs)
     if static:
         batches = list(batches)
@@ -410,6 +484,8 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     take.round = [0] * lanes
 
     def work(k):
+        if stagger > 0 and k:
+            time.sleep(k * stagger)
         while not errs:
             try:
                 item = take(k)
