@@ -78,12 +78,13 @@ def sum_stats(dicts):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=256, help="regions per GPU (BASELINE.json configs[1]: 256)")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "3")), help="concurrent lanes per GPU (contexts / streams / host threads)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "5")), help="concurrent lanes per GPU (contexts / streams / host threads)")
     ap.add_argument("--lane-mode", choices=["split", "steps"], default=os.environ.get("FSV_BENCH_LANE_MODE", "steps"),
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
+    ap.add_argument("--heavy-slots", type=int, default=int(os.environ.get("FSV_BENCH_HEAVY_SLOTS", "3")), help="lanes allowed in the assembly at once (0 = all)")
     ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
     ap.add_argument("--cpu-sample", type=int, default=8, help="regions the CPU baseline runs (0 = skip)")
     args = ap.parse_args()
@@ -146,7 +147,7 @@ def main():
         def gathered(i, r):
             last[0] = pipeline.gather_vcf(list(r.lines)) if world > 1 else list(r.lines)
 
-        results = pipeline.run_stream(ctxs, [batches[0]] * count, on_result=gathered, static=static, stagger=0.0 if static else args.stagger)
+        results = pipeline.run_stream(ctxs, [batches[0]] * count, on_result=gathered, static=static, stagger=0.0 if static else args.stagger, heavy_slots=args.heavy_slots)
         return results, last[0]
 
     def fence():
@@ -156,9 +157,13 @@ def main():
         if world > 1:
             dist.barrier()
 
+    priming = 0
     if by_steps:
-        if args.warmup:
-            run_steps(args.warmup, static=True)
+        # every lane allocates its workspace on its first batch: with fewer warm-up steps than lanes the rest are primed here,
+        # untimed like the upload (reported as lane_priming_steps)
+        priming = max(0, lanes - args.warmup)
+        if args.warmup + priming:
+            run_steps(args.warmup + priming, static=True)
     else:
         for _ in range(args.warmup):
             step()
@@ -249,12 +254,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{n} synthetic 50 kb regions per GPU, 30x HiFi-like reads U(10k,20k), 0.2% error, seed 1000+i "
-                                   "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather; {lanes} concurrent lanes (streams) per GPU, " + ("each taking whole steps (one batch in flight per lane)" if by_steps else "each half of every step's batch")},
+                                   "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather; {lanes} concurrent lanes (streams) per GPU, " + (f"each taking whole steps (one batch in flight per lane, at most {args.heavy_slots or lanes} in the assembly at once)" if by_steps else "each half of every step's batch")},
             "sv_vs_truth": {"truth": len(truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok, "tp_within_1bp_of_left_aligned_truth": tp1},
             "stage_ms": {k: round(v, 2) for k, v in a.items() if k.startswith("ms_")},
             "kernel_ms": {k: [round(v["ms"], 2), int(round(v["launches"]))] for k, v in kern.items()},
             "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},
-            "lanes": lanes, "lane_mode": args.lane_mode if lanes > 1 else "single",
+            "lanes": lanes, "lane_mode": args.lane_mode if lanes > 1 else "single", "assembly_slots": args.heavy_slots if by_steps else 0,
+            "lane_priming_steps": priming,
             "host_ms": res.host_ms,
             # companion compute figure: banded DP column-steps of K5 + K6 (windows x their x_len, 31-row bands)
             "dp": {"column_steps_per_step": int(a.get("dp_columns", 0)), "windows_per_step": int(a.get("n_windows", 0)),
