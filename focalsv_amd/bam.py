@@ -64,6 +64,35 @@ class FetchedRecords:
     def __len__(self):
         return len(self.pos)
 
+    def long_indel_records(self, min_len=30) -> np.ndarray:
+        """bool per record: its CIGAR holds an I or D of at least min_len (works on subsets: the CIGAR buffer may be shared)"""
+        key = "_long_pre_%d" % min_len
+        pre = getattr(self, key, None)
+        if pre is None:
+            ops, lens = self.cigar & 0xf, self.cigar >> 4
+            pre = np.concatenate([[0], np.cumsum(((ops == 1) | (ops == 2)) & (lens >= min_len))]).astype(np.int64)
+            setattr(self, key, pre)
+        off = self.cigar_off.astype(np.int64)
+        return pre[off + self.n_cigar_op.astype(np.int64)] - pre[off] > 0
+
+    def subset(self, idx) -> "FetchedRecords":
+        """the records idx (in that order) as a FetchedRecords of their own: the per-record arrays are gathered, the CIGAR / name / base
+        / SA buffers stay shared (the offsets keep pointing into them)"""
+        idx = np.asarray(idx, dtype=np.int64)
+        o = FetchedRecords.__new__(FetchedRecords)
+        o.chrom, o.ref_names = self.chrom, self.ref_names
+        for f in ("pos", "ref_end", "flag", "mapq", "cigar_off", "n_cigar_op", "qname_off", "l_seq", "ref_id", "ps", "hp"):
+            setattr(o, f, getattr(self, f)[idx])
+        for f in ("seq_word_off", "seq_ascii_off", "sa_off"):
+            a = getattr(self, f)
+            setattr(o, f, a[idx] if len(a) else a)
+        o.cigar, o.qname_buf, o.seq_words, o.seq_ascii, o.sa_buf = self.cigar, self.qname_buf, self.seq_words, self.seq_ascii, self.sa_buf
+        o._names = [self._names[i] for i in idx] if self._names is not None else None
+        for k, v in self.__dict__.items():
+            if k.startswith("_long_pre_"):
+                setattr(o, k, v)       # the prefix sums over the shared CIGAR buffer
+        return o
+
     @property
     def names(self) -> List[str]:
         if self._names is None:

@@ -132,8 +132,27 @@ def read_bam_regions(bam_path: str, regions: Sequence[Tuple[str, int, int]], win
     inputs, packs, set_region, set_kind = [], [], [], []
     f = bam or B.BamFile(bam_path)
     try:
+        # many regions of one chromosome: one pass over the span they cover (the reader inflates ahead on its threads) and a cut per
+        # region on the position-sorted records, instead of a seek and a cold read-ahead per region
+        stream: Dict[str, tuple] = {}
+        by_chrom: Dict[str, list] = {}
+        for chrom, start, end in regions:
+            by_chrom.setdefault(chrom, []).append((start, end))
+        for chrom, spans in by_chrom.items():
+            lo, hi = min(s for s, _ in spans) - 1, max(e for _, e in spans)
+            if len(spans) >= 4 and sum(e - s + 1 for s, e in spans) * 4 >= hi - lo:     # dense enough to be worth reading it all
+                big = f.fetch(chrom, lo, hi, want_seq=1)
+                big.names, big.long_indel_records(30)     # decoded / scanned once, shared by the subsets
+                stream[chrom] = (big, int((big.ref_end - big.pos).max()) if len(big) else 0)
         for ri, ((chrom, start, end), (wstart, ref)) in enumerate(zip(regions, windows)):
-            recs = f.fetch(chrom, start - 1, end, want_seq=1)
+            if chrom in stream:
+                big, longest = stream[chrom]
+                a = int(np.searchsorted(big.pos, start - 1 - longest, 'left'))
+                b = int(np.searchsorted(big.pos, end, 'left'))
+                keep = np.nonzero((big.ref_end[a:b] > start - 1) & ((big.flag[a:b] & 4) == 0))[0] + a
+                recs = big.subset(keep)
+            else:
+                recs = f.fetch(chrom, start - 1, end, want_seq=1)
             files = OF.read_set_files(recs)
             sets = []
             for fn in sorted(files):
@@ -152,11 +171,7 @@ def _signature_records(recs) -> List[S.AlignedSegment]:
     n = len(recs)
     if n == 0:
         return []
-    k = int(recs.n_cigar_op.sum())
-    ops, lens = recs.cigar[:k] & 0xf, recs.cigar[:k] >> 4
-    long_op = np.nonzero(((ops == 1) | (ops == 2)) & (lens >= 30))[0]
-    use = np.zeros(n, bool)
-    use[np.searchsorted(recs.cigar_off, long_op, 'right') - 1] = True
+    use = recs.long_indel_records(30).copy()
     names = recs.names
     if len(set(names)) != n:
         seen: Dict[str, int] = {}

@@ -168,10 +168,7 @@ def scan_chromosome(bamfile, chrom, out=None, **kw):
     n = len(recs)
     if n == 0:
         return out
-    ops, lens = recs.cigar[:int(recs.n_cigar_op.sum())] & 0xf, recs.cigar[:int(recs.n_cigar_op.sum())] >> 4
-    long_op = np.nonzero(((ops == 1) | (ops == 2)) & (lens >= sv_size))[0]
-    has = np.zeros(n, bool)
-    has[np.searchsorted(recs.cigar_off, long_op, 'right') - 1] = True
+    has = recs.long_indel_records(sv_size).copy()
     sa_len = np.diff(np.concatenate([recs.sa_off, [len(recs.sa_buf)]]).astype(np.int64)) - 1
     has |= sa_len > 0
     names = recs.names

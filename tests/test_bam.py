@@ -350,3 +350,36 @@ def test_corrupted_records_fail_cleanly(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", child] + paths, capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
     assert res.returncode == 0 and "survived" in res.stdout, res.stderr[-500:]
+
+
+def test_streamed_region_cut_equals_per_region_fetch(tmp_path):
+    """pipeline.read_bam_regions reads a dense run of regions in one pass and cuts it per region: same read sets, same packed
+    bases, same signature records as one fetch per region (host only, no GPU)"""
+    import numpy as np
+    from focalsv_amd import pipeline, synth
+    rs = [synth.make_region(40 + i, width=14000, start=i * 20000) for i in range(6)]
+    recs = []
+    for r in rs:
+        for h in (0, 1):
+            for j, (pos, ops, rev) in enumerate(r.read_aln[h]):
+                seq = r.reads[h][j]
+                recs.append({"ref": 0, "pos": r.start + pos, "mapq": 60, "flag": 16 if rev else 0, "qname": "r%d_h%d_%d" % (r.index, h + 1, j),
+                             "cigar": ops, "seq": (synth.revcomp(seq) if rev else seq).decode(), "tags": [("PS", "I", r.start + 1), ("HP", "C", h + 1)]})
+    recs.sort(key=lambda x: x["pos"])
+    path = W.write_bam(str(tmp_path / "wgs.bam"), [("chr21", 1_000_000)], recs)
+    regions = [(r.chrom, r.start + 1, r.start + len(r.ref)) for r in rs]
+    wins = [(r.start, r.ref) for r in rs]
+    streamed = pipeline.read_bam_regions(path, regions, wins)
+    single = [pipeline.read_bam_regions(path, regions[i:i + 1], wins[i:i + 1]) for i in range(len(rs))]
+    assert streamed.set_kind == [1, 2] * len(rs) and streamed.set_region == [i for i in range(len(rs)) for _ in (0, 1)]
+    w0 = r0 = 0
+    for i, one in enumerate(single):
+        n, nr = int(one.packed.word_off[-1]), one.packed.n_reads
+        assert np.array_equal(streamed.packed.words[w0:w0 + n], one.packed.words[:n])
+        assert np.array_equal(streamed.packed.read_len[r0:r0 + nr], one.packed.read_len)
+        key = lambda x: (x.qname, x.pos, x.reference_end, x.cigar, x.is_reverse, x.mapq)
+        assert [key(x) for x in streamed.regions[i].read_records] == [key(x) for x in one.regions[0].read_records]
+        assert [int(x) for x in np.diff(one.packed.set_start)] == [len(rs[i].reads[0]), len(rs[i].reads[1])]
+        w0 += n
+        r0 += nr
+    assert sum(len(r.read_records) for r in streamed.regions) > 20
