@@ -2,7 +2,7 @@
 pysam.AlignmentFile(...).fetch(chr) (extract_reads_signature.py:68-105, 160-209) and `samtools view bam region`
 (1_crop_bam.py:74), without either tool."""
 import ctypes as C
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 
