@@ -352,12 +352,193 @@ def final_vcf(filtered_vcf, parts, out_path):
     return out_path
 
 
-def filter_gt_correct(bam_file, out_dir, chr_num, sigdir, data_type='Hifi'):
-    """FocalSV_Filter_GT_Correct.py for HiFi data with pre-extracted read signatures: reads
-    <out_dir>/SV/chr<N>/final_vcf/dippav_variant_no_redundancy.vcf, works in <out_dir>/post_processing/, writes
-    <out_dir>/FocalSV_Final_SV.vcf"""
+# ------------------------------------------------------------------------------------------------ CLR / ONT: genotypes from the read-based draft
+def _load_nonref(vcf_file):
+    """GT_impute.load_vcf: records without '0/0' anywhere in the line, per chromosome, sorted by position (stable)"""
+    header, dc = [], defaultdict(list)
+    with open(vcf_file) as f:
+        for line in f:
+            if line[0] == '#':
+                header.append(line)
+            elif '0/0' not in line:
+                data = line.split()
+                svlen = abs(int(data[7].split('SVLEN=')[1].split(';')[0]))
+                svtype = data[7].split('SVTYPE=')[1].split(';')[0]
+                dc[data[0]].append([int(data[1]), svlen, data[-1].split(':')[0], svtype, line])
+    for chrom in dc:
+        dc[chrom] = sorted(dc[chrom], key=lambda x: x[0])
+    return dc, header
+
+
+def gt_impute(vcf_cand, vcf_gt, outfile, dist_thresh=1000, sim_thresh=0.5):
+    """GT_impute.py: every candidate takes the genotype of the read-based draft call of the same type within dist_thresh whose
+    length is most similar (ratio >= sim_thresh; ties: the smaller signed distance); candidates without one keep theirs.  The scan
+    over the draft calls resumes, for each candidate, at the first one the previous candidate had within reach."""
+    dc_cand, header = _load_nonref(vcf_cand)
+    dc_gt, _ = _load_nonref(vcf_gt)
+    for chrom, cands in dc_cand.items():
+        gts = dc_gt[chrom] if chrom in dc_gt else []
+        start_i = 0
+        for cand in cands:
+            matches, moved = [], False
+            for i in range(start_i, len(gts)):
+                g = gts[i]
+                d = cand[0] - g[0]
+                sim = min(cand[1], g[1]) / max(cand[1], g[1])
+                if abs(d) <= dist_thresh and not moved:
+                    start_i, moved = i, True
+                if abs(d) <= dist_thresh and sim >= sim_thresh and cand[3] == g[3]:
+                    matches.append([sim, d, g[2]])
+                if g[0] - cand[0] > dist_thresh:
+                    break
+            if matches:
+                cand[2] = sorted(matches, key=lambda x: (-x[0], x[1]))[0][2]
+    with open(outfile, 'w') as f:
+        f.writelines(header)
+        for cands in dc_cand.values():
+            for pos, svlen, gt, svtype, line in cands:
+                data = line.split()
+                data[-1] = gt
+                f.write('\t'.join(data) + '\n')
+    return outfile
+
+
+def _load_ins(vcffile):
+    """match_sv.load_vcf: PASS insertions of 30 bp .. 50 kb per (chromosome, type), in file order"""
+    import gzip
+    dc, header = defaultdict(list), []
+    with (gzip.open(vcffile, 'rt') if vcffile.endswith('.gz') else open(vcffile)) as f:
+        for line in f:
+            if line[0] == '#':
+                header.append(line)
+            elif 'SVTYPE=INS' in line:
+                data = line.split()
+                svtype = data[7].split('SVTYPE=')[1].split(';')[0]
+                svlen = abs(int(data[7].split('SVLEN=')[1].split(';')[0]))
+                if 30 <= svlen <= 50e3 and data[6] == 'PASS':
+                    dc[(data[0], svtype)].append([int(data[1]), svlen, line])
+    return dc, header
+
+
+def match_union_ins(comp_vcf, ref_vcf, outfile):
+    """match_sv.match_union_ins: for every insertion of the read-based draft (ref_vcf) the assembly-based call (comp_vcf) within
+    200 bp -- the longest when there are several -- stands in for it, keeping the draft's genotype; a draft insertion without one
+    stays.  Output: the draft's header without its last line, the candidate file's header, the records per chromosome by position."""
+    dc_ref, header_ref = _load_ins(ref_vcf)
+    dc_comp, header_comp = _load_ins(comp_vcf)
+    lines = []
+    for key, refs in dc_ref.items():
+        if key not in dc_comp:
+            continue
+        comps = dc_comp[key]
+        start_i, picked = 0, []
+        for ref in refs:
+            near, first = [], True
+            for i in range(start_i, len(comps)):
+                dist = abs(comps[i][0] - ref[0])
+                if dist <= 200:
+                    near.append((dist, comps[i]))
+                    if first:
+                        start_i, first = i, False
+                elif comps[i][0] - ref[0] > 200:
+                    break
+            ref_gt = ref[2].split('\t')[-1].split(':')[0]
+            if len(near) > 1:
+                opt = sorted(near, key=lambda x: x[1][1])[-1][1]
+            elif near:
+                opt = near[0][1]
+            else:
+                opt = ref
+            data = opt[2].split('\t')
+            data[-1] = ref_gt
+            opt[2] = '\t'.join(data) + '\n'     # in place, as the reference: a candidate picked twice carries the last genotype
+            picked.append(opt)
+        lines += [sv[-1] for sv in sorted(picked, key=lambda x: x[0])]
+    with open(outfile, 'w') as f:
+        f.writelines(header_ref[:-1] + header_comp + lines)
+    return outfile
+
+
+def vcf_to_bed(input_vcf, output_bed, flank=100, svlen_threshold=30):
+    """ONT_var_process.vcf_to_bed: +-flank around every draft call of at least 30 bp on chr1 .. chr22"""
+    with open(input_vcf) as vcf, open(output_bed, 'w') as bed:
+        for line in vcf:
+            if line.startswith('#'):
+                continue
+            cols = line.strip().split('\t')
+            chrom, pos = cols[0], int(cols[1])
+            if chrom.startswith('chr') and chrom[3:].isdigit() and 1 <= int(chrom[3:]) <= 22:
+                info = {k: v for k, v in (fld.split('=') for fld in cols[7].split(';') if '=' in fld)}
+                if abs(int(info.get('SVLEN', 0))) >= svlen_threshold:
+                    bed.write("%s\t%d\t%d\n" % (chrom, max(pos - flank, 0), pos + flank))
+    return output_bed
+
+
+def filter_del_by_bed(invcf, bedfile):
+    """ONT_var_process.filter_vcf_by_bed_del without bgzip / tabix / bcftools: the header and the lines holding 'DEL'
+    (`grep '#\\|DEL'`), of which `bcftools view -R bed` keeps the records that overlap a BED interval -- a record spans POS ..
+    POS + len(REF) - 1, an interval start+1 .. end -- each once -> <invcf stem>_del_filter.vcf"""
+    from bisect import bisect_right
+    beds = defaultdict(list)
+    for line in open(bedfile):
+        c, s0, e0 = line.split()[:3]
+        beds[c].append((int(s0) + 1, int(e0)))
+    merged = {}
+    for c, iv in beds.items():
+        iv.sort()
+        out = []
+        for s0, e0 in iv:
+            if out and s0 <= out[-1][1] + 1:
+                out[-1][1] = max(out[-1][1], e0)
+            else:
+                out.append([s0, e0])
+        merged[c] = (out, [x[0] for x in out])
+    stem = invcf.replace(".vcf", '')
+    outfile = stem + "_del_filter.vcf"
+    with open(invcf) as f, open(outfile, 'w') as fo:
+        for line in f:
+            if line[0] == '#':
+                fo.write(line)
+            elif 'DEL' in line:
+                cols = line.split('\t')
+                c, pos = cols[0], int(cols[1])
+                end = pos + len(cols[3]) - 1
+                if c in merged:
+                    iv, starts = merged[c]
+                    k = bisect_right(starts, end) - 1
+                    if k >= 0 and iv[k][1] >= pos:
+                        fo.write(line)
+    return outfile
+
+
+def final_process_ont(infile, reads_draft_vcf, outfile):
+    """ONT_var_process.final_process_ont: insertions united with the draft's, deletions kept where the draft has a call within
+    100 bp, `(cat ins; grep -v '^#' del) | vcf-sort`"""
+    ins_vcf = infile.replace(".vcf", '_ins_union.vcf')
+    bed_file = reads_draft_vcf.replace(".vcf", "_chr1_22_gte30.bed")
+    match_union_ins(infile, reads_draft_vcf, ins_vcf)
+    vcf_to_bed(reads_draft_vcf, bed_file)
+    del_vcf = filter_del_by_bed(infile, bed_file)
+    header = [l for l in open(ins_vcf) if l[0] == '#']
+    body = [l for l in open(ins_vcf) if l[0] != '#'] + [l for l in open(del_vcf) if l[0] != '#']
+    body.sort(key=lambda l: (l.split('\t', 2)[0], int(l.split('\t', 2)[1]), l))
+    with open(outfile, 'w') as f:
+        f.writelines(header)
+        f.writelines(body)
+    return outfile
+
+
+def filter_gt_correct(bam_file, out_dir, chr_num, sigdir, data_type='Hifi', draft_vcf=None):
+    """FocalSV_Filter_GT_Correct.py: reads <out_dir>/SV/chr<N>/final_vcf/dippav_variant_no_redundancy.vcf, works in
+    <out_dir>/post_processing/, writes <out_dir>/FocalSV_Final_SV.vcf.  HiFi: read signatures (from the BAM, or sigdir), support
+    filter, genotype correction.  CLR / ONT: support filter, then the genotypes (and for ONT the insertion union / deletion filter)
+    of the read-based draft calls -- draft_vcf, or <sigdir>/reads_draft_variants.vcf: the clustering / genotyping half of
+    Reads_Based_Scan that writes it is not built here."""
+    assert data_type in ('Hifi', 'CLR', 'ONT')
     if data_type != 'Hifi':
-        raise NotImplementedError("the CLR / ONT branch needs Reads_Based_Scan's clustered draft VCF (gt_impute), which is not built")
+        draft_vcf = draft_vcf or (os.path.join(sigdir, "reads_draft_variants.vcf") if sigdir else None)
+        if not draft_vcf or not os.path.isfile(draft_vcf):
+            raise NotImplementedError("the CLR / ONT branch needs Reads_Based_Scan's clustered draft calls (reads_draft_variants.vcf): pass draft_vcf=")
     wdir = os.path.join(os.path.realpath(out_dir), "post_processing")
     vcffile = os.path.realpath(os.path.join(out_dir, "SV", "chr%s" % chr_num, "final_vcf", "dippav_variant_no_redundancy.vcf"))
     for p in (bam_file, vcffile):
@@ -370,10 +551,16 @@ def filter_gt_correct(bam_file, out_dir, chr_num, sigdir, data_type='Hifi'):
     os.makedirs(gtdir, exist_ok=True)
     signature_support(vcffile, sigdir, wdir)
     filtered = filter_by_support(vcffile, wdir, data_type.lower(), 'volcano', 'DEL')
+    final = os.path.realpath(os.path.join(out_dir, "FocalSV_Final_SV.vcf"))
+    if data_type == 'CLR':
+        return gt_impute(filtered, draft_vcf, final, 1000, 0.5)
+    if data_type == 'ONT':
+        cand = gt_impute(filtered, draft_vcf, filtered.replace(".vcf", "_updated_GT.vcf"), 1000, 0.5)
+        return final_process_ont(cand, draft_vcf, final)
     spans = SpanCounter(bam_file)
     try:
         d = correct_gt(filtered, os.path.join(gtdir, "bnd_del_real.tsv"), bam_file, os.path.join(sigdir, "DEL.sigs"), data_type, 'DEL', spans)
         i = correct_gt(filtered, os.path.join(gtdir, "bnd_ins_real.tsv"), bam_file, os.path.join(sigdir, "INS.sigs"), data_type, 'INS', spans)
     finally:
         spans.close()
-    return final_vcf(filtered, [d, i], os.path.realpath(os.path.join(out_dir, "FocalSV_Final_SV.vcf")))
+    return final_vcf(filtered, [d, i], final)
