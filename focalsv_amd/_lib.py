@@ -135,6 +135,7 @@ def load():
         "fsv_bam_close": (None, [vp]),
         "fsv_bam_n_refs": (C.c_int, [vp]),
         "fsv_bam_ref_name": (C.c_char_p, [vp, C.c_int]),
+        "fsv_bam_ref_length": (C.c_int64, [vp, C.c_int]),
         "fsv_bam_ref_id": (C.c_int, [vp, C.c_char_p]),
         "fsv_bam_has_index": (C.c_int, [vp]),
         "fsv_bam_set_threads": (None, [vp, C.c_int]),

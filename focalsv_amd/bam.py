@@ -161,6 +161,10 @@ class BamFile:
         return [self._lib.fsv_bam_ref_name(self._h, i).decode() for i in range(self._lib.fsv_bam_n_refs(self._h))]
 
     @property
+    def reference_lengths(self) -> List[int]:
+        return [int(self._lib.fsv_bam_ref_length(self._h, i)) for i in range(self._lib.fsv_bam_n_refs(self._h))]
+
+    @property
     def has_index(self) -> bool:
         return bool(self._lib.fsv_bam_has_index(self._h))
 

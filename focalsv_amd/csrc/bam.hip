@@ -380,6 +380,7 @@ extern "C" int fsv_bam_ref_id(const fsv_bam *b, const char *name)
 extern "C" int fsv_bam_n_refs(const fsv_bam *b) { return b ? (int)b->ref_name.size() : 0; }
 extern "C" const char *fsv_bam_ref_name(const fsv_bam *b, int id) { return b && id >= 0 && id < (int)b->ref_name.size() ? b->ref_name[(size_t)id].c_str() : nullptr; }
 extern "C" void fsv_bam_set_threads(fsv_bam *b, int n) { if (b) b->n_threads = n < 1 ? 1 : n; }
+extern "C" int64_t fsv_bam_ref_length(const fsv_bam *b, int id) { return b && id >= 0 && id < (int)b->ref_len.size() ? (int64_t)b->ref_len[(size_t)id] : -1; }
 extern "C" int fsv_bam_has_index(const fsv_bam *b) { return b && b->have_index ? 1 : 0; }
 
 // Records of reference ref_id overlapping [beg, end) (end <= 0: to the end of the reference), in file order -- the iteration

@@ -528,25 +528,30 @@ def final_process_ont(infile, reads_draft_vcf, outfile):
     return outfile
 
 
-def filter_gt_correct(bam_file, out_dir, chr_num, sigdir, data_type='Hifi', draft_vcf=None):
+def filter_gt_correct(bam_file, out_dir, chr_num, sigdir, data_type='Hifi', draft_vcf=None, reference=None):
     """FocalSV_Filter_GT_Correct.py: reads <out_dir>/SV/chr<N>/final_vcf/dippav_variant_no_redundancy.vcf, works in
     <out_dir>/post_processing/, writes <out_dir>/FocalSV_Final_SV.vcf.  HiFi: read signatures (from the BAM, or sigdir), support
     filter, genotype correction.  CLR / ONT: support filter, then the genotypes (and for ONT the insertion union / deletion filter)
-    of the read-based draft calls -- draft_vcf, or <sigdir>/reads_draft_variants.vcf: the clustering / genotyping half of
-    Reads_Based_Scan that writes it is not built here."""
+    of the read-based draft calls -- draft_vcf, or <sigdir>/reads_draft_variants.vcf, made here (reads_cluster.draft_calls, the
+    clustering / genotyping half of Reads_Based_Scan) when it does not exist and the reference FASTA is given."""
     assert data_type in ('Hifi', 'CLR', 'ONT')
-    if data_type != 'Hifi':
-        draft_vcf = draft_vcf or (os.path.join(sigdir, "reads_draft_variants.vcf") if sigdir else None)
-        if not draft_vcf or not os.path.isfile(draft_vcf):
-            raise NotImplementedError("the CLR / ONT branch needs Reads_Based_Scan's clustered draft calls (reads_draft_variants.vcf): pass draft_vcf=")
     wdir = os.path.join(os.path.realpath(out_dir), "post_processing")
     vcffile = os.path.realpath(os.path.join(out_dir, "SV", "chr%s" % chr_num, "final_vcf", "dippav_variant_no_redundancy.vcf"))
     for p in (bam_file, vcffile):
         if not os.path.isfile(p):
             raise FileNotFoundError(p)
-    if not sigdir:      # call_sig (FocalSV_Filter_GT_Correct.py:116-151): the read signatures come from the BAM
+    made_sigs = not sigdir
+    if made_sigs:       # call_sig (FocalSV_Filter_GT_Correct.py:116-151): the read signatures come from the BAM
         from . import reads_scan
         sigdir = reads_scan.call_sig(bam_file, os.path.join(wdir, "reads_sig"), chr_num)
+    if data_type != 'Hifi':
+        draft_vcf = draft_vcf or os.path.join(sigdir, "reads_draft_variants.vcf")
+        if not os.path.isfile(draft_vcf):
+            if not reference:
+                raise NotImplementedError("the CLR / ONT branch takes its genotypes from the read-based draft calls: pass draft_vcf=, or "
+                                          "reference= (the FASTA) to have them made (reads_cluster.draft_calls)")
+            from . import reads_cluster
+            reads_cluster.draft_calls(bam_file, reference, draft_vcf, sigdir, data_type, chr_num)
     gtdir = os.path.join(wdir, "GT_Correction")
     os.makedirs(gtdir, exist_ok=True)
     signature_support(vcffile, sigdir, wdir)

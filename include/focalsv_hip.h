@@ -306,6 +306,7 @@ int  fsv_bam_open(const char *path, fsv_bam **out);
 void fsv_bam_close(fsv_bam *bam);
 int  fsv_bam_n_refs(const fsv_bam *bam);
 const char *fsv_bam_ref_name(const fsv_bam *bam, int ref_id);
+int64_t fsv_bam_ref_length(const fsv_bam *bam, int ref_id);   /* -1: no such reference sequence (pysam get_reference_length) */
 int  fsv_bam_ref_id(const fsv_bam *bam, const char *name);   /* -1: no such reference sequence */
 int  fsv_bam_has_index(const fsv_bam *bam);
 void fsv_bam_set_threads(fsv_bam *bam, int n);   /* host threads inflating BGZF blocks (default: the machine's, at most 16) */

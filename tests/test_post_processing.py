@@ -68,11 +68,14 @@ def test_span_counter_equals_plain_count(cases, tmp_path):
         sc.close()
 
 
-def test_unsupported_branches_say_so(tmp_path):
-    with pytest.raises(NotImplementedError):
-        PP.filter_gt_correct("x.bam", str(tmp_path), 21, str(tmp_path), "ONT")    # no reads_draft_variants.vcf there
+def test_unsupported_branches_say_so(cases, tmp_path):
     with pytest.raises(FileNotFoundError):
         PP.filter_gt_correct(str(tmp_path / "missing.bam"), str(tmp_path), 21, "sig", "Hifi")
+    root = str(tmp_path / "r")
+    os.makedirs(root)
+    bam, sig = _lay_out(cases[2], root)
+    with pytest.raises(NotImplementedError):      # CLR / ONT: neither a draft VCF nor the reference to make one from
+        PP.filter_gt_correct(bam, root, 21, sig, "ONT")
 
 
 # ---- CLR / ONT branch: genotypes and insertions of the read-based draft calls (goldens: tools/make_golden_gt_impute.py) ------------
@@ -137,5 +140,3 @@ def test_clr_and_ont_branches_end_to_end(cases, impute_cases, tmp_path):
         assert body and all(l.rstrip('\n').split('\t')[-1] == '1/1' for l in body)
         if dtype == "ONT":
             assert os.path.exists(os.path.join(root, "post_processing", "dippav_variant_no_redundancy_filter_DEL_updated_GT_ins_union.vcf"))
-    with pytest.raises(NotImplementedError):
-        PP.filter_gt_correct(bam, root, 21, None, "CLR")
