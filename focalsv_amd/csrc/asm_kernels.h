@@ -20,7 +20,7 @@
 #define FSV_PATH_CAP    416  // ops per window path: x_len (<= 375) + y-only ops (<= k <= 31)
 #define FSV_CW_STRIDE   448  // bytes reserved per corrected grid window
 #define FSV_INS_MAXLEN   12
-#define FSV_EV_CAP     1024  // insertion events per grid window
+#define FSV_EV_CAP     256   // insertion events per grid window (HiFi at 30x: ~8; more sets the read's warning bit 8 and drops the excess)
 
 // fsv_wpath (include/focalsv_hip.h): 128 bytes per window task; state 2 = queued for the DP kernel (internal)
 static_assert(sizeof(fsv_wpath) == 128, "fsv_wpath layout");
