@@ -141,14 +141,17 @@ def main():
 
     def run_steps(count, static=False):
         """`count` whole-batch steps over the lanes (pipeline.run_stream: one batch in flight per lane); the VCF gather of step s
-        runs on this thread in step order -> (per-step results, the last step's lines)"""
-        last = [[]]
+        runs on this thread in step order -> (per-step statistics, the last step's result, the last step's lines)"""
+        last, stats = [None, []], []
 
         def gathered(i, r):
-            last[0] = pipeline.gather_vcf(list(r.lines)) if world > 1 else list(r.lines)
+            last[0] = r
+            last[1] = pipeline.gather_vcf(list(r.lines)) if world > 1 else list(r.lines)
+            stats.append((sum_stats([r.asm_stats]), sum_stats([r.aln_stats])))
 
-        results = pipeline.run_stream(ctxs, [batches[0]] * count, on_result=gathered, static=static, stagger=0.0 if static else args.stagger, heavy_slots=args.heavy_slots)
-        return results, last[0]
+        pipeline.run_stream(ctxs, [batches[0]] * count, on_result=gathered, static=static, stagger=0.0 if static else args.stagger,
+                            heavy_slots=args.heavy_slots, keep_results=False)
+        return stats, last[0], last[1]
 
     def fence():
         for c in ctxs:
@@ -171,9 +174,7 @@ def main():
     t0 = time.perf_counter()
     stats_acc = []
     if by_steps:
-        results, lines = run_steps(args.steps)
-        res = results[-1]
-        stats_acc = [(sum_stats([r.asm_stats]), sum_stats([r.aln_stats])) for r in results]
+        stats_acc, res, lines = run_steps(args.steps)
     else:
         for _ in range(args.steps):
             results, lines = step()

@@ -341,7 +341,7 @@ def run_hot_path_lanes(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBat
 
 
 def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, stagger: float = 0.0, host_workers: int = 1,
-               heavy_slots: int = 0, **kw) -> List[CallResult]:
+               heavy_slots: int = 0, keep_results: bool = True, **kw) -> List[CallResult]:
     """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
     next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
     host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
@@ -352,7 +352,8 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     stagger: lane k waits k x stagger seconds before its first batch -- lanes started together run in lockstep (all in their GPU
     stretch, then all in their host stretch, the GPU idle meanwhile); out of phase, one lane's host stretch falls into the others'
     GPU stretches.  A lane only does the GPU half of a batch (launch_hot_path); the host half (PendingCall.finish: records, signatures,
-    VCF, filters) runs on `host_workers` other threads, so the lane is back on the GPU at once.  -> results in batch order"""
+    VCF, filters) runs on `host_workers` other threads, so the lane is back on the GPU at once.  -> results in batch order
+    (keep_results=False: an empty list -- a long stream hands its results to on_result only)"""
     lanes = len(ctxs)
     if static:
         batches = list(batches)
@@ -439,16 +440,19 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     cl = threading.Thread(target=closer, name="fsv-closer")
     cl.start()
     out: List[CallResult] = []
+    nxt = 0
     while True:
         with ready:
-            while len(out) not in results and not errs and any(t.is_alive() for t in fin):
+            while nxt not in results and not errs and any(t.is_alive() for t in fin):
                 ready.wait(0.05)
-            r = None if errs else results.pop(len(out), None)
+            r = None if errs else results.pop(nxt, None)
         if r is None:       # something failed, or every batch has been finished and handed out
             break
         if on_result is not None:
-            on_result(len(out), r)
-        out.append(r)
+            on_result(nxt, r)
+        if keep_results:
+            out.append(r)
+        nxt += 1
     if errs:                # unblock lanes waiting on a full queue, then drain
         while any(t.is_alive() for t in th + fin):
             try:
@@ -469,7 +473,7 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
 
 
 def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, stagger: float = 0.0, host_workers: int = 1,
-               heavy_slots: int = 0, **kw) -> List[CallResult]:
+               heavy_slots: int = 0, keep_results: bool = True, **kw) -> List[CallResult]:
     """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
     next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
     host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
@@ -480,7 +484,8 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     stagger: lane k waits k x stagger seconds before its first batch -- lanes started together run in lockstep (all in their GPU
     stretch, then all in their host stretch, the GPU idle meanwhile); out of phase, one lane's host stretch falls into the others'
     GPU stretches.  A lane only does the GPU half of a batch (launch_hot_path); the host half (PendingCall.finish: records, signatures,
-    VCF, filters) runs on `host_workers` other threads, so the lane is back on the GPU at once.  -> results in batch order"""
+    VCF, filters) runs on `host_workers` other threads, so the lane is back on the GPU at once.  -> results in batch order
+    (keep_results=False: an empty list -- a long stream hands its results to on_result only)"""
     lanes = len(ctxs)
     if static:
         batches = list(batches)
