@@ -78,13 +78,13 @@ def sum_stats(dicts):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=256, help="regions per GPU (BASELINE.json configs[1]: 256)")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "5")), help="concurrent lanes per GPU (contexts / streams / host threads)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "6")), help="concurrent lanes per GPU (contexts / streams / host threads)")
     ap.add_argument("--lane-mode", choices=["split", "steps"], default=os.environ.get("FSV_BENCH_LANE_MODE", "steps"),
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
-    ap.add_argument("--heavy-slots", type=int, default=int(os.environ.get("FSV_BENCH_HEAVY_SLOTS", "3")), help="lanes allowed in the assembly at once (0 = all)")
+    ap.add_argument("--heavy-slots", type=int, default=int(os.environ.get("FSV_BENCH_HEAVY_SLOTS", "0")), help="lanes allowed in the assembly at once (0 = all)")
     ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
     ap.add_argument("--cpu-sample", type=int, default=8, help="regions the CPU baseline runs (0 = skip)")
     args = ap.parse_args()

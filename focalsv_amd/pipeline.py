@@ -418,7 +418,7 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
                 return
             i, pend = item
             try:
-                r = pend.finish()
+                r = pend.finish()     # also after a failure elsewhere: it ends the batch's read-side thread, and the queue keeps draining
             except BaseException as e:
                 errs.append(e)
                 r = None
@@ -453,111 +453,8 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
         if keep_results:
             out.append(r)
         nxt += 1
-    if errs:                # unblock lanes waiting on a full queue, then drain
-        while any(t.is_alive() for t in th + fin):
-            try:
-                item = pend_q.get(timeout=0.05)
-                if item is not None:
-                    try:
-                        item[1].finish()
-                    except BaseException:
-                        pass
-            except queue.Empty:
-                pass
     cl.join()
     for t in th + fin:
-        t.join()
-    if errs:
-        raise errs[0]
-    return out, sorted((l for o in out for l in o.lines), key=_vcf_key)
-
-
-def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, stagger: float = 0.0, host_workers: int = 1,
-               heavy_slots: int = 0, keep_results: bool = True, **kw) -> List[CallResult]:
-    """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
-    next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
-    host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
-    MI355X).  `batches` is any iterable of DeviceBatch (the read store is only read, so the same one may come several times) or
-    HostBatch (uploaded by the lane that takes it and freed after its run); an iterator is pulled as lanes come free, so a producer
-    such as bam_batches stays a bounded distance ahead.  on_result(i, result) is called on the calling thread in batch order (the
-    place for an ordered collective such as gather_vcf); static deals batch i to lane i % len(ctxs) (needs a sequence).
-    stagger: lane k waits k x stagger seconds before its first batch -- lanes started together run in lockstep (all in their GPU
-    stretch, then all in their host stretch, the GPU idle meanwhile); out of phase, one lane's host stretch falls into the others'
-    GPU stretches.  A lane only does the GPU half of a batch (launch_hot_path); the host half (PendingCall.finish: records, signatures,
-    VCF, filters) runs on `host_workers` other threads, so the lane is back on the GPU at once.  -> results in batch order
-    (keep_results=False: an empty list -- a long stream hands its results to on_result only)"""
-    lanes = len(ctxs)
-    if static:
-        batches = list(batches)
-    results: Dict[int, CallResult] = {}
-    errs: List[BaseException] = []
-    source = enumerate(batches)
-    lock, ready = threading.Lock(), threading.Condition()
-    state = {"taken": 0, "exhausted": False}
-
-    def take(k):
-        if static:
-            i = k + lanes * take.round[k]
-            take.round[k] += 1
-            return (i, batches[i]) if i < len(batches) else None
-        with lock:
-            if state["exhausted"]:
-                return None
-            item = next(source, None)
-            if item is None:
-                state["exhausted"] = True
-            else:
-                state["taken"] += 1
-            return item
-    take.round = [0] * lanes
-
-    def work(k):
-        if stagger > 0 and k:
-            time.sleep(k * stagger)
-        while not errs:
-            try:
-                item = take(k)
-                if item is None:
-                    return
-                i, b = item
-                if isinstance(b, HostBatch):
-                    db = upload_host_batch(ctxs[k], b)
-                    try:
-                        r = run_hot_path(ctxs[k], db, **kw)
-                    finally:
-                        db.free(ctxs[k])
-                else:
-                    r = run_hot_path(ctxs[k], b, **kw)
-            except BaseException as e:
-                errs.append(e)
-                with ready:
-                    ready.notify_all()
-                return
-            with ready:
-                results[i] = r
-                ready.notify_all()
-
-    th = [threading.Thread(target=work, args=(k,), name="fsv-lane-%d" % k) for k in range(lanes)]
-    for t in th:
-        t.start()
-    out: List[CallResult] = []
-    while not errs:
-        with ready:
-            while len(out) not in results and not errs and any(t.is_alive() for t in th):
-                ready.wait(0.05)
-            r = results.pop(len(out), None)
-        if r is None:
-            if errs or not any(t.is_alive() for t in th):
-                with ready:
-                    r = results.pop(len(out), None)
-                if r is None:
-                    break
-            else:
-                continue
-        if on_result is not None:
-            on_result(len(out), r)
-        out.append(r)
-    for t in th:
         t.join()
     if errs:
         raise errs[0]
