@@ -84,7 +84,6 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "6")), help="concurrent lanes per GPU (contexts / streams / host threads)")
     ap.add_argument("--lane-mode", choices=["split", "steps"], default=os.environ.get("FSV_BENCH_LANE_MODE", "steps"),
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
-    ap.add_argument("--heavy-slots", type=int, default=int(os.environ.get("FSV_BENCH_HEAVY_SLOTS", "0")), help="lanes allowed in the assembly at once (0 = all)")
     ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
     ap.add_argument("--cpu-sample", type=int, default=8, help="regions the CPU baseline runs (0 = skip)")
     args = ap.parse_args()
@@ -150,7 +149,7 @@ def main():
             stats.append((sum_stats([r.asm_stats]), sum_stats([r.aln_stats])))
 
         pipeline.run_stream(ctxs, [batches[0]] * count, on_result=gathered, static=static, stagger=0.0 if static else args.stagger,
-                            heavy_slots=args.heavy_slots, keep_results=False)
+                            keep_results=False)
         return stats, last[0], last[1]
 
     def fence():
@@ -255,12 +254,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{n} synthetic 50 kb regions per GPU, 30x HiFi-like reads U(10k,20k), 0.2% error, seed 1000+i "
-                                   "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather; {lanes} concurrent lanes (streams) per GPU, " + (f"each taking whole steps (one batch in flight per lane, at most {args.heavy_slots or lanes} in the assembly at once)" if by_steps else "each half of every step's batch")},
+                                   "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather; {lanes} concurrent lanes (streams) per GPU, " + ("each taking whole steps (one batch in flight per lane, the host half of a batch on its own thread)" if by_steps else "each half of every step's batch")},
             "sv_vs_truth": {"truth": len(truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok, "tp_within_1bp_of_left_aligned_truth": tp1},
             "stage_ms": {k: round(v, 2) for k, v in a.items() if k.startswith("ms_")},
             "kernel_ms": {k: [round(v["ms"], 2), int(round(v["launches"]))] for k, v in kern.items()},
             "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},
-            "lanes": lanes, "lane_mode": args.lane_mode if lanes > 1 else "single", "assembly_slots": args.heavy_slots if by_steps else 0,
+            "lanes": lanes, "lane_mode": args.lane_mode if lanes > 1 else "single",
             "lane_priming_steps": priming,
             "host_ms": res.host_ms,
             # companion compute figure: banded DP column-steps of K5 + K6 (windows x their x_len, 31-row bands)

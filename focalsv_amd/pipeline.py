@@ -190,7 +190,7 @@ def upload_bam_regions(ctx: _lib.Context, bam_path: str, regions: Sequence[Tuple
     return upload_host_batch(ctx, read_bam_regions(bam_path, regions, windows))
 
 
-def launch_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None, gate=None) -> "PendingCall":
+def launch_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', asm_params=None, aln_params=None) -> "PendingCall":
     """the GPU half of run_hot_path; .finish() on the result gives the CallResult"""
     regions, pk = batch.regions, batch.packed
     chroms = sorted({r.chrom for r in regions}, key=lambda c: (len(c), c))
@@ -218,7 +218,7 @@ def launch_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS
     t_enter = time.perf_counter()
     side = threading.Thread(target=_read_side, name="fsv-read-signatures")
     side.start()
-    stages = _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err, gate)
+    stages = _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err)
     try:
         next(stages)          # the GPU half: assembly and contig alignment
     except BaseException:
@@ -248,7 +248,7 @@ def run_hot_path(ctx: _lib.Context, batch: DeviceBatch, data_type: str = 'CCS', 
     return launch_hot_path(ctx, batch, data_type, asm_params, aln_params).finish()
 
 
-def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err, gate=None):
+def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, chroms, read_sigs, refs, side, side_err):
     """generator of two stages: everything that needs the GPU context (then yields None), then the host logic (yields the CallResult)"""
     host_ms, t_prev = {}, [time.perf_counter()]
 
@@ -260,11 +260,7 @@ def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, ch
     set_kind = batch.set_kind if batch.set_kind is not None else [1 + (i & 1) for i in range(len(pk.set_start) - 1)]
     set_region = batch.set_region if batch.set_region is not None else [i // 2 for i in range(len(pk.set_start) - 1)]
     flags = [_lib.SET_UNPHASED if k == 0 else 0 for k in set_kind] if 0 in set_kind else None
-    if gate is not None:     # run_stream's limit on the lanes that are in the assembly at once
-        with gate:
-            contigs, cset, cnr, set_status = ctx.assemble_batch(batch.store_dev, pk.word_off, pk.read_len, pk.set_start, asm_params, flags)
-    else:
-        contigs, cset, cnr, set_status = ctx.assemble_batch(batch.store_dev, pk.word_off, pk.read_len, pk.set_start, asm_params, flags)
+    contigs, cset, cnr, set_status = ctx.assemble_batch(batch.store_dev, pk.word_off, pk.read_len, pk.set_start, asm_params, flags)
     lap("assemble_call")
     asm_stats = ctx.asm_stats()
     # reformat_fasta (DipPAV_variant_call.py:14-23): contigs are numbered per haplotype across the whole call.  The contigs of an
@@ -341,7 +337,7 @@ def run_hot_path_lanes(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBat
 
 
 def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bool = False, stagger: float = 0.0, host_workers: int = 1,
-               heavy_slots: int = 0, keep_results: bool = True, **kw) -> List[CallResult]:
+               keep_results: bool = True, **kw) -> List[CallResult]:
     """a sequence of batches over the lanes of one GPU: every lane (context = HIP stream + workspace, own host thread) takes the
     next batch as it comes free, so len(ctxs) batches are in flight and every launch keeps its full-batch size -- one lane's
     host-side stretches and latency-bound kernels overlap the other lanes' kernels (three lanes: +28 % regions/s over one on
@@ -361,13 +357,16 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     errs: List[BaseException] = []
     source = enumerate(batches)
     lock, ready = threading.Lock(), threading.Condition()
-    state = {"taken": 0, "exhausted": False}
+    state = {"taken": 0, "consumed": 0, "exhausted": False}
 
     def take(k):
         if static:
             i = k + lanes * take.round[k]
             take.round[k] += 1
             return (i, batches[i]) if i < len(batches) else None
+        with ready:      # no lane runs more than a few rounds ahead of what the caller has been handed: results cannot pile up
+            while state["taken"] >= state["consumed"] + 4 * lanes and not errs:
+                ready.wait(0.05)
         with lock:
             if state["exhausted"]:
                 return None
@@ -381,10 +380,6 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
 
     import queue
     pend_q: "queue.Queue" = queue.Queue(maxsize=2 * lanes)
-    if heavy_slots and heavy_slots < lanes:
-        # lanes started together stay in step: all in the assembly, then all in its host-side tail and the small alignment kernels,
-        # the GPU nearly idle meanwhile.  With fewer assembly slots than lanes one lane is always out of phase with the others.
-        kw = dict(kw, gate=threading.BoundedSemaphore(heavy_slots))
 
     def work(k):
         if stagger > 0 and k:
@@ -453,6 +448,9 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
         if keep_results:
             out.append(r)
         nxt += 1
+        with ready:
+            state["consumed"] = nxt
+            ready.notify_all()
     cl.join()
     for t in th + fin:
         t.join()
