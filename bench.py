@@ -81,7 +81,8 @@ def main():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=256, help="regions per GPU (BASELINE.json configs[1]: 256)")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "6")), help="concurrent lanes per GPU (contexts / streams / host threads)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "0")),
+                    help="concurrent lanes per GPU (contexts / streams / host threads); 0 = 3..7, whichever wastes least of the last round of --steps")
     ap.add_argument("--lane-mode", choices=["split", "steps"], default=os.environ.get("FSV_BENCH_LANE_MODE", "steps"),
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
     ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
@@ -120,6 +121,11 @@ def main():
     truth_left = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in regions for t in r.truth]
 
     # two lanes per GPU (pipeline.run_hot_path_lanes): halves of the batch on their own context / stream / host thread
+    if args.lanes <= 0:
+        # K steps over L lanes take ceil(K / L) rounds: pick the lane count whose last round is fullest, weighted by what that many
+        # lanes sustain (measured regions/s at a multiple of L steps: 3: 1980, 4: 2110, 5: 2150, 6: 2165, 7: 2190)
+        rate = {3: 1980, 4: 2110, 5: 2150, 6: 2165, 7: 2190}
+        args.lanes = max(rate, key=lambda l: (args.steps / (-(-args.steps // l) * l)) * rate[l]) if args.lane_mode == "steps" else 2
     lanes = max(1, min(args.lanes, n))
     ctxs = [_lib.Context(local) for _ in range(lanes)]
     by_steps = args.lane_mode == "steps" and lanes > 1
