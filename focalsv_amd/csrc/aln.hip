@@ -5,6 +5,7 @@
 //   k_sketch / k_uniq   seeds (ha_sketch without HPC, k = 19)           sketch.cpp:39-137
 //   k_chain_aln         co-linear chain, one wavefront per pair, all state in LDS
 //   k_aln_events        gap-free runs vs DP events, padding, X-drop end extension
+//   k_gap_shift         every gap of the stitched CIGAR to its leftmost position (minimap2's mm_fix_cigar rule)
 //   k_nw                dual-affine global DP of one event on anti-diagonals (one workgroup per event), the
 //                       recurrence / tie rules / backtrack of the in-tree ksw2 (ksw2_extz2_sse.c:171-196, ksw2.h:115-150)
 #include "asm_kernels.h"
@@ -243,6 +244,37 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
     hdr[p] = h;
 }
 
+// ------------------------------------------------------------------------------------------------ gap left alignment
+// minimap2 moves every I/D of a finished CIGAR to its leftmost position (mm_fix_cigar: a deletion while the reference base
+// entering the gap on the left equals the one leaving it on the right, an insertion the same on the query) -- restated in
+// oracle/aln.c:shift_gaps_left.  How far a gap could travel depends on the sequence alone, so the device answers that for
+// all gaps of the batch at once (one wavefront per gap, 64 positions per step); the host then applies the shifts in CIGAR
+// order, each bounded by the M run in front of it.
+struct GapQuery { uint32_t slot; int32_t is_ins, off, len, cap; };
+__global__ __launch_bounds__(64) void k_gap_shift(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                                  const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
+                                                  const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
+                                                  const GapQuery *__restrict__ gaps, int32_t *__restrict__ max_shift)
+{
+    const GapQuery g = gaps[blockIdx.x];
+    const int lane = threadIdx.x;
+    const uint32_t qw = word_off[pair_q[g.slot]], tw = word_off[pair_t[g.slot]];
+    const int lenq = read_len[pair_q[g.slot]], rev = hdr[g.slot].rev;
+    int res = g.cap;
+    for (int base = 0; base < g.cap; base += 64) {
+        const int l = base + lane;
+        bool stop = true;
+        if (l < g.cap) {
+            const int a = g.off - 1 - l, b = g.off + g.len - 1 - l;
+            stop = g.is_ins ? qbase(store, qw, lenq, rev, a) != qbase(store, qw, lenq, rev, b)
+                            : fsv_base_fwd(store, tw, a) != fsv_base_fwd(store, tw, b);
+        }
+        const uint64_t m = __ballot(stop);
+        if (m) { res = base + (int)__ffsll((long long)m) - 1; break; }
+    }
+    if (lane == 0) max_shift[blockIdx.x] = res;
+}
+
 // ------------------------------------------------------------------------------------------------ NW
 // One workgroup per event, cells of one anti-diagonal in parallel.  Rolling rows indexed by the query position:
 //   H on diagonals d-1 and d-2, and the E/F/E2/F2 values *leaving* each cell of diagonal d-1.
@@ -432,9 +464,9 @@ __global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ sto
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 struct AlnWs {
-    DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, ev_packed, ev_count, tasks, bt, rows, cg, cg_n, scores;
+    DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, ev_packed, ev_count, tasks, bt, rows, cg, cg_n, scores, gaps, gap_shift;
     fsv_aln_stats stats;
-    std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores}; }
+    std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores, &gaps, &gap_shift}; }
 };
 
 void aln_ws_free(fsv_ctx *ctx)
@@ -819,9 +851,14 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
     W.stats.ms_dp = tdp.stop();
     W.stats.n_pairs = np; W.stats.n_events = tasks.size();
     // stitch: S, M runs, events, S -- one record per used slot, the primary first
+    struct Rec { uint32_t contig, slot; std::vector<uint32_t> c; };
+    std::vector<Rec> recs;
+    std::vector<GapQuery> gaps;
+    std::vector<int32_t> status(np, 0);
     for (uint32_t cp = 0; cp < np; cp++) {
         W.stats.algo_bytes += (uint64_t)(len[pair_q[cp]] + len[pair_t[cp]] + 3) / 4;
         int32_t st = pre_status[cp] != 0 ? pre_status[cp] : hdr[cp * R].status;
+        const size_t first_rec = recs.size(), first_gap = gaps.size();
         for (uint32_t r = 0; r < R && st == 0; r++) {
             const uint32_t p = cp * R + r;
             const AlnHeader &h = hdr[p];
@@ -837,21 +874,66 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
                 for (uint32_t i = 0; i < cg_n[t]; i++) { uint32_t v = runs[i]; push_cg(c, v & 0xf, v >> 4); }
                 mstart = T.qs + T.ql;
             }
-            if (st == 0) {
-                push_cg(c, 0, (uint32_t)(h.qend + 1 - mstart));
-                push_cg(c, 4, (uint32_t)(len[pair_q[cp]] - 1 - h.qend));
-                if (out->n_rec >= out->rec_cap) return fsv_fail(ctx, FSV_ECAP, "record buffer too small (rec_cap >= 3 x n_contigs holds every case)");
-                if (out->n_cigar + c.size() > out->cigar_cap) return fsv_fail(ctx, FSV_ECAP, "cigar buffer too small");
-                fsv_aln_rec &rr = out->rec[out->n_rec++];
-                rr.ref_start = h.tbeg; rr.ref_end = h.tend + 1; rr.q_start = h.qbeg; rr.q_end = h.qend + 1; rr.n_cigar = (uint32_t)c.size();
-                rr.n_chain = (uint32_t)h.n_chain; rr.cigar_off = out->n_cigar; rr.contig = cp; rr.rev = (uint8_t)h.rev; rr.mapq = 60; rr.pad[0] = rr.pad[1] = 0;
-                memcpy(out->cigar + out->n_cigar, c.data(), c.size() * 4);
-                out->n_cigar += c.size();
-                W.stats.algo_bytes += c.size() * 4;
+            if (st != 0) break;
+            push_cg(c, 0, (uint32_t)(h.qend + 1 - mstart));
+            push_cg(c, 4, (uint32_t)(len[pair_q[cp]] - 1 - h.qend));
+            // gaps flanked by M on both sides: how far could each travel left (answered on the device below)
+            int toff = h.tbeg, qoff = 0;
+            for (size_t k = 0; k < c.size(); k++) {
+                const uint32_t op = c[k] & 0xf; const int l = (int)(c[k] >> 4);
+                if (op == 0) { toff += l; qoff += l; }
+                else if (op == 4) qoff += l;
+                else {
+                    if (k > 0 && k + 1 < c.size() && (c[k - 1] & 0xf) == 0 && (c[k + 1] & 0xf) == 0)
+                        gaps.push_back(GapQuery{p, op == 1, op == 1 ? qoff : toff, l, std::min(toff - h.tbeg, qoff - h.qbeg)});
+                    if (op == 2) toff += l; else qoff += l;
+                }
             }
+            recs.push_back(Rec{cp, p, std::move(c)});
         }
-        out->contig_status[cp] = st;
+        if (st != 0) { recs.resize(first_rec); gaps.resize(first_gap); }
+        status[cp] = st;
     }
+    std::vector<int32_t> max_shift(gaps.size());
+    if (!gaps.empty()) {
+        TRY(upload(ctx, W.gaps, gaps));
+        TRY(ensure(ctx, W.gap_shift, gaps.size() * 4));
+        hipLaunchKernelGGL(k_gap_shift, dim3((uint32_t)gaps.size()), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
+                           (const GapQuery *)W.gaps.p, (int32_t *)W.gap_shift.p);
+        FSV_HIP(ctx, hipGetLastError());
+        FSV_HIP(ctx, hipMemcpyAsync(max_shift.data(), W.gap_shift.p, gaps.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    {
+        size_t gi = 0;
+        for (Rec &rc : recs) {
+            std::vector<uint32_t> &c = rc.c;
+            bool shrink = false;
+            for (size_t k = 1; k + 1 < c.size(); k++) {
+                const uint32_t op = c[k] & 0xf;
+                if ((op != 1 && op != 2) || (c[k - 1] & 0xf) != 0 || (c[k + 1] & 0xf) != 0) continue;
+                const uint32_t prev = c[k - 1] >> 4, l = std::min<uint32_t>(prev, (uint32_t)max_shift[gi++]);   // same gaps, same order as collected
+                c[k - 1] -= l << 4; c[k + 1] += l << 4;
+                shrink |= l == prev;
+            }
+            if (shrink) {
+                std::vector<uint32_t> d;
+                for (uint32_t v : c) push_cg(d, v & 0xf, v >> 4);
+                c.swap(d);
+            }
+            const AlnHeader &h = hdr[rc.slot];
+            if (out->n_rec >= out->rec_cap) return fsv_fail(ctx, FSV_ECAP, "record buffer too small (rec_cap >= 3 x n_contigs holds every case)");
+            if (out->n_cigar + c.size() > out->cigar_cap) return fsv_fail(ctx, FSV_ECAP, "cigar buffer too small");
+            fsv_aln_rec &rr = out->rec[out->n_rec++];
+            rr.ref_start = h.tbeg; rr.ref_end = h.tend + 1; rr.q_start = h.qbeg; rr.q_end = h.qend + 1; rr.n_cigar = (uint32_t)c.size();
+            rr.n_chain = (uint32_t)h.n_chain; rr.cigar_off = out->n_cigar; rr.contig = rc.contig; rr.rev = (uint8_t)h.rev; rr.mapq = 60; rr.pad[0] = rr.pad[1] = 0;
+            memcpy(out->cigar + out->n_cigar, c.data(), c.size() * 4);
+            out->n_cigar += c.size();
+            W.stats.algo_bytes += c.size() * 4;
+        }
+    }
+    for (uint32_t cp = 0; cp < np; cp++) out->contig_status[cp] = status[cp];
     trace("stitch");
     W.stats.ms_total = ttot.stop();
     return FSV_OK;

@@ -83,6 +83,8 @@ void orc_aln_default_params(orc_aln_params *P);
 int orc_nw(const char *t, int tl, const char *q, int ql, const orc_aln_params *P, uint32_t *cigar, int cigar_cap, int *n_cigar, uint8_t *bt);
 int orc_aln_chain(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, const orc_aln_params *P, int *rev_out,
                   int32_t *cq, int32_t *ct, int cap);
+/* longest left shift (< = cap) of a gap of `len` bases that starts at s[off]: the count of l with s[off-1-l] == s[off+len-1-l] */
+int orc_gap_max_shift(const char *s, int off, int len, int cap);
 int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
                      uint32_t *cigar, int cigar_cap);
 #define ORC_ALN_MAX_REC 3      /* records per contig: primary + supplementary chains */

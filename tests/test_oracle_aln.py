@@ -59,3 +59,64 @@ def test_alignment_recovers_planted_svs():
                     assert pos <= tpos, (i, h, ev, truth)
                     if i % 8 != 7:
                         assert tpos - pos <= 8, (i, h, ev, truth)
+
+
+# regions where round 1's aligner put a DEL 2-9 bp right of its leftmost position (VERDICT r01, weak item 1): the gap sat at
+# the left edge of its DP event and could not travel further; the CIGAR-wide left shift (minimap2's mm_fix_cigar rule) fixes it
+LEFT_SHIFT_REGRESSIONS = (367, 423, 559, 703, 791, 823, 1039, 1175, 1359)
+
+
+def sv_position_tolerance(region, t, hap):
+    """+-1 bp of the left-aligned truth.  Where a haplotype-2 SNP (every 1 kb from 500, synth.make_region) lies within 3 bp
+    of a breakpoint, the best-scoring alignment absorbs the SNP into the gap (one mismatch saved, same haplotype sequence):
+    the call may then sit up to that many bases further left."""
+    if hap != 1:
+        return 1
+    snps = range(500, len(region.ref), 1000)
+    d = min(abs(e - s) for e in (t.pos_left, t.pos_left + (t.length if t.svtype == "DEL" else 0)) for s in snps)
+    return 1 + (d if d <= 3 else 0)
+
+
+def check_planted(region, hap, aln):
+    """every planted SV of the haplotype called with its exact length within the tolerance, nothing else called"""
+    ev = _events(aln)
+    want = [t for t in region.truth if t.hap & (hap + 1)]
+    misses = [(t.svtype, t.pos_left, t.length) for t in want
+              if not any(k == t.svtype and n == t.length and abs(p - t.pos_left) <= sv_position_tolerance(region, t, hap) for k, p, n in ev)]
+    return misses, len(ev) - len(want)
+
+
+def test_planted_svs_left_aligned_over_2000_seeds():
+    """seeds 1000 + i for i < 2000 (all 250 tandem-repeat regions i % 8 == 7 included): 0 misses, 0 extra calls"""
+    n_sv = 0
+    for i in range(2000):
+        r = synth.make_region(i, depth_per_hap=0.3)      # reads are not needed here: the haplotypes themselves are aligned
+        for h in (0, 1):
+            a = O.align_contig(r.haps[h], r.ref)
+            assert a is not None
+            misses, extra = check_planted(r, h, a)
+            assert not misses and extra == 0, (i, h, misses, extra, _events(a))
+            n_sv += sum(1 for t in r.truth if t.hap & (h + 1))
+    assert n_sv > 5000
+
+
+def test_gap_shift_rule():
+    """shift_gaps_left on hand-made cases: a deletion inside a tandem repeat goes to the repeat's first base, an M run shifted
+    away completely merges the neighbouring gaps"""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    A = np.frombuffer(b"ACGT", dtype=np.uint8)
+    left, right = A[rng.integers(0, 4, 3000)].tobytes(), A[rng.integers(0, 4, 3000)].tobytes()
+    unit = b"ACGGTCATTGCAAGTCCTGA"
+    while left[-1:] == unit[-1:]:
+        left = left[:-1]
+    ref = left + unit * 40 + right
+    hap = left + unit * 33 + right                      # 7 units deleted, wherever
+    a = O.align_contig(hap, ref)
+    assert _events(a) == [("DEL", len(left), 140)], O.cigar_str(a["raw"])
+    hap = left + unit * 45 + right                      # 5 units inserted
+    a = O.align_contig(hap, ref)
+    assert _events(a) == [("INS", len(left), 100)], O.cigar_str(a["raw"])
+    s = b"TTTTACACACACACACGGGG"
+    assert O.lib().orc_gap_max_shift(s, 10, 2, 10) == 6    # a 2-base gap at 10 can move back to 4 (the first AC)
+    assert O.lib().orc_gap_max_shift(s, 10, 2, 3) == 3
