@@ -36,6 +36,8 @@ class ReadSets(C.Structure):
 
 
 SET_UNPHASED = 1
+# return / status codes of include/focalsv_hip.h
+OK, ENODEV, EINVAL, ENOMEM, EHIP, ECAP, EUNSUP = 0, -1, -2, -3, -4, -5, -6
 
 
 class Contigs(C.Structure):
@@ -122,6 +124,7 @@ def load():
         "fsv_pack_reads": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_size_t, vp]),
         "fsv_bpm_windows_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
         "fsv_bpm_windows": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp]),
+        "fsv_bpm_paths": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp]),
         "fsv_asm_default_params": (None, [C.POINTER(AsmParams)]),
         "fsv_assemble_batch_bound": (C.c_int, [C.POINTER(ReadSets), u64p, u32p]),
         "fsv_assemble_batch": (C.c_int, [vp, C.POINTER(ReadSets), C.POINTER(AsmParams), C.POINTER(Contigs)]),

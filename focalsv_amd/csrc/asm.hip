@@ -758,7 +758,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     for (uint32_t s = 0; s < B.n_sets && rc_out == FSV_OK; s++) {
         const uint32_t r0 = B.set_start[s], ns = B.set_start[s + 1] - r0;
         int32_t st = 0;
-        for (uint32_t r = r0; r < r0 + ns; r++) st |= (int32_t)(hwarn[r] & 3u);
+        for (uint32_t r = r0; r < r0 + ns; r++) st |= (int32_t)(hwarn[r] & (FSV_W_MZ_TRUNC | FSV_W_ANCHOR_TRUNC | FSV_W_INS_EVENTS | FSV_W_WINDOW_KEPT | FSV_W_INTERNAL));
         if (ns == 0) { out->set_status[s] = st; continue; }
         if (lay[s].fallback) st |= FSV_W_NO_LAYOUT;
         for (auto &c : lay[s].contigs) {

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
                 __syncthreads();
             }
         for (uint32_t i = tid; i < m; i += 256) { fsv_mz x; x.hash = s_hash[i]; const uint64_t p = s_pay[i]; x.pos = (uint32_t)p; x.rev = (uint8_t)(p >> 32); x.span = (uint8_t)(p >> 40); x.pad = 0; a[m + i] = x; }
-    } else if (tid == 0) atomicOr(&warn[r], 32u); // cannot happen: at most one minimizer per base and slots hold len + 64
+    } else if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_INTERNAL); // cannot happen: at most one minimizer per base and slots hold len + 64
 }
 
 // ------------------------------------------------------------------------------------------------ k_chain
@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     // fewer than three overlaps: the reference leaves the window alone; no deviation anywhere: every vote is for the backbone
     const bool verbatim = s_cover < 3u || s_anydev == 0u;
     const uint32_t evn = min(s_evn, (uint32_t)FSV_EV_CAP);
-    if (s_evn > FSV_EV_CAP && lane == 0) atomicOr(&A.warn[r], 8u);
+    if (s_evn > FSV_EV_CAP && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
     int arrived = before;
     bool differs = false;
     for (int c = c0; c < c1; c++) {
@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     for (int i = 0; i < 64; i++) { uint32_t v = s_scan[i]; if (i < lane) off += v; tot += v; }
     if (tot > FSV_CW_STRIDE) { // cannot happen with <= 12-base insertions winning at a few columns; keep the read as it is
         for (int c = lane; c < glen; c += 64) dst[c] = (uint8_t)XB(gs + c);
-        if (lane == 0) { A.cwin_len[gw] = (uint16_t)glen; atomicOr(&A.warn[r], 16u); }
+        if (lane == 0) { A.cwin_len[gw] = (uint16_t)glen; atomicOr(&A.warn[r], (uint32_t)FSV_W_WINDOW_KEPT); }
         return;
     }
     for (int c = c0; c < c1; c++) for (int b = 0; b < s_out[c][0]; b++) dst[off++] = s_out[c][1 + b];

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <new>
 #include <vector>
 #include <thread>
 #include <atomic>
@@ -223,10 +224,10 @@ void load_bai(fsv_bam *b)
         std::vector<std::vector<uint64_t>> lin((size_t)std::max(0, n_ref));
         for (int32_t r = 0; ok && r < n_ref; r++) {
             int32_t n_bin = 0;
-            ok = rd(&n_bin, 4);
+            ok = rd(&n_bin, 4) && n_bin >= 0;      // a damaged index is "no index" (whole-file scan), never a huge resize
             for (int32_t i = 0; ok && i < n_bin; i++) {
                 uint32_t bin = 0; int32_t n_chunk = 0;
-                ok = rd(&bin, 4) && rd(&n_chunk, 4);
+                ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0;
                 for (int32_t c = 0; ok && c < n_chunk; c++) {
                     uint64_t beg = 0, end = 0;
                     ok = rd(&beg, 8) && rd(&end, 8);
@@ -234,7 +235,7 @@ void load_bai(fsv_bam *b)
                 }
             }
             int32_t n_intv = 0;
-            ok = ok && rd(&n_intv, 4);
+            ok = ok && rd(&n_intv, 4) && n_intv >= 0 && n_intv <= (1 << 24);   // 2^24 x 16 kb windows = 2^38 bases
             if (ok) { lin[r].resize((size_t)n_intv); ok = n_intv == 0 || rd(lin[r].data(), (size_t)n_intv * 8); }
         }
         fclose(f);
@@ -337,7 +338,7 @@ static int copy_out(fsv_bam *b, fsv_bam_records *out, int want_seq)
     return FSV_OK;
 }
 
-extern "C" int fsv_bam_open(const char *path, fsv_bam **out)
+static int fsv_bam_open_impl(const char *path, fsv_bam **out)
 {
     if (!path || !out) return FSV_EINVAL;
     fsv_bam *b = new fsv_bam();
@@ -346,7 +347,9 @@ extern "C" int fsv_bam_open(const char *path, fsv_bam **out)
     if (!b->f) { delete b; return FSV_EINVAL; }
     b->n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     char magic[4]; int32_t l_text = 0, n_ref = 0;
-    bool ok = bgzf_read(b, magic, 4) && !memcmp(magic, "BAM\1", 4) && bgzf_read(b, &l_text, 4) && l_text >= 0;
+    bool ok = false;
+    try {
+    ok = bgzf_read(b, magic, 4) && !memcmp(magic, "BAM\1", 4) && bgzf_read(b, &l_text, 4) && l_text >= 0;
     if (ok) { std::vector<char> text((size_t)l_text); ok = l_text == 0 || bgzf_read(b, text.data(), (size_t)l_text); }
     ok = ok && bgzf_read(b, &n_ref, 4) && n_ref >= 0;
     for (int32_t r = 0; ok && r < n_ref; r++) {
@@ -354,10 +357,11 @@ extern "C" int fsv_bam_open(const char *path, fsv_bam **out)
         ok = bgzf_read(b, &l_name, 4) && l_name > 0 && l_name < (1 << 16);
         std::vector<char> nm((size_t)std::max(1, l_name));
         ok = ok && bgzf_read(b, nm.data(), (size_t)l_name) && bgzf_read(b, &l_ref, 4);
-        if (ok) { b->ref_name.emplace_back(nm.data()); b->ref_len.push_back(l_ref); }
+        if (ok) { b->ref_name.emplace_back(nm.data(), strnlen(nm.data(), (size_t)l_name)); b->ref_len.push_back(l_ref); }   // the name may lack its NUL
     }
+    if (ok) load_bai(b);
+    } catch (...) { fclose(b->f); delete b; throw; }
     if (!ok) { fclose(b->f); delete b; return FSV_EINVAL; }
-    load_bai(b);
     *out = b;
     return FSV_OK;
 }
@@ -388,7 +392,7 @@ extern "C" int fsv_bam_has_index(const fsv_bam *b) { return b && b->have_index ?
 // caller allocates and calls again.  want_seq bit 0: also the bases, 2 bits each as in the read store (N -> A), read r at word
 // seq_word_off[r]; bit 1: the bases as text (what pysam's read.seq gives), read r at seq_ascii + seq_ascii_off[r].  ref_id -1: every
 // record of the file, unmapped ones included -- fetch(until_eof=True) of output_fas.py:26.
-extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, fsv_bam_records *out, int want_seq)
+static int fsv_bam_fetch_impl(fsv_bam *b, int ref_id, int64_t beg, int64_t end, fsv_bam_records *out, int want_seq)
 {
     if (!b || !out || ref_id < -1 || ref_id >= (int)b->ref_name.size()) return FSV_EINVAL;
     const bool all = ref_id == -1;   // every record of the file in file order, unmapped ones included: fetch(until_eof=True)
@@ -414,13 +418,13 @@ extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, f
         // no index: from the first record (skip the header again)
         if (!bgzf_seek(b, 0)) return FSV_EINVAL;
         char magic[4]; int32_t l_text = 0, n_ref = 0;
-        if (!bgzf_read(b, magic, 4) || !bgzf_read(b, &l_text, 4)) return FSV_EINVAL;
+        if (!bgzf_read(b, magic, 4) || !bgzf_read(b, &l_text, 4) || l_text < 0) return FSV_EINVAL;
         std::vector<char> skip((size_t)l_text);
         if (l_text && !bgzf_read(b, skip.data(), (size_t)l_text)) return FSV_EINVAL;
-        if (!bgzf_read(b, &n_ref, 4)) return FSV_EINVAL;
+        if (!bgzf_read(b, &n_ref, 4) || n_ref < 0) return FSV_EINVAL;
         for (int32_t r = 0; r < n_ref; r++) {
             int32_t l_name = 0, l_ref = 0;
-            if (!bgzf_read(b, &l_name, 4)) return FSV_EINVAL;
+            if (!bgzf_read(b, &l_name, 4) || l_name <= 0 || l_name >= (1 << 16)) return FSV_EINVAL;
             skip.resize((size_t)l_name);
             if (!bgzf_read(b, skip.data(), (size_t)l_name) || !bgzf_read(b, &l_ref, 4)) return FSV_EINVAL;
         }
@@ -546,7 +550,7 @@ __global__ void k_cigar_sigs(const int32_t *__restrict__ pos, const uint8_t *__r
 }
 } // namespace
 
-extern "C" int fsv_read_signatures(fsv_ctx *ctx, const fsv_bam_records *rec, int min_mapq, int min_svlen, fsv_read_sig *out, uint32_t cap, uint32_t *n_out)
+static int fsv_read_signatures_impl(fsv_ctx *ctx, const fsv_bam_records *rec, int min_mapq, int min_svlen, fsv_read_sig *out, uint32_t cap, uint32_t *n_out)
 {
     if (!ctx || !rec || !out || !n_out) return FSV_EINVAL;
     *n_out = 0;
@@ -576,4 +580,28 @@ extern "C" int fsv_read_signatures(fsv_ctx *ctx, const fsv_bam_records *rec, int
     }
     for (void *p : {d_pos, d_mq, d_off, d_nop, d_cig, d_out, d_n}) if (p) (void)hipFree(p);
     return rc;
+}
+
+// no C++ exception crosses the C ABI (a caller through ctypes would see std::terminate)
+extern "C" int fsv_bam_open(const char *path, fsv_bam **out)
+{
+    try { return fsv_bam_open_impl(path, out); }
+    catch (const std::bad_alloc &) { return FSV_ENOMEM; }
+    catch (...) { return FSV_EINVAL; }
+}
+
+// no C++ exception crosses the C ABI (a caller through ctypes would see std::terminate)
+extern "C" int fsv_bam_fetch(fsv_bam *b, int ref_id, int64_t beg, int64_t end, fsv_bam_records *out, int want_seq)
+{
+    try { return fsv_bam_fetch_impl(b, ref_id, beg, end, out, want_seq); }
+    catch (const std::bad_alloc &) { return FSV_ENOMEM; }
+    catch (...) { return FSV_EINVAL; }
+}
+
+// no C++ exception crosses the C ABI (a caller through ctypes would see std::terminate)
+extern "C" int fsv_read_signatures(fsv_ctx *ctx, const fsv_bam_records *rec, int min_mapq, int min_svlen, fsv_read_sig *out, uint32_t cap, uint32_t *n_out)
+{
+    try { return fsv_read_signatures_impl(ctx, rec, min_mapq, min_svlen, out, cap, n_out); }
+    catch (const std::bad_alloc &) { return FSV_ENOMEM; }
+    catch (...) { return FSV_EINVAL; }
 }

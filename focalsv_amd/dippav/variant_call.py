@@ -117,6 +117,11 @@ def dippav_variant_call(data_type, read_bam_file, reference_path, hp1_contig_pat
     try:
         keep = [i for i, w in enumerate(wins) if w[0] == chrom and seqs[i]]
         rec, cigar, status = ctx.align_batch([seqs[i].encode() for i in keep], [win_index[wins[i]] for i in keep], refs)
+        for i, st in zip(keep, status):      # a refused contig yields no record: say so instead of losing its SVs silently
+            if int(st) < 0:
+                logging.getLogger("focalsv_amd").error("%s: the aligner refused this contig (status %d); no alignment record, its SVs are not called", names[i], int(st))
+            elif int(st) > 0:
+                logging.getLogger("focalsv_amd").warning("%s: no chain against its reference window (unaligned)", names[i])
         # read signatures (extract_reads_signature.py): from the records handed in, or straight from the BAM
         if read_records is None and read_bam_file:
             from .. import bam

@@ -88,7 +88,11 @@ def output_fa(fd, out_dir=None, logger=None):
 
 def pack_record_sets(recs: B.FetchedRecords, sets: List[List[int]]) -> PackedBatch:
     """record index lists -> the 2-bit read store (recs fetched with want_seq & 1): a gather of whole words, reads stay on word
-    boundaries as fsv_pack_reads lays them out"""
+    boundaries as fsv_pack_reads lays them out.  Records without bases (SEQ '*', l_seq 0: minimap2 writes secondary alignments
+    that way) are left out here, after the grouping and the name de-duplication have seen them as the reference's do
+    (output_fas.py:63-73 writes such a read as an empty / "None" line, which no assembler uses): the FASTA path drops empty
+    sequences the same way (fasta.read_reads), and one zero-length read would have fsv_assemble_batch refuse the whole batch."""
+    sets = [[r for r in s if recs.l_seq[r] > 0] for s in sets]
     idx = np.asarray([r for s in sets for r in s], dtype=np.int64)
     lens = recs.l_seq[idx].astype(np.int32) if len(idx) else np.zeros(0, np.int32)
     nw = (lens.astype(np.int64) + 15) // 16

@@ -7,6 +7,7 @@ Region-level data parallelism: `shard_regions` deals regions to ranks largest-fi
 collective while computing); `gather_vcf` is the one exchange step -- the analogue of `cat chr*/...vcf | vcf-sort`
 (focalsv/focalsv.py:66-70) -- an all-gather of per-rank VCF bytes (RCCL on GPUs, gloo in the CPU tests).
 """
+import logging
 import threading
 import time
 from dataclasses import dataclass, field
@@ -18,6 +19,45 @@ from . import _lib
 from .dippav import fp_filter, reads_signature, redundancy, signatures as S, vcf
 from .dippav.variant_call import WindowedRef, call_chromosome, records_from_alignment
 from .readsets import PackedBatch, pack_sets
+
+
+log = logging.getLogger("focalsv_amd")
+
+_SET_WARNINGS = {1: "minimizers truncated", 2: "anchors truncated", 4: "no layout (no contig, as hifiasm)", 8: "consensus insertion events dropped",
+                 16: "a corrected window kept uncorrected", 32: "internal minimizer slot overflow"}
+
+
+def describe_set_status(st: int) -> str:
+    if st < 0:
+        return "error %d" % st
+    return ", ".join(txt for bit, txt in _SET_WARNINGS.items() if st & bit) or "ok"
+
+
+def report_statuses(regions, set_region, set_kind, set_status, cref, names, contig_status):
+    """one log line per read set / contig the library flagged -- a contig the aligner refused yields no record and its SVs would
+    otherwise vanish without a trace -> names of the regions with a hard failure (negative status)"""
+    failed = []
+    for s, st in enumerate(set_status):
+        st = int(st)
+        if st == 0:
+            continue
+        reg = regions[set_region[s]].name or "region %d" % set_region[s]
+        kind = "unphased" if set_kind[s] == 0 else "hp%d" % set_kind[s]
+        (log.error if st < 0 else log.warning)("%s %s read set: assembly status %d (%s)", reg, kind, st, describe_set_status(st))
+        if st < 0:
+            failed.append(reg)
+    for i, st in enumerate(contig_status):
+        st = int(st)
+        if st == 0:
+            continue
+        reg = regions[cref[i]].name or "region %d" % cref[i]
+        if st < 0:
+            log.error("%s %s: the aligner refused this contig (status %d: %s); no alignment record, its SVs are not called", reg, names[i][0], st,
+                      {_lib.EUNSUP: "window or event beyond what the kernels hold", _lib.ECAP: "CIGAR-run or event capacity exceeded"}.get(st, "error"))
+            failed.append(reg)
+        else:
+            log.warning("%s %s: no chain against the reference window (unaligned)", reg, names[i][0])
+    return sorted(set(failed))
 
 
 @dataclass
@@ -64,6 +104,7 @@ class CallResult:
     asm_stats: Dict
     aln_stats: Dict
     host_ms: Dict = field(default_factory=dict)   # wall time of the host-side stages of this call
+    failed_regions: List[str] = field(default_factory=list)   # regions with a read set or contig the library refused (logged)
 
     @property
     def contigs(self) -> List[Tuple[int, int, bytes]]:
@@ -287,6 +328,7 @@ def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, ch
     rec, cigar, contig_status = ctx.align_batch(None, cref, batch.refs or [r.ref for r in regions], aln_params) if len(contigs) else (np.zeros(0, _lib.ALN_REC_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.int32))
     aln_stats = ctx.aln_stats() if len(contigs) else {}
     lap("align_call")
+    failed = report_statuses(regions, set_region, set_kind, set_status, cref, names, contig_status)
     yield None
     t_prev[0] = time.perf_counter()
     records = records_from_alignment(rec, cigar, names, [regions[i].chrom for i in cref], [regions[i].start for i in cref])
@@ -305,7 +347,7 @@ def _run_hot_path(ctx, regions, pk, batch, data_type, asm_params, aln_params, ch
     lap("fp_filter")
     header, final, dropped = redundancy.collapse(vcf.HEADER_LINES, kept)
     lap("redundancy")
-    yield CallResult(header, final, raw, contigs, cref, chp, set_status, contig_status, asm_stats, aln_stats, host_ms)
+    yield CallResult(header, final, raw, contigs, cref, chp, set_status, contig_status, asm_stats, aln_stats, host_ms, failed)
 
 
 def run_hot_path_lanes(ctxs: Sequence[_lib.Context], batches: Sequence[DeviceBatch], **kw) -> Tuple[List[CallResult], List[str]]:
@@ -436,20 +478,25 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     cl.start()
     out: List[CallResult] = []
     nxt = 0
-    while True:
+    try:
+        while True:
+            with ready:
+                while nxt not in results and not errs and any(t.is_alive() for t in fin):
+                    ready.wait(0.05)
+                r = None if errs else results.pop(nxt, None)
+            if r is None:       # something failed, or every batch has been finished and handed out
+                break
+            if on_result is not None:
+                on_result(nxt, r)
+            if keep_results:
+                out.append(r)
+            nxt += 1
+            with ready:
+                state["consumed"] = nxt
+                ready.notify_all()
+    except BaseException as e:      # on_result raised (or KeyboardInterrupt): the lanes stop taking batches, what is in flight drains
+        errs.insert(0, e)
         with ready:
-            while nxt not in results and not errs and any(t.is_alive() for t in fin):
-                ready.wait(0.05)
-            r = None if errs else results.pop(nxt, None)
-        if r is None:       # something failed, or every batch has been finished and handed out
-            break
-        if on_result is not None:
-            on_result(nxt, r)
-        if keep_results:
-            out.append(r)
-        nxt += 1
-        with ready:
-            state["consumed"] = nxt
             ready.notify_all()
     cl.join()
     for t in th + fin:
@@ -496,15 +543,23 @@ class RegionQueue:
     iterates `batches()`; a batch is a list of region indices.  Without an initialised process group it degrades to one
     rank that takes everything."""
 
+    _made = 0     # queues built so far in this process: every rank builds its queues in the same order, so the count names the queue
+
     def __init__(self, work: Sequence[int], batch: int = 64, static_fraction: float = 0.75, store=None, rank: Optional[int] = None,
-                 world_size: Optional[int] = None, key: str = "fsv_region_cursor"):
+                 world_size: Optional[int] = None, key: Optional[str] = None):
         import torch.distributed as dist
         if rank is None:
             live = dist.is_available() and dist.is_initialized()
             rank, world_size = (dist.get_rank(), dist.get_world_size()) if live else (0, 1)
             if live and store is None and world_size > 1:
                 store = dist.distributed_c10d._get_default_store()
+        # the shared cursor is a counter in the store under a key of its own: a second queue on the same process group (the next
+        # chromosome, the next step) must not start from the first one's final count
+        if key is None:
+            key = "fsv_region_cursor_%d" % RegionQueue._made
+        RegionQueue._made += 1
         self.rank, self.world, self.store, self.key, self.batch = rank, world_size, store, key, max(1, batch)
+        self.n_static_batches = self.n_stolen_batches = 0
         order = sorted(range(len(work)), key=lambda i: (-work[i], i))
         n_static = len(order) if self.world == 1 else int(len(order) * static_fraction)
         head = order[:n_static]
@@ -513,7 +568,9 @@ class RegionQueue:
         self.tail = order[n_static:]
 
     def batches(self):
+        """one pass over this rank's share (a queue is used once: the cursor only moves forward)"""
         for b in range(0, len(self.static), self.batch):
+            self.n_static_batches += 1
             yield self.static[b:b + self.batch]
         if not self.tail:
             return
@@ -523,6 +580,7 @@ class RegionQueue:
             k = (self.store.add(self.key, 1) - 1) if self.store is not None else self._local_next()
             if k >= n_batches:
                 return
+            self.n_stolen_batches += 1
             yield self.tail[k * self.batch:(k + 1) * self.batch]
 
     def _local_next(self):

@@ -198,6 +198,9 @@ typedef struct fsv_contigs {
 #define FSV_W_MZ_TRUNC     1  /* a read had more minimizers than the per-read cap; the rest were ignored */
 #define FSV_W_ANCHOR_TRUNC 2  /* a read pair had more anchors than the chaining tile holds */
 #define FSV_W_NO_LAYOUT    4  /* no chain of min_contig_reads reads: the set has no contig (hifiasm writes an empty GFA for it too) */
+#define FSV_W_INS_EVENTS   8  /* a consensus window saw more inserted-base events than its buffer holds; the extra votes were dropped */
+#define FSV_W_WINDOW_KEPT 16  /* a corrected window would have outgrown its slot; the read keeps that window uncorrected */
+#define FSV_W_INTERNAL    32  /* a minimizer slot overflowed (cannot happen: one minimizer per base at most) */
 
 /* capacity needed for fsv_contigs.seq / contig count for these read sets */
 int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap);

@@ -220,6 +220,27 @@ def test_pack_record_sets_equals_pack_reads(tmp_path):
     assert np.array_equal(pk.words[:n], ref.words[:n]) and len(pk.words) >= n + 4
 
 
+def test_records_without_bases_do_not_reach_the_store(tmp_path):
+    """a secondary record with SEQ '*' ahead of its primary -- grouped and de-duplicated by name as the reference does
+    (the first record of a name wins), then left out of the packed store instead of arriving as a zero-length read"""
+    import numpy as np
+    from focalsv_amd import output_fas
+    recs = _phased_records(22, [1001], n=30)
+    first = min(range(len(recs)), key=lambda i: recs[i]["pos"])
+    ghost = dict(recs[first]); ghost["seq"] = ""; ghost["flag"] = recs[first].get("flag", 0) | 256; ghost["pos"] = max(0, recs[first]["pos"] - 1)
+    ghost["cigar"] = [(0, 100)]
+    allr = sorted(recs + [ghost], key=lambda r: r["pos"])
+    path = W.write_bam(str(tmp_path / "z.bam"), [("chr1", 60000)], allr, index=False)
+    with B.BamFile(path) as f:
+        got = f.fetch(until_eof=True, want_seq=3)
+    files = output_fas.read_set_files(got)
+    n_listed = sum(len(v) for v in files.values())
+    pk = output_fas.pack_record_sets(got, [files[k] for k in sorted(files)])
+    assert (pk.read_len > 0).all() and len(pk.read_len) == int(pk.set_start[-1])
+    assert len(pk.read_len) < n_listed                          # the base-less record was listed (it won its name) and then dropped
+    assert sum(1 for v in files.values() for r in v if got.l_seq[r] == 0) == n_listed - len(pk.read_len)
+
+
 def _golden_bams(tmp_path, golden_dir):
     import json
     import os
@@ -350,6 +371,78 @@ def test_corrupted_records_fail_cleanly(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", child] + paths, capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
     assert res.returncode == 0 and "survived" in res.stdout, res.stderr[-500:]
+
+
+def test_corrupted_header_and_index_fail_cleanly(tmp_path):
+    """the same for the BAM header (l_text, n_ref, l_name, a name without its NUL) and for the .bai (negative or
+    absurd n_bin / n_chunk / n_intv): an FsvError, or records read without the index -- never an exception across the C ABI"""
+    import os
+    import struct
+    import subprocess
+    import sys
+    import zlib
+    recs = make_records(6, n=30, ref_lens=(200000,))
+    base = W.write_bam(str(tmp_path / "hb.bam"), [("chr1", 200000)], recs, index=True)
+    raw, stream, p = open(base, "rb").read(), bytearray(), 0
+    while p < len(raw):
+        bs = struct.unpack("<H", raw[p + 16:p + 18])[0] + 1
+        stream += zlib.decompress(raw[p + 18:p + bs - 8], -15)
+        p += bs
+    l_text = struct.unpack("<i", stream[4:8])[0]
+    hdr_end = 12 + l_text + 4 + 5 + 4            # magic, l_text, text, n_ref, l_name, "chr1\0", l_ref
+    rng = random.Random(8)
+    paths = []
+    weird = [-1, -2 ** 31, 2 ** 31 - 1, 1 << 24, 70000, 0]
+    for it in range(30):
+        s = bytearray(stream)
+        if it < 12:      # the length fields themselves
+            off = [4, 8 + l_text, 12 + l_text][it % 3]
+            s[off:off + 4] = struct.pack("<i", weird[(it // 3) % len(weird)] if it < 18 else 0)
+        elif it < 16:    # reference name without a terminating NUL
+            s[12 + l_text + 4 + 4] = ord("X")
+        else:
+            for _ in range(rng.choice([1, 3, 8])):
+                s[rng.randrange(hdr_end)] = rng.randrange(256)
+        out = bytearray()
+        for o in range(0, len(s), 0xff00):
+            out += W._bgzf_block(bytes(s[o:o + 0xff00]))
+        out += W._bgzf_block(b"")
+        fn = str(tmp_path / ("h%d.bam" % it))
+        open(fn, "wb").write(bytes(out))
+        paths.append(fn)
+    bai = open(base + ".bai", "rb").read()
+    for it in range(30):
+        b = bytearray(bai)
+        if it < 15:
+            off = [8, 12, 16][it % 3] if it < 9 else rng.randrange(8, len(b) - 4)     # n_ref | n_bin | first bin ... or anywhere
+            b[off:off + 4] = struct.pack("<i", weird[it % len(weird)])
+        elif it < 22:
+            b = b[:rng.randrange(4, len(b))]
+        else:
+            for _ in range(rng.choice([1, 4, 16])):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+        fn = str(tmp_path / ("i%d.bam" % it))
+        open(fn, "wb").write(raw)
+        open(fn + ".bai", "wb").write(bytes(b))
+        paths.append(fn)
+    child = (
+        "import sys\n"
+        "from focalsv_amd import _lib, bam as B\n"
+        "n_ok = 0\n"
+        "for fn in sys.argv[1:]:\n"
+        "    try:\n"
+        "        with B.BamFile(fn, threads=2) as f:\n"
+        "            for rid in [None] + f.references[:1]:\n"
+        "                r = f.fetch(rid, 1000, 150000, want_seq=3) if rid else f.fetch(until_eof=True, want_seq=3)\n"
+        "                r.names\n"
+        "                n_ok += 1\n"
+        "    except (_lib.FsvError, KeyError, ValueError, UnicodeDecodeError, IndexError):\n"
+        "        pass\n"
+        "print('survived', n_ok)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", child] + paths, capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
+    assert res.returncode == 0 and "survived" in res.stdout, res.stderr[-500:]
+    assert int(res.stdout.split()[-1]) >= 30      # a damaged index never costs the records (whole-file scan instead)
 
 
 def test_streamed_region_cut_equals_per_region_fetch(tmp_path):

@@ -69,6 +69,11 @@ def _queue_worker(rank, world, port, q):
             time.sleep(0.002)          # a slow rank: the other one should drain most of the tail
     q.put((rank, got, len(rq.static)))
     dist.barrier()
+    # a second queue on the same process group (the next chromosome): its cursor starts from zero again
+    rq2 = pipeline.RegionQueue(work[:300], batch=16)
+    got2 = [i for b in rq2.batches() for i in b]
+    q.put((rank + 10, got2, rq2.n_stolen_batches))
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -79,10 +84,14 @@ def test_region_queue_gloo_world2_covers_every_region_once():
     ps = [ctx.Process(target=_queue_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=120) for _ in range(2)]
+    res = [q.get(timeout=120) for _ in range(4)]
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
+    second = [r for r in res if r[0] >= 10]
+    res = [r for r in res if r[0] < 10]
+    assert sorted(i for _, got, _ in second for i in got) == list(range(300))      # second queue: every region once, tail included
+    assert sum(n for _, _, n in second) == (300 - int(300 * 0.75) + 15) // 16
     allr = sorted(i for _, got, _ in res for i in got)
     assert allr == list(range(1000))                       # every region exactly once
     by = {r: (len(got), ns) for r, got, ns in res}

@@ -83,3 +83,33 @@ def test_failures_come_back_to_the_caller(monkeypatch):
     monkeypatch.setattr(pipeline, "launch_hot_path", lambda ctx, batch, **kw: _Pending(weakref.WeakSet()))
     with pytest.raises(KeyError):
         pipeline.run_stream(list("ab"), producer())
+
+
+def test_on_result_failure_stops_the_stream_and_leaves_no_thread(fake):
+    """an exception out of on_result (a failing gather, KeyboardInterrupt) used to leave the lanes spinning in take()"""
+    import threading
+
+    def on_result(i, r):
+        if i == 2:
+            raise RuntimeError("gather failed")
+
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="gather failed"):
+        pipeline.run_stream(list("ab"), iter([object()] * 1000), on_result=on_result, keep_results=False)
+    assert time.time() - t0 < 20
+    assert not [t.name for t in threading.enumerate() if t.name.startswith("fsv-")]
+
+
+def test_refused_sets_and_contigs_are_logged(caplog):
+    """statuses the library returns are reported, and hard failures name their region"""
+    import logging
+    from focalsv_amd import _lib
+    regions = [pipeline.RegionInput("chr21", 0, b"A", [], [], name="Region_chr21_S1_E2"), pipeline.RegionInput("chr21", 9, b"A", [], [], name="Region_chr21_S9_E99")]
+    with caplog.at_level(logging.WARNING, logger="focalsv_amd"):
+        failed = pipeline.report_statuses(regions, [0, 0, 1, 1], [1, 2, 1, 2], [0, 8 | 4, 0, _lib.EUNSUP], [0, 1, 1], [["contig_hp1_0"], ["contig_hp1_1"], ["contig_hp2_0"]],
+                                          [0, _lib.EUNSUP, 1])
+    assert failed == ["Region_chr21_S9_E99"]
+    text = caplog.text
+    assert "Region_chr21_S1_E2 hp2 read set: assembly status 12" in text and "insertion events dropped" in text and "no layout" in text
+    assert "contig_hp1_1: the aligner refused this contig (status -6" in text and "contig_hp2_0: no chain" in text
+    assert "Region_chr21_S9_E99 hp2 read set: assembly status -6" in text
