@@ -21,27 +21,42 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-// HIP-event timing of individual kernels on the context's stream; resolved once at the end of the batch
+// HIP-event timing of kernels and of whole stages on the context's stream: recorded while the work is queued, resolved once
+// at the end of the batch -- nothing here waits for the GPU (round 1's stage timers synchronised the stream twice each)
 struct KTimes {
     struct Rec { int k; hipEvent_t a, b; uint64_t bytes; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     hipEvent_t get() { if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); } return pool[used++]; }
-    void begin(fsv_ctx *ctx, int k, uint64_t bytes) { Rec r{k, get(), get(), bytes}; (void)hipEventRecord(r.a, ctx->stream); recs.push_back(r); }
+    size_t begin(fsv_ctx *ctx, int k, uint64_t bytes) { Rec r{k, get(), get(), bytes}; (void)hipEventRecord(r.a, ctx->stream); recs.push_back(r); return recs.size() - 1; }
     void end(fsv_ctx *ctx) { (void)hipEventRecord(recs.back().b, ctx->stream); }
+    void end(fsv_ctx *ctx, size_t idx) { (void)hipEventRecord(recs[idx].b, ctx->stream); }
     void reset() { recs.clear(); used = 0; }
     ~KTimes() { for (auto e : pool) (void)hipEventDestroy(e); }
 };
-enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_COUNT };
+enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_COUNT,
+       ST_SKETCH = KN_COUNT, ST_CHAIN, ST_VERIFY, ST_PATH, ST_CONSENSUS, ST_FINAL };
 const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm", "k_rescue_accept", "k_path_fast", "k_path_dp", "k_consensus",
                                         "k_repack", "k_exact", "k_stitch"};
 
+// a stage: from construction to stop(), in stream order
+struct Span {
+    fsv_ctx *ctx; KTimes &kt; size_t idx;
+    Span(fsv_ctx *c, KTimes &k, int stage) : ctx(c), kt(k), idx(k.begin(c, stage, 0)) {}
+    void stop() { kt.end(ctx, idx); }
+};
+
+// per-round block of device counters (one 64-byte slot per correction round + one for the final pass, zeroed once per batch and
+// read back with the round's one synchronisation or at the end): u32 indices
+enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4, CT_COLS_HI = 5, CT_DP_WIDE = 6, CT_DP_SB = 7, CT_DP_GEN = 8,
+       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_SLOT = 16 };
+
 struct AsmWs {
-    DevBuf store[2], word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, set_cols, trans, read_flag, changed,
+    DevBuf store[2], cols_sb, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, set_cols, trans, read_flag, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
-    uint64_t last_chain_bytes = 0;
+    std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -52,8 +67,8 @@ struct AsmWs {
     void *h_pin = nullptr; size_t h_pin_cap = 0; // pinned host staging (exact hits)
     std::vector<DevBuf *> all()
     {
-        return {&store[0], &store[1], &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &set_cols, &trans, &read_flag, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+        return {&store[0], &store[1], &cols_sb, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &set_cols, &trans, &read_flag, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -91,13 +106,6 @@ template <class T> int upload(fsv_ctx *ctx, DevBuf &b, const std::vector<T> &v)
     FSV_HIP(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return FSV_OK;
 }
-
-struct Timer {
-    std::chrono::steady_clock::time_point t0;
-    fsv_ctx *ctx;
-    explicit Timer(fsv_ctx *c) : ctx(c) { (void)hipStreamSynchronize(c->stream); t0 = std::chrono::steady_clock::now(); }
-    double stop() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
-};
 
 uint8_t thr_for_len_host(int x_len)
 {
@@ -151,17 +159,16 @@ int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len,
     return FSV_OK;
 }
 
-// sketch + per-read index + chaining on the current store; fills ws.ovl (and ws.tasks when emit_tasks)
+// sketch + per-read index + chaining on the current store; fills ws.ovl (and ws.tasks when emit_tasks).  Nothing here waits
+// for the GPU: launches are sized from the read lengths the host already has, counts stay in the round's counter slot `ct`.
 int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, const uint32_t *store, const fsv_asm_params &P, int bw,
-                  bool emit_tasks, uint32_t task_cap, const uint32_t *only_changed = nullptr)
+                  bool emit_tasks, uint32_t task_cap, uint32_t *ct, bool short_reads, const uint32_t *only_changed = nullptr)
 {
-    Timer ts(ctx);
+    Span ts(ctx, W.kt, ST_SKETCH);
     TRY(ensure(ctx, W.mz, (size_t)G.mz_off[B.n_reads] * sizeof(fsv_mz)));
     TRY(ensure(ctx, W.mz_cnt, (size_t)B.n_reads * 4));
     TRY(ensure(ctx, W.ovl, (size_t)std::max(1u, B.n_pairs) * sizeof(fsv_ovl)));
     TRY(ensure(ctx, W.ovl_c, (size_t)std::max(1u, B.n_pairs) * sizeof(uint4)));
-    TRY(ensure(ctx, W.counters, 64));
-    FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, 64, ctx->stream));
     W.kt.begin(ctx, KN_SKETCH, (uint64_t)G.word_off[B.n_reads] * 4 + (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz));
     if (!(only_changed && (P.k & 1))) FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)B.n_reads * 4, ctx->stream));
     // (with only_changed the unchanged reads keep their count; the kernel zeroes the others itself)
@@ -188,58 +195,42 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
         FSV_HIP(ctx, hipGetLastError());
     }
     W.kt.end(ctx);
-    // the sort in k_uniq holds a read's minimizers in LDS: size it to the longest list of the batch (16 B per entry), so that
-    // short-read batches keep many reads per CU
-    std::vector<uint32_t> cnt(B.n_reads);
-    FSV_HIP(ctx, hipMemcpyAsync(cnt.data(), W.mz_cnt.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
-    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t max_raw = 0;
-    for (uint32_t r = 0; r < B.n_reads; r++) max_raw = std::max(max_raw, cnt[r]);
+    // the sort in k_uniq holds a read's minimizers in LDS (16 B per entry): one instantiation for lists up to 1 024 entries (many
+    // reads per CU), one for longer ones; each launch skips the reads of the other size class, so the host need not know the
+    // longest list of the batch (round 1 read the counts back to choose)
+    unsigned long long *mz_total = (unsigned long long *)(ct + CT_MZ_LO);
     W.kt.begin(ctx, KN_UNIQ, (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz) * 2);
-    if (max_raw <= 1024)
-        hipLaunchKernelGGL(k_uniq<1024>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
-                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed);
-    else
-        hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
-                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed);
+    hipLaunchKernelGGL(k_uniq<1024>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
+                       (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed, 0u, 1024u, mz_total);
     FSV_HIP(ctx, hipGetLastError());
+    if (G.max_words * 16u > 1024u) {   // at most one minimizer per base: shorter reads cannot have a longer list
+        hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
+                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed, 1024u, 0xffffffffu, mz_total);
+        FSV_HIP(ctx, hipGetLastError());
+    }
     W.kt.end(ctx);
-    W.stats.ms_sketch += ts.stop();
+    ts.stop();
     if (B.n_pairs == 0) return FSV_OK;
-    Timer tc(ctx);
+    Span tc(ctx, W.kt, ST_CHAIN);
     ChainArgs A;
     A.store = store; A.word_off = (const uint32_t *)W.word_off.p; A.read_len = (const int32_t *)W.len.p;
     A.set_start = (const uint32_t *)W.set_start.p; A.pair_base = (const uint32_t *)W.pair_base.p; A.upair_base = (const uint32_t *)W.upair_base.p;
     A.mz = (const fsv_mz *)W.mz.p; A.mz_off = (const uint32_t *)W.mz_off.p; A.mz_cnt = (const uint32_t *)W.mz_cnt.p;
-    A.ovl = (fsv_ovl *)W.ovl.p; A.tasks = (fsv_wtask *)W.tasks.p; A.task_counter = (uint32_t *)W.counters.p; A.task_cap = task_cap;
-    TRY(ensure(ctx, W.set_cols, (size_t)B.n_reads * 4));
-    FSV_HIP(ctx, hipMemsetAsync(W.set_cols.p, 0, (size_t)B.n_reads * 4, ctx->stream));
-    A.overflow = (uint32_t *)W.counters.p + 1; A.warn = (uint32_t *)W.warn.p; A.set_cols = (uint32_t *)W.set_cols.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
+    A.ovl = (fsv_ovl *)W.ovl.p; A.tasks = (fsv_wtask *)W.tasks.p; A.task_counter = ct + CT_TASKS; A.task_cap = task_cap;
+    A.overflow = ct + CT_OVERFLOW; A.warn = (uint32_t *)W.warn.p; A.set_cols = (uint32_t *)W.set_cols.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
     A.n_sets = B.n_sets; A.k_score = P.k; A.min_anchors = P.min_anchors; A.min_ovlp = P.min_ovlp; A.bw = bw; A.emit_tasks = emit_tasks ? 1 : 0;
-    // algorithmic bytes of the pairwise join: every unordered pair reads both unique-minimizer lists (16 B each) and writes two
-    // overlap slots; the window tasks it emits are added once their number is known
-    uint64_t chain_bytes = (uint64_t)B.n_pairs * sizeof(fsv_ovl);
-    uint32_t max_cnt = 0;
-    {
-        FSV_HIP(ctx, hipMemcpyAsync(cnt.data(), W.mz_cnt.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
-        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t s2 = 0; s2 < B.n_sets; s2++) {
-            const uint64_t ns = B.set_start[s2 + 1] - B.set_start[s2];
-            uint64_t tot = 0;
-            for (uint32_t r = B.set_start[s2]; r < B.set_start[s2 + 1]; r++) { tot += cnt[r]; if (ns > 1) max_cnt = std::max(max_cnt, cnt[r]); }
-            if (ns > 1) chain_bytes += (ns - 1) * tot * sizeof(fsv_mz); // every unordered pair reads both lists once
-        }
-    }
-    // LDS per pair = 24 B x the longest minimizer list of the batch (rounded up to 64, at most FSV_AMAX): more pairs per CU
-    A.upair_tab = (const uint4 *)W.upair_tab.p; A.pair_list = nullptr;
-    A.amax = (int32_t)std::min<uint32_t>(FSV_AMAX, std::max<uint32_t>(64u, (max_cnt + 63u) / 64u * 64u));
-    W.kt.begin(ctx, KN_CHAIN, chain_bytes);
-    hipLaunchKernelGGL(k_chain, dim3(B.n_upairs), dim3(64), (size_t)A.amax * 24, ctx->stream, A);
+    // LDS per pair: the anchor arrays for FSV_AMAX entries -- 12 B each in the compact layout (every read of the batch below
+    // 65 536 bases), so the tile no longer has to be cut to the batch's longest list to keep several pairs per CU
+    A.upair_tab = (const uint4 *)W.upair_tab.p; A.pair_list = nullptr; A.n_list_dev = nullptr;
+    A.amax = FSV_AMAX;
+    // algorithmic bytes of the launch are filled in when the batch ends (they need the counts this launch leaves on the device)
+    W.chain_rec.push_back(W.kt.begin(ctx, KN_CHAIN, 0));
+    if (short_reads) hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A.amax), ctx->stream, A);
+    else hipLaunchKernelGGL(k_chain<false>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(false, A.amax), ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
     W.last_chain = A;
-    W.last_chain_bytes = chain_bytes;
-    W.stats.ms_chain += tc.stop();
+    tc.stop();
     return FSV_OK;
 }
 
@@ -342,8 +333,8 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
     for (uint32_t i = 0; i < n_tasks; i++)
         if (tasks[i].k > FSV_K_MAX || tasks[i].x_len == 0 || tasks[i].x_len > FSV_WINDOW) return fsv_fail(ctx, FSV_EINVAL, "task k/x_len out of range");
     FSV_HIP(ctx, hipSetDevice(ctx->device));
-    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_cnt, d_cols, d_cols2;
-    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_cnt, &d_cols, &d_cols2}) if (b->p) (void)hipFree(b->p); };
+    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_list2, d_list3, d_wide, d_cnt, d_cols, d_cols_sb;
+    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_list2, &d_list3, &d_wide, &d_cnt, &d_cols, &d_cols_sb}) if (b->p) (void)hipFree(b->p); };
     int rc = FSV_OK;
     auto run = [&]() -> int {
         std::vector<fsv_wtask> t(tasks, tasks + n_tasks);
@@ -356,42 +347,34 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         TRY(upload(ctx, d_ovl, std::vector<fsv_ovl>{o}));
         TRY(ensure(ctx, d_res, (size_t)n_tasks * sizeof(fsv_wres)));
         TRY(ensure(ctx, d_paths, (size_t)n_tasks * sizeof(fsv_wpath)));
-        TRY(ensure(ctx, d_list, (size_t)n_tasks * 4));
-        TRY(ensure(ctx, d_cnt, 64));
-        FSV_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, 64, ctx->stream));
+        for (DevBuf *b : {&d_list, &d_list2, &d_list3, &d_wide}) TRY(ensure(ctx, *b, (size_t)n_tasks * 4));
+        TRY(ensure(ctx, d_cnt, CT_SLOT * 4));
+        uint32_t *ct = (uint32_t *)d_cnt.p;
+        FSV_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, CT_SLOT * 4, ctx->stream));
         FSV_HIP(ctx, hipMemsetAsync(d_paths.p, 0, (size_t)n_tasks * sizeof(fsv_wpath), ctx->stream));
+        // the same launches as a correction round of fsv_assemble_batch (device-side list lengths, no host round trip in between)
         TRY(fsv_bpm_windows_dev(ctx, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, n_tasks, (fsv_wres *)d_res.p));
         hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_ovl *)d_ovl.p,
                            (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p, n_tasks, (fsv_wpath *)d_paths.p, (uint32_t *)d_list.p,
-                           (uint32_t *)d_cnt.p + 2, (uint32_t *)d_cnt.p + 6, true);
+                           ct + CT_DP, (uint32_t *)d_wide.p, ct + CT_DP_WIDE, true, (const uint32_t *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
-        uint32_t cnt[8];
-        FSV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        DevBuf &d_list2 = d_cols2;
-        const uint32_t *narrow = (const uint32_t *)d_list.p;
-        if (cnt[2]) {
-            TRY(ensure(ctx, d_list2, (size_t)cnt[2] * 4));
-            hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(cnt[2], 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
-                               (const fsv_wres *)d_res.p, (const uint32_t *)d_list.p, cnt[2], (fsv_wpath *)d_paths.p, (uint32_t *)d_list2.p, (uint32_t *)d_cnt.p + 7);
-            FSV_HIP(ctx, hipGetLastError());
-            FSV_HIP(ctx, hipMemcpyAsync(&cnt[2], (uint32_t *)d_cnt.p + 7, 4, hipMemcpyDeviceToHost, ctx->stream));
-            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            narrow = (const uint32_t *)d_list2.p;
-        }
-        for (int wide = 0; wide < 2; wide++) {
-            const uint32_t n_here = wide ? cnt[6] : cnt[2], list0 = wide ? n_tasks - cnt[6] : 0u;
-            if (!n_here) continue;
-            const uint32_t grid = std::min<uint32_t>(fsv_grid_for(n_here, 64), 8u * (uint32_t)ctx->n_cu);
-            TRY(ensure(ctx, d_cols, (size_t)grid * 64 * (FSV_WINDOW + 2) * 3 * (wide ? 8 : 4)));
-            if (wide)
-                hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
-                                   (const uint32_t *)d_list.p, list0, list0 + n_here, (fsv_wpath *)d_paths.p, (uint64_t *)d_cols.p, grid * 64);
-            else
-                hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
-                                   narrow, list0, list0 + n_here, (fsv_wpath *)d_paths.p, (uint32_t *)d_cols.p, grid * 64);
-            FSV_HIP(ctx, hipGetLastError());
-        }
+        hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
+                           (const fsv_wres *)d_res.p, (const uint32_t *)d_list.p, 0u, (fsv_wpath *)d_paths.p, (uint32_t *)d_list2.p, ct + CT_DP_SB,
+                           (const uint32_t *)(ct + CT_DP), (uint32_t *)d_list3.p, ct + CT_DP_GEN);
+        FSV_HIP(ctx, hipGetLastError());
+        const uint32_t grid = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 8u * (uint32_t)ctx->n_cu);
+        TRY(ensure(ctx, d_cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
+        hipLaunchKernelGGL(k_path_sb, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+                           (const uint32_t *)d_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)d_paths.p, (uint4 *)d_cols_sb.p);
+        FSV_HIP(ctx, hipGetLastError());
+        const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 2u * (uint32_t)ctx->n_cu);
+        TRY(ensure(ctx, d_cols, (size_t)gridg * 64 * (FSV_WINDOW + 2) * 3 * 8));
+        hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(gridg), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
+                           (const uint32_t *)d_list3.p, 0u, 0u, (fsv_wpath *)d_paths.p, (uint32_t *)d_cols.p, gridg * 64, (const uint32_t *)(ct + CT_DP_GEN));
+        FSV_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(gridg), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
+                           (const uint32_t *)d_wide.p, 0u, 0u, (fsv_wpath *)d_paths.p, (uint64_t *)d_cols.p, gridg * 64, (const uint32_t *)(ct + CT_DP_WIDE));
+        FSV_HIP(ctx, hipGetLastError());
         FSV_HIP(ctx, hipMemcpyAsync(res, d_res.p, (size_t)n_tasks * sizeof(fsv_wres), hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipMemcpyAsync(paths, d_paths.p, (size_t)n_tasks * sizeof(fsv_wpath), hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -421,7 +404,8 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     AsmWs &W = *ws_get(ctx);
     memset(&W.stats, 0, sizeof(W.stats));
     W.kt.reset();
-    Timer ttotal(ctx);
+    W.chain_rec.clear(); W.bpm_rec.clear(); W.rescue_rec.clear(); W.fast_rec.clear(); W.dp_rec.clear(); W.cons_rec.clear();
+    const auto t_enter = std::chrono::steady_clock::now();
 
     Batch B;
     B.n_reads = sets->n_reads; B.n_sets = sets->n_sets;
@@ -490,9 +474,20 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     G.word_off = woff0;
     const uint32_t *store = sets->store_dev;
     uint64_t reads_in_bytes = 0;
-    for (uint32_t r = 0; r < B.n_reads; r++) reads_in_bytes += (uint64_t)(len[r] + 3) / 4;
+    bool short_reads = true;     // every read below 65 536 bases: k_chain's compact LDS layout
+    for (uint32_t r = 0; r < B.n_reads; r++) { reads_in_bytes += (uint64_t)(len[r] + 3) / 4; if (len[r] >= 65536) short_reads = false; }
+    TRY(ensure(ctx, W.counters, (size_t)(P.n_rounds + 1) * CT_SLOT * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, (size_t)(P.n_rounds + 1) * CT_SLOT * 4, ctx->stream));
+    TRY(ensure(ctx, W.set_cols, (size_t)B.n_reads * 4));       // K5 columns per set, summed over the rounds (statistics)
+    FSV_HIP(ctx, hipMemsetAsync(W.set_cols.p, 0, (size_t)B.n_reads * 4, ctx->stream));
 
+    // every launch of a round is sized from what the host knows when the round starts (read lengths, the window-task bound);
+    // counts the kernels produce stay in the round's counter slot.  One synchronisation per round is left: the corrected reads'
+    // lengths, which the host turns into the next round's geometry -- the round's counters ride along with it.
+    auto ct_of = [&](int slot) { return (uint32_t *)W.counters.p + (size_t)slot * CT_SLOT; };
+    std::vector<uint32_t> h_ct((size_t)(P.n_rounds + 1) * CT_SLOT, 0u);
     for (int round = 0; round < P.n_rounds; round++) {
+        uint32_t *ct = ct_of(round);
         TRY(upload(ctx, W.word_off, G.word_off));
         TRY(upload(ctx, W.len, len));
         TRY(upload(ctx, W.mz_off, G.mz_off));
@@ -502,93 +497,69 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         const uint32_t task_cap = (uint32_t)std::max<uint64_t>(G.task_bound, 1);
         TRY(ensure(ctx, W.tasks, (size_t)task_cap * sizeof(fsv_wtask)));
         TRY(ensure(ctx, W.res, (size_t)task_cap * sizeof(fsv_wres)));
-        TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_ec, true, task_cap));
-        uint32_t cnt[4] = {0, 0, 0, 0};
-        FSV_HIP(ctx, hipMemcpyAsync(cnt, W.counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (cnt[1]) return fsv_fail(ctx, FSV_ECAP, "internal window task buffer overflow");
-        const uint32_t n_tasks = cnt[0];
+        TRY(ensure(ctx, W.paths, (size_t)task_cap * sizeof(fsv_wpath)));
+        TRY(ensure(ctx, W.dp_list, (size_t)task_cap * 4));
+        TRY(ensure(ctx, W.dp_list2, (size_t)task_cap * 4));
+        TRY(ensure(ctx, W.dp_list3, (size_t)task_cap * 4));
+        TRY(ensure(ctx, W.dp_wide, (size_t)task_cap * 4));
+        TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_ec, true, task_cap, ct, short_reads));
         W.stats.n_pairs += B.n_pairs;
-        W.stats.n_windows += n_tasks;
-        if (n_tasks) {
-            Timer tv(ctx);
-            W.kt.begin(ctx, KN_BPM, (uint64_t)n_tasks * (32 + 196 + 16));
-            TRY(fsv_bpm_windows_dev(ctx, store, (const fsv_wtask *)W.tasks.p, n_tasks, (fsv_wres *)W.res.p));
+        if (B.n_pairs) {
+            Span tv(ctx, W.kt, ST_VERIFY);
+            W.bpm_rec.push_back(W.kt.begin(ctx, KN_BPM, 0));
+            TRY(fsv_bpm_windows_dev_n(ctx, store, (const fsv_wtask *)W.tasks.p, task_cap, ct + CT_TASKS, (fsv_wres *)W.res.p));
             W.kt.end(ctx);
-            W.kt.begin(ctx, KN_RESCUE, (uint64_t)n_tasks * 48 + (uint64_t)B.n_pairs * sizeof(fsv_ovl) * 2);
+            W.rescue_rec.push_back(W.kt.begin(ctx, KN_RESCUE, (uint64_t)B.n_pairs * sizeof(fsv_ovl) * 2));
             hipLaunchKernelGGL(k_rescue_accept, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
-                               B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)((uint32_t *)W.counters.p + 4),
+                               B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)(ct + CT_COLS_LO),
                                (uint4 *)W.ovl_c.p);
             FSV_HIP(ctx, hipGetLastError());
             W.kt.end(ctx);
-            W.stats.ms_verify += tv.stop();
-            Timer tp(ctx);
-            TRY(ensure(ctx, W.paths, (size_t)n_tasks * sizeof(fsv_wpath)));
-            TRY(ensure(ctx, W.dp_list, (size_t)n_tasks * 4));
-            W.kt.begin(ctx, KN_PATH_FAST, (uint64_t)n_tasks * (48 + 128));
-            hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
-                               (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, n_tasks, (fsv_wpath *)W.paths.p,
-                               (uint32_t *)W.dp_list.p, (uint32_t *)W.counters.p + 2, (uint32_t *)W.counters.p + 6, false);
+            tv.stop();
+            Span tp(ctx, W.kt, ST_PATH);
+            W.fast_rec.push_back(W.kt.begin(ctx, KN_PATH_FAST, 0));
+            hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
+                               (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, task_cap, (fsv_wpath *)W.paths.p,
+                               (uint32_t *)W.dp_list.p, ct + CT_DP, (uint32_t *)W.dp_wide.p, ct + CT_DP_WIDE, false, (const uint32_t *)(ct + CT_TASKS));
             FSV_HIP(ctx, hipGetLastError());
             W.kt.end(ctx);
-            uint32_t cnt2[8];
-            FSV_HIP(ctx, hipMemcpyAsync(cnt2, W.counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            W.stats.dp_columns += (uint64_t)cnt2[4] | (uint64_t)cnt2[5] << 32;   // rescue re-runs (k_rescue_accept)
+            // single-indel windows are settled without the DP (k_path_indel1); what is left goes to the sub-band kernel
+            // (distance <= FSV_SB_MAXERR) or to the general one
+            hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                               (const fsv_wres *)W.res.p, (const uint32_t *)W.dp_list.p, 0u, (fsv_wpath *)W.paths.p, (uint32_t *)W.dp_list2.p, ct + CT_DP_SB,
+                               (const uint32_t *)(ct + CT_DP), (uint32_t *)W.dp_list3.p, ct + CT_DP_GEN);
+            FSV_HIP(ctx, hipGetLastError());
+            // persistent grids: as many blocks as the device holds at once, each striding through its list, so the column scratch
+            // is a fixed few hundred MB whatever the number of windows
+            W.dp_rec.push_back(W.kt.begin(ctx, KN_PATH_DP, 0));
             {
-                std::vector<uint32_t> sc(B.n_reads);
-                FSV_HIP(ctx, hipMemcpyAsync(sc.data(), W.set_cols.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
-                FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                for (uint32_t s2 = 0; s2 < B.n_sets; s2++) if (B.set_start[s2] < B.n_reads) W.stats.dp_columns += sc[B.set_start[s2]]; // K5 windows
-            }
-            uint32_t n_dp = cnt2[2];
-            const uint32_t n_dp_wide = cnt2[6];
-            const uint32_t *narrow_list = (const uint32_t *)W.dp_list.p;
-            if (n_dp) {
-                // single-indel windows are settled without the DP (k_path_indel1); the rest is compacted into a second list
-                TRY(ensure(ctx, W.dp_list2, (size_t)n_dp * 4));
-                uint32_t *n2_dev = (uint32_t *)W.counters.p + 7;
-                hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(n_dp, 256)), dim3(256), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                                   (const fsv_wres *)W.res.p, (const uint32_t *)W.dp_list.p, n_dp, (fsv_wpath *)W.paths.p, (uint32_t *)W.dp_list2.p, n2_dev);
-                FSV_HIP(ctx, hipGetLastError());
-                uint32_t n2 = 0;
-                FSV_HIP(ctx, hipMemcpyAsync(&n2, n2_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
-                FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                W.stats.n_path_indel1 += n_dp - n2;
-                n_dp = n2;
-                narrow_list = (const uint32_t *)W.dp_list2.p;
-            }
-            W.stats.n_path_dp += n_dp + n_dp_wide;
-            // narrow bands: [0, n_dp) of the list with 32-bit column words; wide bands: the last n_dp_wide entries with 64-bit words
-            for (int wide = 0; wide < 2; wide++) {
-                const uint32_t n_here = wide ? n_dp_wide : n_dp, list0 = wide ? n_tasks - n_dp_wide : 0u;
-                if (!n_here) continue;
-                // persistent grid: as many blocks as the device holds at once (LDS- and wave-limited), each striding through the list
                 int per_cu = 0;
-                auto launch = [&](auto kern, auto *colp) -> int {
-                    FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0));
-                    const uint32_t grid = std::min<uint32_t>(fsv_grid_for(n_here, 64), (uint32_t)std::max(1, per_cu) * (uint32_t)ctx->n_cu);
-                    const uint32_t stride = grid * 64;
-                    TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * sizeof(*colp)));
-                    W.kt.begin(ctx, KN_PATH_DP, (uint64_t)n_here * (32 + 196 + 128));
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                                       wide ? (const uint32_t *)W.dp_list.p : narrow_list, list0, list0 + n_here, (fsv_wpath *)W.paths.p, (decltype(colp))W.cols.p, stride);
-                    return FSV_OK;
-                };
-                if (wide) TRY(launch(k_path_dp<uint64_t>, (uint64_t *)nullptr));
-                else TRY(launch(k_path_dp<uint32_t>, (uint32_t *)nullptr));
+                FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_sb, 64, 0));
+                const uint32_t grid = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, per_cu) * (uint32_t)ctx->n_cu);
+                TRY(ensure(ctx, W.cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
+                hipLaunchKernelGGL(k_path_sb, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p,
+                                   (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)W.paths.p, (uint4 *)W.cols_sb.p);
                 FSV_HIP(ctx, hipGetLastError());
-                W.kt.end(ctx);
+                // the general kernel's lists are short (rescue windows, distances above 7): two blocks per CU are plenty
+                const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 2u * (uint32_t)ctx->n_cu), stride = gridg * 64;
+                TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * sizeof(uint64_t)));
+                hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(gridg), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                                   (const uint32_t *)W.dp_list3.p, 0u, 0u, (fsv_wpath *)W.paths.p, (uint32_t *)W.cols.p, stride, (const uint32_t *)(ct + CT_DP_GEN));
+                FSV_HIP(ctx, hipGetLastError());
+                hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(gridg), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
+                                   (const uint32_t *)W.dp_wide.p, 0u, 0u, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p, stride, (const uint32_t *)(ct + CT_DP_WIDE));
+                FSV_HIP(ctx, hipGetLastError());
             }
-            W.stats.ms_path += tp.stop();
+            W.kt.end(ctx);
+            tp.stop();
         }
         // consensus -> corrected windows -> new read store
-        Timer tcs(ctx);
+        Span tcs(ctx, W.kt, ST_CONSENSUS);
         const uint32_t n_gwin = G.gwin_off[B.n_reads];
         TRY(ensure(ctx, W.cwin, (size_t)n_gwin * FSV_CW_STRIDE));
         TRY(ensure(ctx, W.cwin_len, (size_t)n_gwin * 2));
         TRY(ensure(ctx, W.new_len, (size_t)B.n_reads * 4));
-        if (!n_tasks) { TRY(ensure(ctx, W.paths, sizeof(fsv_wpath))); FSV_HIP(ctx, hipMemsetAsync(W.ovl_c.p, 0, (size_t)std::max(1u, B.n_pairs) * sizeof(uint4), ctx->stream)); }
+        if (!B.n_pairs) FSV_HIP(ctx, hipMemsetAsync(W.ovl_c.p, 0, sizeof(uint4), ctx->stream));
         TRY(ensure(ctx, W.gwin_tab, (size_t)std::max(1u, n_gwin) * sizeof(uint4)));
         hipLaunchKernelGGL(k_gwin_tab, dim3(fsv_grid_for(n_gwin, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_read.p, (const uint32_t *)W.gwin_off.p,
                            (const uint32_t *)W.read_set.p, (const uint32_t *)W.set_start.p, (const uint32_t *)W.pair_base.p, n_gwin, (uint4 *)W.gwin_tab.p);
@@ -603,7 +574,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         TRY(ensure(ctx, W.changed, (size_t)B.n_reads * 4));
         FSV_HIP(ctx, hipMemsetAsync(W.changed.p, 0, (size_t)B.n_reads * 4, ctx->stream));
         C.changed = (uint32_t *)W.changed.p;
-        if (any_unphased && n_tasks && B.n_pairs) {
+        if (any_unphased && B.n_pairs) {
             // unphased sets: mark the overlaps that carry the other allele at a heterozygous column, then take them out of
             // the consensus (and, through is_match = 2, out of what the final pass accepts as verified)
             TRY(ensure(ctx, W.trans, (size_t)B.n_pairs * 4));
@@ -614,16 +585,19 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
                                (const uint32_t *)W.trans.p, B.n_pairs);
             FSV_HIP(ctx, hipGetLastError());
         }
-        W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_tasks * 128 + (uint64_t)n_gwin * (96 + 448));
+        W.cons_rec.push_back(W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_gwin * (96 + 448)));
         hipLaunchKernelGGL(k_consensus, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);
         hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
                            (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p);
         FSV_HIP(ctx, hipGetLastError());
+        // the round's one synchronisation: new read lengths (+ this round's counters)
         std::vector<int32_t> nlen(B.n_reads);
         FSV_HIP(ctx, hipMemcpyAsync(nlen.data(), W.new_len.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipMemcpyAsync(h_ct.data() + (size_t)round * CT_SLOT, ct, CT_SLOT * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_ct[(size_t)round * CT_SLOT + CT_OVERFLOW]) return fsv_fail(ctx, FSV_ECAP, "internal window task buffer overflow");
         Geometry G2;
         TRY(make_geometry(ctx, B, nlen, G2, P.w, &mz_fixed));
         DevBuf &dst = W.store[round & 1];
@@ -638,14 +612,16 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);
         FSV_HIP(ctx, hipMemsetAsync((uint8_t *)dst.p + (size_t)total_words * 4, 0, 32, ctx->stream));
-        W.stats.ms_consensus += tcs.stop();
+        tcs.stop();
         store = (const uint32_t *)dst.p;
         len = nlen;
+        for (int32_t l : len) if (l >= 65536) short_reads = false;
         G = G2;
     }
 
     // final overlaps on the corrected reads
-    Timer tf(ctx);
+    Span tf(ctx, W.kt, ST_FINAL);
+    uint32_t *ctf = ct_of(P.n_rounds);
     auto tr0 = std::chrono::steady_clock::now();
     auto trace = [&](const char *what) { if (getenv("FSV_TRACE")) { (void)hipStreamSynchronize(ctx->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[fsv] final %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tr0).count()); tr0 = t; } };
     TRY(upload(ctx, W.word_off, G.word_off));
@@ -660,10 +636,11 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         FSV_HIP(ctx, hipMemcpyAsync(W.ovl_prev.p, W.ovl.p, (size_t)B.n_pairs * sizeof(fsv_ovl), hipMemcpyDeviceToDevice, ctx->stream));
     }
     // reads the last round left untouched keep that round's minimizer lists (the last round does not reverse-complement)
-    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0, P.n_rounds > 0 ? (const uint32_t *)W.changed.p : nullptr));
+    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0, ctf, short_reads, P.n_rounds > 0 ? (const uint32_t *)W.changed.p : nullptr));
     trace("overlaps");
     const fsv_hit *hraw = nullptr;
     std::vector<uint32_t> hit_first(B.n_sets + 1, 0);
+    std::vector<uint32_t> hwarn(B.n_reads), h_setcols(B.n_reads, 0u);
     if (B.n_pairs) {
         TRY(ensure(ctx, W.hits, (size_t)B.n_pairs * sizeof(fsv_hit)));
         TRY(ensure(ctx, W.set_hits, (size_t)(2 * B.n_sets + 2) * 4));
@@ -676,36 +653,38 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);
         if (have_prev) {
-            // pairs without an exact overlap that the last correction round had verified: gapped re-chain, accept per direction
+            // pairs without an exact overlap that the last correction round had verified: gapped re-chain, accept per direction.
+            // The list's length stays on the device: the re-chain is launched over every pair slot and the blocks beyond the list
+            // return at once (a few hundred pairs are listed out of hundreds of thousands; the empty blocks cost ~40 us)
             TRY(ensure(ctx, W.inexact_list, (size_t)B.n_upairs * 4 + 16));
-            uint32_t *n_list_dev = (uint32_t *)W.counters.p + 3;
-            FSV_HIP(ctx, hipMemsetAsync(n_list_dev, 0, 4, ctx->stream));
+            uint32_t *n_list_dev = ctf + CT_INEXACT;
             hipLaunchKernelGGL(k_inexact_list, dim3(fsv_grid_for(B.n_upairs, 256)), dim3(256), 0, ctx->stream, (const uint4 *)W.upair_tab.p,
                                (const uint8_t *)W.exact_flag.p, (const fsv_ovl *)W.ovl_prev.p, B.n_upairs, (uint32_t *)W.inexact_list.p, n_list_dev);
             FSV_HIP(ctx, hipGetLastError());
-            uint32_t n_list = 0;
-            FSV_HIP(ctx, hipMemcpyAsync(&n_list, n_list_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
-            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (n_list) {
-                ChainArgs A2 = W.last_chain;
-                A2.bw = 1; A2.emit_tasks = 0; A2.pair_list = (const uint32_t *)W.inexact_list.p;
-                // timed like the other k_chain launches (a profiler counts it too); its share of the pair lists as algorithmic bytes
-                W.kt.begin(ctx, KN_CHAIN, B.n_upairs ? W.last_chain_bytes / B.n_upairs * n_list : 0);
-                hipLaunchKernelGGL(k_chain, dim3(n_list), dim3(64), (size_t)A2.amax * 24, ctx->stream, A2);
-                FSV_HIP(ctx, hipGetLastError());
-                W.kt.end(ctx);
-                hipLaunchKernelGGL(k_accept_inexact, dim3(fsv_grid_for(2 * n_list, 256)), dim3(256), 0, ctx->stream, (const uint4 *)W.upair_tab.p,
-                                   (const uint32_t *)W.inexact_list.p, n_list, (const fsv_ovl *)W.ovl.p, (const fsv_ovl *)W.ovl_prev.p,
-                                   (const uint32_t *)W.read_set.p, (const uint32_t *)W.pair_base.p, (fsv_hit *)W.hits.p, (uint32_t *)W.set_hits.p);
-                FSV_HIP(ctx, hipGetLastError());
-            }
-            W.stats.n_inexact_candidates = n_list;
+            ChainArgs A2 = W.last_chain;
+            A2.bw = 1; A2.emit_tasks = 0; A2.pair_list = (const uint32_t *)W.inexact_list.p; A2.n_list_dev = n_list_dev;
+            // timed like the other k_chain launches (a profiler counts it too)
+            W.kt.begin(ctx, KN_CHAIN, 0);
+            if (short_reads) hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A2.amax), ctx->stream, A2);
+            else hipLaunchKernelGGL(k_chain<false>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(false, A2.amax), ctx->stream, A2);
+            FSV_HIP(ctx, hipGetLastError());
+            W.kt.end(ctx);
+            hipLaunchKernelGGL(k_accept_inexact, dim3(fsv_grid_for(2ull * B.n_upairs, 256)), dim3(256), 0, ctx->stream, (const uint4 *)W.upair_tab.p,
+                               (const uint32_t *)W.inexact_list.p, 0u, (const fsv_ovl *)W.ovl.p, (const fsv_ovl *)W.ovl_prev.p,
+                               (const uint32_t *)W.read_set.p, (const uint32_t *)W.pair_base.p, (fsv_hit *)W.hits.p, (uint32_t *)W.set_hits.p,
+                               (const uint32_t *)n_list_dev);
+            FSV_HIP(ctx, hipGetLastError());
         }
         // per-set counts -> offsets; the segments are packed on the device and come back in one copy, already grouped by set.
         // The order inside a set depends on atomics and does not matter: the layout's containment marks and "longest arc,
-        // smallest target on ties" choices are order-independent.
+        // smallest target on ties" choices are order-independent.  The warnings and the batch's counters ride along.
         FSV_HIP(ctx, hipMemcpyAsync(hit_first.data() + 1, W.set_hits.p, (size_t)B.n_sets * 4, hipMemcpyDeviceToHost, ctx->stream));
-        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    FSV_HIP(ctx, hipMemcpyAsync(hwarn.data(), W.warn.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipMemcpyAsync(h_setcols.data(), W.set_cols.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipMemcpyAsync(h_ct.data() + (size_t)P.n_rounds * CT_SLOT, ctf, CT_SLOT * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (B.n_pairs) {
         for (uint32_t s2 = 0; s2 < B.n_sets; s2++) hit_first[s2 + 1] += hit_first[s2];
         const uint32_t nh = hit_first[B.n_sets];
         if ((size_t)nh * sizeof(fsv_hit) > W.h_pin_cap) {
@@ -727,9 +706,6 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         W.stats.n_exact_overlaps = nh;
     }
     trace("exact+gather");
-    std::vector<uint32_t> hwarn(B.n_reads);
-    FSV_HIP(ctx, hipMemcpyAsync(hwarn.data(), W.warn.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
-    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
     // layout per set (host), then stitch on the device
     std::vector<fsv_piece> pieces;
@@ -789,17 +765,50 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     trace("stitch+d2h");
-    W.stats.ms_final += tf.stop();
+    tf.stop();
     W.h_word_off = G.word_off; W.h_len = len; W.cur_store = store; W.n_reads = B.n_reads;
+    // statistics out of the counter slots (one per correction round, one for the final pass)
+    uint64_t mz_total[17] = {0};
+    for (int sl = 0; sl <= P.n_rounds; sl++) {
+        const uint32_t *c = h_ct.data() + (size_t)sl * CT_SLOT;
+        mz_total[sl] = (uint64_t)c[CT_MZ_LO] | (uint64_t)c[CT_MZ_HI] << 32;
+        if (sl == P.n_rounds) { W.stats.n_inexact_candidates = c[CT_INEXACT]; break; }
+        W.stats.n_windows += c[CT_TASKS];
+        W.stats.dp_columns += (uint64_t)c[CT_COLS_LO] | (uint64_t)c[CT_COLS_HI] << 32;      // rescue re-runs (k_rescue_accept)
+        W.stats.n_path_dp += (uint64_t)c[CT_DP_SB] + c[CT_DP_GEN] + c[CT_DP_WIDE];
+        W.stats.n_path_indel1 += (uint64_t)c[CT_DP] - c[CT_DP_SB] - c[CT_DP_GEN];
+        // algorithmic bytes of the round's launches, now that the counts are known: a window task is
+        // 94 + 102 B of 2-bit operands + 16 B of result; a K6 window leaves a 128 B path record instead;
+        // k_chain reads every unique-minimizer list once (two sorted copies, 16 B entries) and writes the overlap slots and
+        // the 32 B task records; the consensus reads the path records and writes its corrected windows
+        const uint64_t nt = c[CT_TASKS];
+        if ((size_t)sl < W.bpm_rec.size()) W.kt.recs[W.bpm_rec[sl]].bytes = nt * 212ull;
+        if ((size_t)sl < W.rescue_rec.size()) W.kt.recs[W.rescue_rec[sl]].bytes += nt * 16ull;
+        if ((size_t)sl < W.fast_rec.size()) W.kt.recs[W.fast_rec[sl]].bytes = nt * (16ull + 196ull) + (nt - c[CT_DP] - c[CT_DP_WIDE]) * 128ull;
+        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = ((uint64_t)c[CT_DP_SB] + c[CT_DP_GEN] + c[CT_DP_WIDE]) * (196ull + 128ull);
+        if ((size_t)sl < W.cons_rec.size()) W.kt.recs[W.cons_rec[sl]].bytes += nt * 128ull;
+    }
+    for (size_t i = 0; i < W.chain_rec.size(); i++) {
+        const uint32_t *c = h_ct.data() + i * CT_SLOT;
+        W.kt.recs[W.chain_rec[i]].bytes = mz_total[i] * 32ull + (uint64_t)B.n_pairs * sizeof(fsv_ovl) + (i < (size_t)P.n_rounds ? (uint64_t)c[CT_TASKS] * sizeof(fsv_wtask) : 0ull);
+    }
+    for (uint32_t s2 = 0; s2 < B.n_sets; s2++) if (B.set_start[s2] < B.n_reads && B.set_start[s2 + 1] > B.set_start[s2]) W.stats.dp_columns += h_setcols[B.set_start[s2]];   // K5 windows
     // algorithmic bytes: 2-bit operands + result of every DP task, reads in once per pass, contigs out
     W.stats.algo_bytes = W.stats.n_windows * 212ull + reads_in_bytes * (uint64_t)(P.n_rounds + 1) + used;
-    W.stats.ms_total = ttotal.stop();
+    W.stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
     // resolve the per-kernel event timings
     W.stats.n_kernels = KN_COUNT;
     for (int k = 0; k < KN_COUNT; k++) { memset(&W.stats.kernels[k], 0, sizeof(fsv_kernel_stat)); strncpy(W.stats.kernels[k].name, kn_names[k], 23); }
     for (auto &r : W.kt.recs) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) W.stats.kernels[r.k].ms += ms;
+        const bool ok = hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess;
+        if (r.k >= KN_COUNT) {   // a stage
+            double *dst = r.k == ST_SKETCH ? &W.stats.ms_sketch : r.k == ST_CHAIN ? &W.stats.ms_chain : r.k == ST_VERIFY ? &W.stats.ms_verify
+                        : r.k == ST_PATH ? &W.stats.ms_path : r.k == ST_CONSENSUS ? &W.stats.ms_consensus : &W.stats.ms_final;
+            if (ok) *dst += ms;
+            continue;
+        }
+        if (ok) W.stats.kernels[r.k].ms += ms;
         W.stats.kernels[r.k].launches++;
         W.stats.kernels[r.k].algo_bytes += r.bytes;
     }

@@ -14,12 +14,15 @@
 //   k_stitch          ma_ug_seq                                  Overlaps.cpp:8969-9034
 #pragma once
 #include "bpm_device.h"
+#include <type_traits>
 
 #define FSV_AMAX       1024  // anchors per read pair held in LDS
 #define FSV_UQ_MAX     4096  // minimizers per read sorted in LDS
 #define FSV_PATH_CAP    416  // ops per window path: x_len (<= 375) + y-only ops (<= k <= 31)
 #define FSV_CW_STRIDE   448  // bytes reserved per corrected grid window
 #define FSV_INS_MAXLEN   12
+#define FSV_SB_MAXERR    7   // k_path_sb: distances it holds in one word per column (2 x 7 + 1 rows x 2 bits)
+#define FSV_SB_QUADS ((FSV_WINDOW + 3) / 4)
 #define FSV_EV_CAP     256   // insertion events per grid window (HiFi at 30x: ~8; more sets the read's warning bit 8 and drops the excess)
 
 // fsv_wpath (include/focalsv_hip.h): 128 bytes per window task; state 2 = queued for the DP kernel (internal)
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
 // One workgroup per read: bitonic sort of (hash, pos) in LDS, keep hashes that occur exactly once.
 template <int UQ_MAX>
 __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
-                                              uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed = nullptr)
+                                              uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed = nullptr,
+                                              uint32_t lo_cnt = 0u, uint32_t hi_cnt = 0xffffffffu, unsigned long long *__restrict__ total = nullptr)
 {
     __shared__ uint64_t s_hash[UQ_MAX];
     __shared__ uint64_t s_pay[UQ_MAX]; // pos | rev << 32 | span << 40
@@ -213,6 +217,10 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
     if (only_changed && !only_changed[r]) return;   // lists of an unchanged read are already in place
+    // The sort holds a read's list in LDS, so the kernel is instantiated for short and for long lists (many reads per CU for
+    // the former) and launched once per size class: lo_cnt < raw count <= hi_cnt.  The small class runs first -- it replaces
+    // the raw count by the unique count, which can only be smaller, so the large class skips what the small one has done.
+    { const uint32_t raw = mz_cnt[r]; if (raw <= lo_cnt || raw > hi_cnt) return; }
     fsv_mz *a = mz + mz_off[r];
     uint32_t n = min(mz_cnt[r], mz_off[r + 1] - mz_off[r]); // k_sketch counts past the cap when it truncates
     if (n > UQ_MAX) { if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = UQ_MAX; }
@@ -250,7 +258,12 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
     }
     s_scan[tid] = cnt;
     __syncthreads();
-    if (tid == 0) { uint32_t acc = 0; for (int i = 0; i < 256; i++) { uint32_t c = s_scan[i]; s_scan[i] = acc; acc += c; } mz_cnt[r] = acc; }
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < 256; i++) { uint32_t c = s_scan[i]; s_scan[i] = acc; acc += c; }
+        mz_cnt[r] = acc;
+        if (total) atomicAdd(total, (unsigned long long)acc);   // statistics: unique minimizers of the launch
+    }
     __syncthreads();
     const uint32_t m = mz_cnt[r];
     const uint32_t o0 = s_scan[tid];
@@ -315,6 +328,7 @@ struct ChainArgs {
     const uint32_t *pair_base;   // n_sets + 1: ordered-pair slots
     const uint32_t *upair_base;  // n_sets + 1: unordered pairs (one block each)
     const uint32_t *pair_list;   // optional: block b works on unordered pair pair_list[b] (nullptr: pair b)
+    const uint32_t *n_list_dev;  // with pair_list: its length, left on the device by the kernel that built it (blocks beyond it return)
     const uint4 *upair_tab;      // per unordered pair: {first read of the set, q | t << 16, slot (q,t), slot (t,q)}  (k_pair_tab)
     int32_t amax;                // anchors per pair held in LDS (multiple of 64, <= FSV_AMAX): sizes the dynamic LDS
     const fsv_mz *mz;
@@ -353,16 +367,35 @@ __global__ void k_pair_tab(const uint32_t *__restrict__ set_start, const uint32_
 
 // One wavefront per UNORDERED read pair (q < t) of a set: the chain is computed with q as the query and the overlap of t on
 // q is its mirror image (oracle/asm.c collect_overlaps); both ordered slots and both window-task lists are written here.
+//
+// LDS per anchor.  SHORT (every read of the batch shorter than 65 536 bases -- all HiFi data): 12 B -- the anchor's two
+// positions as 16-bit halves of one word, score / run start / predecessor / chain entry as 16-bit values (a chain of at most
+// 1 024 anchors scores at most 1 024 x 63), the anchors' strands in a 128-byte bitmap, and the target's sorted hashes staged
+// in the 8 B the DP arrays do not need yet (position / span / strand of a hit come from the L2-resident list).  Round 1 used
+// 24 B (64-bit keys, 32-bit DP arrays, 12-byte staged records), which capped the kernel at 1-2 waves per SIMD on the batch's
+// longest lists; the long layout is kept for batches with a read of 65 536 bases or more.
+template <bool SHORT>
 __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int AMAX = A.amax;
-    uint64_t *const s_key = (uint64_t *)s_raw;                      // qe << 32 | te   (raw te first, strand-corrected later)
-    int32_t *const s_dp = (int32_t *)(s_raw + 8 * (size_t)AMAX);    // s_f | s_ind | s_sl ; doubles as the staged t records
-    uint16_t *const s_aux = (uint16_t *)(s_raw + 20 * (size_t)AMAX); // t span | strand << 8 ; later: predecessor index
-    uint16_t *const s_chain = (uint16_t *)(s_raw + 22 * (size_t)AMAX);
-    int32_t *const s_f = s_dp, *const s_ind = s_dp + AMAX;   // the third row only serves the staged t records
+    using key_t = typename std::conditional<SHORT, uint32_t, uint64_t>::type;   // qe << 16 | te   or   qe << 32 | te
+    using dp_t = typename std::conditional<SHORT, uint16_t, int32_t>::type;
+    constexpr int KSH = SHORT ? 16 : 32;
+    constexpr uint64_t KMASK = SHORT ? 0xffffull : 0xffffffffull;
+    key_t *const s_key = (key_t *)s_raw;
+    unsigned char *const s_rest = s_raw + sizeof(key_t) * (size_t)AMAX;
+    // SHORT: s_f | s_ind | s_aux | s_chain, 2 B each (8 B: the staged target hashes lie over all four)
+    // long:  s_f | s_ind | (4 B only used by the staged records) | s_aux | s_chain
+    dp_t *const s_f = (dp_t *)s_rest, *const s_ind = s_f + AMAX;
+    uint16_t *const s_aux = (uint16_t *)(s_rest + (SHORT ? 4 : 12) * (size_t)AMAX);   // long: t span | strand << 8; then the predecessor index
+    uint16_t *const s_chain = s_aux + AMAX;
+    uint32_t *const s_strand = (uint32_t *)(s_rest + (SHORT ? 8 : 16) * (size_t)AMAX);  // SHORT only: one strand bit per anchor (128 B)
+#define KEY_Q(i) ((int)((uint64_t)s_key[i] >> KSH))
+#define KEY_T(i) ((int)((uint64_t)s_key[i] & KMASK))
+#define MAKE_KEY(q_, t_) ((key_t)(((uint64_t)(uint32_t)(q_) << KSH) | (uint64_t)(uint32_t)(t_)))
     const int lane = threadIdx.x;
+    if (A.pair_list && A.n_list_dev && blockIdx.x >= *A.n_list_dev) return;
     const uint4 pt = A.upair_tab[A.pair_list ? A.pair_list[blockIdx.x] : blockIdx.x];
     const uint32_t q = pt.y & 0xffffu, t = pt.y >> 16;
     const uint32_t p = pt.z, pm = pt.w;     // ordered slots (q, t) and (t, q)
@@ -378,11 +411,11 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
 #define PUT_BOTH() do { if (lane == 0) { A.ovl[p] = o; A.ovl[pm] = om; } } while (0)
 
     // 1. anchors: every q minimizer is looked up in t's sorted unique list.  All global loads are issued up front -- t's
-    //    records go to LDS (hash 8 B + {pos, span, strand} 4 B: s_dp is free until the DP), q's records to registers (16 B
-    //    per lane per 64 minimizers) -- so a pair pays one memory latency instead of two per batch of 64 lookups; the ~10
-    //    probes of a lookup are LDS reads.
-    uint64_t *s_th = (uint64_t *)s_dp;
-    uint32_t *s_tp = (uint32_t *)(s_dp + 2 * AMAX);
+    //    hashes go to LDS (the long layout also stages {pos, span, strand}: 12 B per entry in the DP arrays, free until the
+    //    DP), q's records to registers (16 B per lane per 64 minimizers) -- so a pair pays one memory latency instead of two
+    //    per batch of 64 lookups; the ~10 probes of a lookup are LDS reads.
+    uint64_t *s_th = (uint64_t *)s_rest;
+    uint32_t *s_tp = (uint32_t *)(s_rest + 8 * (size_t)AMAX);   // long layout only
     const bool t_in_lds = nt <= AMAX && lent < (1 << 23);
     const uint4 *mq4 = (const uint4 *)mq, *mt4 = (const uint4 *)mt;
     constexpr int QR = FSV_AMAX / 64;   // AMAX <= FSV_AMAX
@@ -396,12 +429,13 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         for (int i = lane; i < nt; i += 64) {
             const uint4 b = mt4[i];
             s_th[i] = (uint64_t)b.x | (uint64_t)b.y << 32;
-            s_tp[i] = b.z | (b.w & 0xffu) << 31 | ((b.w >> 8) & 0xffu) << 23; // pos < 2^23 | span << 23 | strand << 31
+            if (!SHORT) s_tp[i] = b.z | (b.w & 0xffu) << 31 | ((b.w >> 8) & 0xffu) << 23; // pos < 2^23 | span << 23 | strand << 31
         }
+    if (SHORT) for (int i = lane; i < 32; i += 64) s_strand[i] = 0u;
     __syncthreads();
     int n = 0, nrev = 0, nfwd = 0;
     auto lookup = [&](int i, const uint4 av) {
-        bool hit = false; uint64_t key = 0; uint16_t aux = 0;
+        bool hit = false; key_t key = 0; uint32_t srev = 0, tspan = 0;
         if (i < nq) {
             const uint64_t ah = (uint64_t)av.x | (uint64_t)av.y << 32;
             const uint32_t arev = av.w & 0xffu;
@@ -412,24 +446,29 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
             if (t_in_lds) {
                 while (l2 < h2) { int mid = (l2 + h2) >> 1; if (s_th[mid] < ah) l2 = mid + 1; else h2 = mid; }
                 if (l2 < nt && s_th[l2] == ah) {
-                    const uint32_t tp = s_tp[l2];
-                    const uint32_t srev = arev ^ (tp >> 31);
-                    hit = true; key = (uint64_t)(srev ? qrev : av.z) << 32 | (tp & 0x7fffffu); aux = (uint16_t)(((tp >> 23) & 0xffu) | (srev << 8));
+                    uint32_t tpos;
+                    if (SHORT) { const uint4 b = mt4[l2]; tpos = b.z; srev = arev ^ (b.w & 0xffu); tspan = (b.w >> 8) & 0xffu; }
+                    else { const uint32_t tp = s_tp[l2]; tpos = tp & 0x7fffffu; srev = arev ^ (tp >> 31); tspan = (tp >> 23) & 0xffu; }
+                    hit = true; key = MAKE_KEY(srev ? qrev : av.z, tpos);
                 }
             } else {
                 while (l2 < h2) { int mid = (l2 + h2) >> 1; if (mt[mid].hash < ah) l2 = mid + 1; else h2 = mid; }
                 if (l2 < nt && mt[l2].hash == ah) {
                     fsv_mz b = mt[l2];
-                    const uint32_t srev = arev ^ b.rev;
-                    hit = true; key = (uint64_t)(srev ? qrev : av.z) << 32 | b.pos; aux = (uint16_t)(b.span | (srev << 8));
+                    srev = arev ^ b.rev; tspan = b.span;
+                    hit = true; key = MAKE_KEY(srev ? qrev : av.z, b.pos);
                 }
             }
         }
         uint64_t m = __ballot(hit);
         int at = n + __popcll(m & ((1ull << lane) - 1));
-        if (hit && at < AMAX) { s_key[at] = key; s_aux[at] = aux; }
-        nrev += __popcll(__ballot(hit && (aux >> 8)));
-        nfwd += __popcll(__ballot(hit && !(aux >> 8)));
+        if (hit && at < AMAX) {
+            s_key[at] = key;
+            if (SHORT) { if (srev) atomicOr(&s_strand[at >> 5], 1u << (at & 31)); }
+            else s_aux[at] = (uint16_t)(tspan | (srev << 8));
+        }
+        nrev += __popcll(__ballot(hit && srev));
+        nfwd += __popcll(__ballot(hit && !srev));
         n += __popcll(m);
     };
     if (q_in_regs) {
@@ -444,10 +483,10 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     int m2 = 0;
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
-        bool keep = false; uint64_t key = 0;
+        bool keep = false; key_t key = 0;
         if (i < n) {
             key = s_key[i];
-            keep = (s_aux[i] >> 8) == rev;
+            keep = (SHORT ? (int)((s_strand[i >> 5] >> (i & 31)) & 1u) : (int)(s_aux[i] >> 8)) == rev;
         }
         uint64_t m = __ballot(keep);
         int at = m2 + __popcll(m & ((1ull << lane) - 1));
@@ -462,7 +501,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     //    are distinct, so (qe, te) order == qe order) -- for a reverse-strand pair that is decreasing order on the query's reverse
     //    strand, so the list is turned around
     if (rev) {
-        for (int i = lane; i < n / 2; i += 64) { const uint64_t a0 = s_key[i], a1 = s_key[n - 1 - i]; s_key[i] = a1; s_key[n - 1 - i] = a0; }
+        for (int i = lane; i < n / 2; i += 64) { const key_t a0 = s_key[i], a1 = s_key[n - 1 - i]; s_key[i] = a1; s_key[n - 1 - i] = a0; }
         __syncthreads();
     }
     // 4. chain DP: lane l examines predecessor i-1-l (nearest first on ties).
@@ -472,27 +511,27 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     //    nearest predecessor winning ties -- so the chain is the whole list and the score a running sum.
     bool colinear;
     {
-        const int d0 = (int)(uint32_t)s_key[0] - (int)(s_key[0] >> 32);
+        const int d0 = KEY_T(0) - KEY_Q(0);
         bool same = true;
-        for (int i = lane; i < n; i += 64) same = same && ((int)(uint32_t)s_key[i] - (int)(s_key[i] >> 32) == d0);
+        for (int i = lane; i < n; i += 64) same = same && (KEY_T(i) - KEY_Q(i) == d0);
         colinear = __all(same);
     }
     if (colinear) {
         int acc = 0;
-        for (int i = 1 + lane; i < n; i += 64) acc += min((int)(s_key[i] >> 32) - (int)(s_key[i - 1] >> 32), A.k_score);
+        for (int i = 1 + lane; i < n; i += 64) acc += min(KEY_Q(i) - KEY_Q(i - 1), A.k_score);
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        for (int i = lane; i < n; i += 64) { s_aux[i] = (uint16_t)(i == 0 ? 0xffff : i - 1); s_f[i] = i == n - 1 ? A.k_score + acc : 0; }
+        for (int i = lane; i < n; i += 64) { s_aux[i] = (uint16_t)(i == 0 ? 0xffff : i - 1); s_f[i] = (dp_t)(i == n - 1 ? A.k_score + acc : 0); }
         __syncthreads();
     } else {
         // The 64 predecessors live in registers, lane l = anchor i-1-l: after anchor i is settled every lane hands its anchor to
         // the next lane (DPP wave_shr, lane 0 takes the new one), so an iteration has no LDS round trip on its critical path --
         // only the broadcast read of the next anchor, requested one iteration ahead, and the stores of f / predecessor.
         int rq = 0, rt = 0, rind = 0, rsl = 0, rf = 0;
-        uint64_t knext = s_key[0];
+        key_t knext = s_key[0];
         for (int i = 0; i < n; i++) {
-            const uint64_t ki = knext;
+            const key_t ki = knext;
             if (i + 1 < n) knext = s_key[i + 1];
-            const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
+            const int qe = (int)((uint64_t)ki >> KSH), te = (int)((uint64_t)ki & KMASK);
             const int j = i - 1 - lane;
             int cand = -1, ti = 0, tl = 0;
             if (j >= 0) {
@@ -525,7 +564,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
                 nf = bests; npred = i - 1 - wl;
                 nind = __builtin_amdgcn_readlane(ti, wl); nsl = __builtin_amdgcn_readlane(tl, wl);
             }
-            if (lane == 0) { s_f[i] = nf; s_aux[i] = (uint16_t)npred; }
+            if (lane == 0) { s_f[i] = (dp_t)nf; s_aux[i] = (uint16_t)npred; }
             rq = __builtin_amdgcn_update_dpp(qe, rq, 0x138, 0xF, 0xF, false);    // wave_shr:1, lane 0 <- the new anchor
             rt = __builtin_amdgcn_update_dpp(te, rt, 0x138, 0xF, 0xF, false);
             rind = __builtin_amdgcn_update_dpp(nind, rind, 0x138, 0xF, 0xF, false);
@@ -554,7 +593,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
             if (i >= n) v = -1;
             for (int off = 1; off < 64; off <<= 1) { const int o2 = __shfl_up(v, off, 64); if (lane >= off) v = max(v, o2); }
             v = max(v, carry);
-            if (i < n) s_ind[i] = v;
+            if (i < n) s_ind[i] = (dp_t)v;
             carry = __shfl(v, 63, 64);
         }
         __syncthreads();
@@ -569,8 +608,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     __syncthreads();
     if (cnt < A.min_anchors) { PUT_BOTH(); return; }
     const int first = s_chain[cnt - 1];
-    int xs = (int)(s_key[first] >> 32), ys = (int)(uint32_t)s_key[first];
-    int xe = (int)(s_key[best] >> 32), ye = (int)(uint32_t)s_key[best];
+    int xs = KEY_Q(first), ys = KEY_T(first);
+    int xe = KEY_Q(best), ye = KEY_T(best);
     { int m = min(xs, ys); xs -= m; ys -= m; int r = min(lenq - 1 - xe, lent - 1 - ye); xe += r; ye += r; }
     if (xe - xs + 1 < A.min_ovlp) { PUT_BOTH(); return; }
     const int score_best = s_f[best];
@@ -581,8 +620,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         { const int t0 = ys; ys = (lent - 1) - ye; ye = (lent - 1) - t0; }
         __syncthreads();
         for (int i = lane; i < n; i += 64) {
-            const uint64_t kk = s_key[i];
-            s_key[i] = (uint64_t)(uint32_t)((lenq - 1) - (int)(kk >> 32)) << 32 | (uint32_t)((lent - 1) - (int)(uint32_t)kk);
+            const int kq = KEY_Q(i), kt2 = KEY_T(i);
+            s_key[i] = MAKE_KEY((lenq - 1) - kq, (lent - 1) - kt2);
         }
         for (int e = lane; e < cnt / 2; e += 64) { const uint16_t c0 = s_chain[e], c1 = s_chain[cnt - 1 - e]; s_chain[e] = c1; s_chain[cnt - 1 - e] = c0; }
         __syncthreads();
@@ -612,8 +651,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     om.first_win = (int32_t)(first_win + (uint32_t)o.n_win);
     const uint32_t xw = A.word_off[rq], yw = A.word_off[rt];
     // chain anchor e (start-to-end order, 0 <= e < cnt)
-#define CH_Q(e) ((int)(s_key[s_chain[cnt - 1 - (e)]] >> 32))
-#define CH_T(e) ((int)(uint32_t)s_key[s_chain[cnt - 1 - (e)]])
+#define CH_Q(e) KEY_Q(s_chain[cnt - 1 - (e)])
+#define CH_T(e) KEY_T(s_chain[cnt - 1 - (e)])
     {
         const int w0 = xs / FSV_WINDOW;
         for (int j = lane; j < o.n_win; j += 64) {
@@ -664,7 +703,13 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
 #undef CH_T
     PUT_BOTH();
 #undef PUT_BOTH
+#undef KEY_Q
+#undef KEY_T
+#undef MAKE_KEY
 }
+
+// LDS bytes of a k_chain block
+__host__ __device__ inline size_t chain_lds_bytes(bool short_reads, int amax) { return short_reads ? (size_t)amax * 12 + 128 : (size_t)amax * 24; }
 
 // ------------------------------------------------------------------------------------------------ k_rescue_accept
 // One lane per overlap slot: right-extension rescue of unmatched windows (Correct.cpp:2655-2744),
@@ -735,9 +780,11 @@ __device__ __forceinline__ uint32_t task_ybase(const uint32_t *__restrict__ stor
 __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ store, const fsv_ovl *__restrict__ ovl,
                                                    const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res, uint32_t n_tasks,
                                                    fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list, uint32_t *__restrict__ dp_count,
-                                                   uint32_t *__restrict__ dp_count_wide, bool write_clean_ops)
+                                                   uint32_t *__restrict__ dp_wide, uint32_t *__restrict__ dp_count_wide, bool write_clean_ops,
+                                                   const uint32_t *__restrict__ n_dev)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n_tasks = *n_dev;   // the grid covers the task bound; the count stays on the device (no host round trip)
     if (tid >= n_tasks) return;
     const fsv_wtask t = tasks[tid];
     const fsv_wres r = res[tid];
@@ -773,11 +820,11 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
         ok = (mm == r.err);
     }
     if (!ok) {
-        // queued for the DP kernel: narrow bands (k <= 15: the three column words fit 32 bits each) fill the list from the
-        // front, wide ones from the back, so that each launch of k_path_dp is homogeneous
+        // queued for the DP kernels: narrow bands (k <= 15: the recurrence fits 32-bit words) and wide ones (the doubled
+        // thresholds of the rescue pass) in lists of their own, so that each launch is homogeneous
         P->state = 2;
         if (t.k <= 15) dp_list[atomicAdd(dp_count, 1u)] = tid;
-        else dp_list[n_tasks - 1u - atomicAdd(dp_count_wide, 1u)] = tid;
+        else dp_wide[atomicAdd(dp_count_wide, 1u)] = tid;
         return;
     }
     // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops (3) and
@@ -827,9 +874,11 @@ __device__ __forceinline__ int path_prefix_match(const uint32_t *__restrict__ st
 
 __global__ __launch_bounds__(256) void k_path_indel1(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
                                                      const fsv_wres *__restrict__ res, const uint32_t *__restrict__ dp_list, uint32_t n_list,
-                                                     fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list2, uint32_t *__restrict__ n_list2)
+                                                     fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list2, uint32_t *__restrict__ n_list2,
+                                                     const uint32_t *__restrict__ n_list_dev, uint32_t *__restrict__ dp_list3, uint32_t *__restrict__ n_list3)
 {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_list_dev) n_list = *n_list_dev;    // the grid covers the largest the list can be; its length stays on the device
     if (idx >= n_list) return;
     const uint32_t tid = dp_list[idx];
     const fsv_wtask t = tasks[tid];
@@ -890,83 +939,17 @@ __global__ __launch_bounds__(256) void k_path_indel1(const uint32_t *__restrict_
             done = true;
         }
     }
-    if (!done) dp_list2[atomicAdd(n_list2, 1u)] = tid;
+    // what is left: distance <= FSV_SB_MAXERR goes to the sub-band kernel, the few beyond it to the general one
+    if (!done) { if (r.err <= FSV_SB_MAXERR) dp_list2[atomicAdd(n_list2, 1u)] = tid; else dp_list3[atomicAdd(n_list3, 1u)] = tid; }
 }
 
-// Full K6: forward pass keeping {D0, VP, VN} of every column in a per-lane slice of an HBM scratch ([block][column][word][lane]:
-// a wave streams through its own contiguous 290 KB, 256-byte stores), the reference's walk back, generate_cigar's end trimming and greedy gap left-shift; the
-// path under construction lives in LDS (2 bits per op) and is packed start-to-end at the end.
-// (Measured and kept out, round 1: checkpointing the DP state every 16 columns and recomputing blocks during the walk back
-//  cut the scratch traffic 8x but ran 1.4x slower; staging 9 columns per lane in LDS ahead of the walk ran 1.2x slower.
-//  SQ counters show why: with 4-5 waves per SIMD the issue slots are full -- the kernel is instruction-bound, not
-//  latency- or HBM-bound, so only fewer instructions help.)
-// WordT = uint32_t for bands of at most 31 diagonals (k <= 15): the walk back only looks at bits below the band width, so the
-// low halves of D0 / VP / VN are all it needs and the scratch traffic halves; uint64_t for the doubled thresholds (k <= 31).
-template <class WordT> struct PathSink {
-    WordT *cols; uint32_t stride, lane;
-    __device__ __forceinline__ void operator()(int i, uint64_t d0, uint64_t vp, uint64_t vn) const
-    {
-        WordT *c = cols + (size_t)(i + 1) * 3 * stride + lane;
-        c[0] = (WordT)d0; c[stride] = (WordT)vp; c[2 * (size_t)stride] = (WordT)vn;
-    }
-};
-
-template <class WordT>
-__global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
-                                                const uint32_t *__restrict__ dp_list, uint32_t list_begin, uint32_t list_end,
-                                                fsv_wpath *__restrict__ paths, WordT *__restrict__ cols, uint32_t stride)
-{
-    __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
-    const int lane64 = threadIdx.x;
-    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;   // this lane's slice of the scratch, reused for every task it takes
-    // persistent blocks: the grid is sized to what the device holds at once and every block strides through the list, so the
-    // scratch is a few hundred MB whatever the number of windows, and the whole list is one launch
-    for (uint32_t li = list_begin + slot; li < list_end; li += gridDim.x * 64) {
-    const uint32_t tid = dp_list[li];
-    const fsv_wtask t = tasks[tid];
-    fsv_wpath *P = paths + tid;
-    const int n = t.x_len, k = t.k, band = 2 * k + 1;
-    fsv_wres r;
-    PathSink<WordT> sink{cols + (size_t)blockIdx.x * (FSV_WINDOW + 2) * 3 * 64, 64u, (uint32_t)lane64};
-    bpm_run(store, t, r, sink);
-    if (r.err < 0) { P->state = 0; continue; } // cannot happen: K5 matched this window
-#define COL(c, w) (sink.cols[((c) * 3 + (w)) * 64 + lane64])
+// The end of K6, shared by the two DP kernels: the all-match rest of the walk, generate_cigar's end trimming and greedy gap
+// left-shift (Correct.cpp:1302-1536) on the path in LDS (2 bits per op, end-to-start), and the record.
 #define TMP(i) ((s_ops[(i) >> 4][lane64] >> (((i) & 15) << 1)) & 3u)
 #define TMP_SET(i, v) do { const int w_ = (i) >> 4, sh_ = ((i) & 15) << 1; s_ops[w_][lane64] = (s_ops[w_][lane64] & ~(3u << sh_)) | ((uint32_t)(v) << sh_); } while (0)
-    for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
-    int end = r.end_site, err = r.err;
-    int cur = err, col = n, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
-    // The walk needs columns col and col-1 at every step and moves to col-1 or stays: a step-by-step walk is a chain of
-    // ~n dependent scratch reads.  Instead each lane keeps TC+1 columns around its position in LDS; when any lane of the wave
-    // runs out, every walking lane re-centres its tile -- 3(TC+1) independent loads in flight, one memory latency per ~TC steps.
-    {
-    // the kernel is instruction-bound (4-5 waves per SIMD keep the issue slots full), so the walk is written for few
-    // instructions: WordT-wide bit tests (only band bits are read), the column it leaves behind handed to the next step
-    // instead of re-read, and the ops gathered in a register that goes to LDS once per 16 steps
-    WordT vp = COL(col, 1), vn = COL(col, 2);
-    uint32_t acc = 0;
-    while (col > 0 && cur != 0) {
-        const WordT d0 = COL(col, 0);
-        const WordT vpi = col > 1 ? COL(col - 1, 1) : (WordT)0, vni = col > 1 ? COL(col - 1, 2) : (WordT)0;
-        const WordT hn = vpi & d0, hp = vni | ~(vpi | d0);
-        const int diag = cur - (int)((~(d0 >> row)) & 1u);
-        const bool can_up = row != 0, can_left = row == 0 || row != band - 1;
-        int left = cur, up = cur;
-        if (can_left) left = cur - (int)((hp >> row) & 1u) + (int)((hn >> row) & 1u);
-        if (can_up) up = cur - (int)((vp >> (row - 1)) & 1u) + (int)((vn >> (row - 1)) & 1u);
-        int best = diag; dir = 0;
-        if (can_up && up < best) { best = up; dir = 2; }
-        if (can_left && left < best) { best = left; dir = 3; }
-        if (dir == 0) { if (diag != cur) dir = 1; col--; start--; vp = vpi; vn = vni; }
-        else if (dir == 2) { row--; start--; }
-        else { col--; row++; vp = vpi; vn = vni; }
-        acc |= (uint32_t)dir << ((plen & 15) << 1);
-        if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
-        plen++;
-        cur = best;
-    }
-    if (plen & 15) s_ops[plen >> 4][lane64] = acc;
-    }
+__device__ __forceinline__ void path_finish(const uint32_t *__restrict__ store, const fsv_wtask &t, fsv_wpath *__restrict__ P, uint32_t (*s_ops)[64],
+                                            int lane64, int col, int dir, int plen, int start, int end, int err)
+{
     if (col > 0) { start -= col; plen += col; dir = 0; } // the rest of the path is matches: the fields are already 0
     if (dir != 3) start++;
     // generate_cigar: TMP is stored end-to-start
@@ -1014,10 +997,166 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
     P->ry_start = t.y_start - t.k + start;
     P->ry_end = t.y_start - t.k + end;
     P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
-    } // next task of this lane
-#undef COL
+}
 #undef TMP
 #undef TMP_SET
+
+// General K6 (any band up to 63 rows, any distance): forward pass keeping {D0, VP, VN} of every column in a per-lane slice of
+// an HBM scratch ([block][column][word][lane]), the reference's walk back on those words, then path_finish.  Since round 2
+// this is the fallback: first-pass windows (k <= 15) at distance <= FSV_SB_MAXERR go through k_path_sb below, which keeps
+// 4 bytes per column instead of 12 and walks without a dependent global load per step; what is left for this kernel are
+// the doubled-threshold rescue windows (k > 15) and distances above 7 -- a fraction of a percent of the HiFi windows.
+// WordT = uint32_t for bands of at most 31 diagonals (k <= 15): the walk back only looks at bits below the band width, so the
+// low halves of D0 / VP / VN are all it needs and the scratch traffic halves; uint64_t for the doubled thresholds (k <= 31).
+template <class WordT> struct PathSink {
+    WordT *cols; uint32_t stride, lane;
+    __device__ __forceinline__ void operator()(int i, uint64_t d0, uint64_t vp, uint64_t vn) const
+    {
+        WordT *c = cols + (size_t)(i + 1) * 3 * stride + lane;
+        c[0] = (WordT)d0; c[stride] = (WordT)vp; c[2 * (size_t)stride] = (WordT)vn;
+    }
+};
+
+template <class WordT>
+__global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
+                                                const uint32_t *__restrict__ dp_list, uint32_t list_begin, uint32_t list_end,
+                                                fsv_wpath *__restrict__ paths, WordT *__restrict__ cols, uint32_t stride,
+                                                const uint32_t *__restrict__ n_dev)
+{
+    __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
+    const int lane64 = threadIdx.x;
+    if (n_dev) list_end = list_begin + *n_dev;   // the list's length as the kernel before left it: no host round trip
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;   // this lane's slice of the scratch, reused for every task it takes
+    // persistent blocks: the grid is sized to what the device holds at once and every block strides through the list, so the
+    // scratch is a few hundred MB whatever the number of windows, and the whole list is one launch
+    for (uint32_t li = list_begin + slot; li < list_end; li += gridDim.x * 64) {
+    const uint32_t tid = dp_list[li];
+    const fsv_wtask t = tasks[tid];
+    fsv_wpath *P = paths + tid;
+    const int n = t.x_len, k = t.k, band = 2 * k + 1;
+    fsv_wres r;
+    PathSink<WordT> sink{cols + (size_t)blockIdx.x * (FSV_WINDOW + 2) * 3 * 64, 64u, (uint32_t)lane64};
+    bpm_run(store, t, r, sink);
+    if (r.err < 0) { P->state = 0; continue; } // cannot happen: K5 matched this window
+#define COL(c, w) (sink.cols[((c) * 3 + (w)) * 64 + lane64])
+    for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
+    int end = r.end_site, err = r.err;
+    int cur = err, col = n, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
+    // The walk needs columns col and col-1 at every step and moves to col-1 or stays: a step-by-step walk is a chain of
+    // ~n dependent scratch reads.  Instead each lane keeps TC+1 columns around its position in LDS; when any lane of the wave
+    // runs out, every walking lane re-centres its tile -- 3(TC+1) independent loads in flight, one memory latency per ~TC steps.
+    {
+    // the kernel is instruction-bound (4-5 waves per SIMD keep the issue slots full), so the walk is written for few
+    // instructions: WordT-wide bit tests (only band bits are read), the column it leaves behind handed to the next step
+    // instead of re-read, and the ops gathered in a register that goes to LDS once per 16 steps
+    WordT vp = COL(col, 1), vn = COL(col, 2);
+    uint32_t acc = 0;
+    while (col > 0 && cur != 0) {
+        const WordT d0 = COL(col, 0);
+        const WordT vpi = col > 1 ? COL(col - 1, 1) : (WordT)0, vni = col > 1 ? COL(col - 1, 2) : (WordT)0;
+        const WordT hn = vpi & d0, hp = vni | ~(vpi | d0);
+        const int diag = cur - (int)((~(d0 >> row)) & 1u);
+        const bool can_up = row != 0, can_left = row == 0 || row != band - 1;
+        int left = cur, up = cur;
+        if (can_left) left = cur - (int)((hp >> row) & 1u) + (int)((hn >> row) & 1u);
+        if (can_up) up = cur - (int)((vp >> (row - 1)) & 1u) + (int)((vn >> (row - 1)) & 1u);
+        int best = diag; dir = 0;
+        if (can_up && up < best) { best = up; dir = 2; }
+        if (can_left && left < best) { best = left; dir = 3; }
+        if (dir == 0) { if (diag != cur) dir = 1; col--; start--; vp = vpi; vn = vni; }
+        else if (dir == 2) { row--; start--; }
+        else { col--; row++; vp = vpi; vn = vni; }
+        acc |= (uint32_t)dir << ((plen & 15) << 1);
+        if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
+        plen++;
+        cur = best;
+    }
+    if (plen & 15) s_ops[plen >> 4][lane64] = acc;
+    }
+    path_finish(store, t, P, s_ops, lane64, col, dir, plen, start, end, err);
+    } // next task of this lane
+#undef COL
+}
+
+// ---- K6 for first-pass windows: k <= 15, distance <= FSV_SB_MAXERR ---------------------------------------------------------
+// What the walk back (Levenshtein_distance.h:757-888) asks of a DP cell is which way it leaves it -- 0 diagonal over a match,
+// 1 diagonal over a mismatch, 2 up, 3 left; ties: diagonal, then up, then left -- and that is known while the column is
+// computed: a cell whose D0 bit is clear is a mismatch (the diagonal is one cheaper than the cell, nothing beats it);
+// otherwise "up" is cheaper exactly when the column's new VP has the bit of the row below set, and "left" when HP has the
+// cell's bit (the top band row has no left neighbour).  And the walk never strays further than `err` rows from the end row:
+// every up / left step spends one of the err errors it has left.  K5 already gave (end site, err) for the window, so the
+// forward pass keeps two bits for each of the 2 x 7 + 1 rows around the end row: ONE 32-bit word per column (bits 0-15 the
+// low code bit of rows row0-7 .. row0+8, bits 16-31 the high one) instead of three band-wide words.  Columns go to the scratch
+// four at a time ([block][column quad][lane] as uint4: 1 KB per wave store); the walk reads them back a quad ahead of where it
+// stands, so no step waits on memory -- round 1's walk was a chain of ~375 dependent loads per window (62 % of its wave cycles
+// parked in s_waitcnt, profiles/r01_i_pmc_sq_summary.txt).  Scratch traffic: 1.5 KB per window, written once, read once.
+struct SubbandSink {
+    uint4 *slot;             // this lane's uint4 of quad 0; quad q sits 64 x q further
+    uint32_t sr, sl, lmask;  // band word -> sub-band: (w >> sr) << sl; rows that may step left
+    uint32_t a0, a1, a2, a3;
+    __device__ __forceinline__ void operator()(int blk, int j, uint32_t d0, uint32_t hp, uint32_t vp, uint32_t)
+    {
+        const uint32_t u = vp << 1, l = hp & lmask;
+        const uint32_t w1 = d0 & (u | l), w0 = ~d0 | (l & ~u);
+        const uint32_t word = (((w0 >> sr) << sl) & 0xffffu) | (((w1 >> sr) << sl) << 16);
+        if ((j & 3) == 0) a0 = word; else if ((j & 3) == 1) a1 = word; else if ((j & 3) == 2) a2 = word; else a3 = word;
+        if ((j & 3) == 3) slot[(size_t)((blk + j) >> 2) * 64] = make_uint4(a0, a1, a2, a3);
+    }
+    __device__ __forceinline__ void flush(int n) { if (n & 3) slot[(size_t)(n >> 2) * 64] = make_uint4(a0, a1, a2, a3); }
+};
+
+__device__ __forceinline__ uint32_t quad_elem(const uint4 &q, int e) { return e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w; }
+
+__global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res,
+                                                const uint32_t *__restrict__ dp_list, const uint32_t *__restrict__ n_dev,
+                                                fsv_wpath *__restrict__ paths, uint4 *__restrict__ cols)
+{
+    __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
+    const int lane64 = threadIdx.x;
+    const uint32_t n_list = *n_dev;
+    uint4 *slot = cols + (size_t)blockIdx.x * FSV_SB_QUADS * 64 + lane64;   // persistent blocks: the slice is reused for every task
+    for (uint32_t li = blockIdx.x * 64 + threadIdx.x; li < n_list; li += gridDim.x * 64) {
+        const uint32_t tid = dp_list[li];
+        const fsv_wtask t = tasks[tid];
+        const fsv_wres r0 = res[tid];
+        fsv_wpath *P = paths + tid;
+        const int n = t.x_len, k = t.k, band = 2 * k + 1;
+        const int end = r0.end_site, err = r0.err;
+        const int row0 = band - (n + 2 * k - end), lo = row0 - FSV_SB_MAXERR;
+        SubbandSink sink;
+        sink.slot = slot; sink.sr = (uint32_t)max(lo, 0); sink.sl = (uint32_t)max(-lo, 0);
+        sink.lmask = band == 1 ? 1u : (1u << (band - 1)) - 1u;
+        sink.a0 = sink.a1 = sink.a2 = sink.a3 = 0;
+        fsv_wres r;
+        bpm_run32(store, t, r, sink);
+        if (r.err != err || r.end_site != end) { P->state = 0; continue; }   // cannot happen: the same DP as K5
+        for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
+        int cur = err, ci = n - 1, plen = 0, start = end, rel = FSV_SB_MAXERR, dir = 0;
+        int qi = ci >> 2;
+        uint4 cq = slot[(size_t)qi * 64], nq = make_uint4(0, 0, 0, 0);
+        if (qi > 0) nq = slot[(size_t)(qi - 1) * 64];
+        uint32_t w = quad_elem(cq, ci & 3), acc = 0;
+        while (ci >= 0 && cur != 0) {
+            const uint32_t code = ((w >> rel) & 1u) | (((w >> (16 + rel)) & 1u) << 1);
+            acc |= code << ((plen & 15) << 1);
+            if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
+            plen++;
+            cur -= (int)(code != 0u);
+            start -= (int)(code != 3u);
+            rel += (int)(code == 3u) - (int)(code == 2u);
+            dir = (int)code;
+            if (code != 2u) {          // the column is done; its left neighbour's word is already here
+                ci--;
+                if ((ci & 3) == 3) {   // into the quad below: it was requested when this one was entered
+                    cq = nq; qi--;
+                    if (qi > 0) nq = slot[(size_t)(qi - 1) * 64];
+                }
+                w = quad_elem(cq, ci & 3);
+            }
+        }
+        if (plen & 15) s_ops[plen >> 4][lane64] = acc;
+        path_finish(store, t, P, s_ops, lane64, ci + 1, dir, plen, start, end, err);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_consensus
@@ -1504,9 +1643,11 @@ __global__ void k_inexact_list(const uint4 *__restrict__ upair_tab, const uint8_
 
 __global__ void k_accept_inexact(const uint4 *__restrict__ upair_tab, const uint32_t *__restrict__ list, uint32_t n_list,
                                  const fsv_ovl *__restrict__ ovl, const fsv_ovl *__restrict__ prev, const uint32_t *__restrict__ read_set,
-                                 const uint32_t *__restrict__ pair_base, fsv_hit *__restrict__ hits, uint32_t *__restrict__ set_hits)
+                                 const uint32_t *__restrict__ pair_base, fsv_hit *__restrict__ hits, uint32_t *__restrict__ set_hits,
+                                 const uint32_t *__restrict__ n_dev = nullptr)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n_list = *n_dev;
     if (i >= 2 * n_list) return;
     const uint4 pt = upair_tab[list[i >> 1]];
     const uint32_t slot = (i & 1) ? pt.w : pt.z;

@@ -1,5 +1,7 @@
 // bpm_device.h -- device-side banded bit-parallel edit distance shared by K5 (verify), the rescue pass and K6 (path).
-// Recurrence and end-site rule follow hifiasm-0.14 Levenshtein_distance.h:274-461 (64-bit words, as the scalar reference).
+// Recurrence and end-site rule follow hifiasm-0.14 Levenshtein_distance.h:274-461.  bpm_run keeps the reference's 64-bit
+// words (bands up to 63 rows: the doubled thresholds of the rescue pass); bpm_run32 is the same recurrence in 32-bit words
+// for bands of at most 31 rows (k <= 15: every first-pass window), half the instructions on a 32-bit VALU.
 #pragma once
 #include "fsv_internal.h"
 
@@ -209,6 +211,78 @@ __device__ __forceinline__ void bpm_run(const uint32_t *__restrict__ store, cons
             xb = xn; yb = yn;
         }
     }
+    int best;
+    r.end_site = bpm_pick_end(s, err, n, k, best);
+    r.err = best;
+}
+
+// ---- 32-bit form, k <= 15 -----------------------------------------------------------------------------------------------
+// Why 32 bits give the reference's bits: the match masks are zero above the band (bit 2k), so above the band X == VN == 0
+// throughout (VN = (D0 >> 1) & HP needs D0 to rise from 0 to 1 between neighbouring bits, and above the band D0 is the carry
+// run of VP + (X & VP): ones from bit 2k+1 upwards, never a rising edge).  The only out-of-band bit that reaches the band is
+// D0 bit 2k+1, which D0 >> 1 brings into the top row -- and it equals the carry out of bit 2k whatever VP holds up there
+// ((VP + carry) ^ VP at that bit).  With 2k+1 <= 31 that bit exists in a 32-bit word; carries lost beyond bit 31 only
+// feed bits beyond 31.  Checked bit for bit against the 64-bit path and the reference-minted vectors (tests/test_gpu_k5.py).
+struct BpmNoSink32 {
+    __device__ __forceinline__ void operator()(int, int, uint32_t, uint32_t, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void flush(int) {}
+};
+
+// Sink32 sees every column: (first column of the 16-column block, column inside the block -- a compile-time constant after
+// unrolling --, D0, HP of the column, VP / VN after it).
+template <class Sink>
+__device__ __forceinline__ void bpm_run32(const uint32_t *__restrict__ store, const fsv_wtask &t, fsv_wres &r, Sink &sink)
+{
+    if (!bpm_window_geometry(t, r)) return;
+    const int n = t.x_len, k = t.k;
+    const int win0 = t.y_start - k;
+    // y as two bit planes + validity over the 2k+17 rows a 16-column block touches (bit b = row win0 + blk + b): the match
+    // mask of a column with x base c is XNOR(lo, c0) & XNOR(hi, c1) & valid, shifted down by the column's offset in the block
+    uint64_t ylo = 0, yhi = 0, yv = 0;
+    for (int b16 = 0; b16 <= 2 * k; b16 += 16) {
+        const Bases16 y = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + b16);
+        const uint32_t m = (1u << min(16, 2 * k + 1 - b16)) - 1u;
+        ylo |= (uint64_t)(compress_even16(y.bits) & m) << b16;
+        yhi |= (uint64_t)(compress_even16(y.bits >> 1) & m) << b16;
+        yv |= (uint64_t)(y.valid & m) << b16;
+    }
+    uint32_t vp = 0, vn = 0;
+    int err = 0;
+    const uint32_t band = (2u << (2 * k)) - 1u;
+    uint32_t xb = fetch16_x(store, t.x_word, t.x_start);
+    Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1);
+    for (int blk = 0; blk < n; blk += 16) {
+        // next block's operands are requested before this block's 16 columns are computed
+        const uint32_t xn = fetch16_x(store, t.x_word, t.x_start + blk + 16);
+        const Bases16 yn = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1 + blk + 16);
+        ylo |= (uint64_t)compress_even16(yb.bits) << (2 * k + 1);
+        yhi |= (uint64_t)compress_even16(yb.bits >> 1) << (2 * k + 1);
+        yv |= (uint64_t)(yb.valid & 0xffffu) << (2 * k + 1);
+        const int lim = min(16, n - blk);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j < lim) {
+                const uint32_t c0 = (uint32_t)(((int32_t)(xb << (31 - 2 * j))) >> 31), c1 = (uint32_t)(((int32_t)(xb << (30 - 2 * j))) >> 31);
+                const uint32_t eq = ~((uint32_t)(ylo >> j) ^ c0) & ~((uint32_t)(yhi >> j) ^ c1) & (uint32_t)(yv >> j) & band;
+                const uint32_t x = eq | vn;
+                const uint32_t d0 = ((vp + (x & vp)) ^ vp) | x;
+                const uint32_t hn = vp & d0;
+                const uint32_t hp = vn | ~(vp | d0);
+                const uint32_t sh = d0 >> 1;
+                vn = sh & hp;
+                vp = hn | ~(sh | hp);
+                err += (int)(~d0 & 1u);
+                sink(blk, j, d0, hp, vp, vn);
+            }
+        }
+        // Levenshtein_distance.h:367-375 gives up at the first column where err - 2k > k; err never decreases, so looking once
+        // per block ends in the same "no match" (and the end-site scan below could not find a row <= k either)
+        if (err - 2 * k > k) return;
+        ylo >>= 16; yhi >>= 16; yv >>= 16;
+        xb = xn; yb = yn;
+    }
+    sink.flush(n);
+    BpmState s; s.eq0 = s.eq1 = s.eq2 = s.eq3 = 0; s.vp = vp; s.vn = vn;
     int best;
     r.end_site = bpm_pick_end(s, err, n, k, best);
     r.err = best;

@@ -12,15 +12,17 @@
 // (end_site, err).  Operands are read from the 2-bit store: 94 + 102 bytes per
 // full window instead of the 375 + 405 ASCII bytes the CPU code unpacks
 // (recover_UC_Read_sub_region, Process_Read.cpp:608, 23 % of the CPU profile).
-// This is integer-ALU bound: ~45 VALU ops per DP column per lane.
+// This is integer-ALU bound: ~30 VALU ops per DP column per lane in the 32-bit form (bpm_run32: bands up to 31 rows,
+// every first-pass window), ~50 in the 64-bit one.
 #include "bpm_device.h"
 
 namespace {
 
 __global__ __launch_bounds__(256) void k5_bpm_kernel(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
-                                                     uint32_t n_tasks, fsv_wres *__restrict__ res)
+                                                     uint32_t n_tasks, fsv_wres *__restrict__ res, const uint32_t *__restrict__ n_dev)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n_tasks = *n_dev;   // the grid covers the task bound; the count stays on the device
     if (tid >= n_tasks) return;
     const fsv_wtask t = tasks[tid];
     fsv_wres r;
@@ -46,7 +48,11 @@ __global__ __launch_bounds__(256) void k5_bpm_kernel(const uint32_t *__restrict_
         exact = acc == 0u;
         if (exact) { r.end_site = n - 1 + t.k; r.err = 0; }
     }
-    if (!exact) bpm_run(store, t, r, BpmNoSink());
+    if (!exact) {
+        // bands of at most 31 rows (k <= 15: every first-pass window) run the recurrence in 32-bit words
+        if (t.k <= 15) { BpmNoSink32 none; bpm_run32(store, t, r, none); }
+        else bpm_run(store, t, r, BpmNoSink());
+    }
     res[tid] = r;
 }
 
@@ -55,11 +61,18 @@ __global__ __launch_bounds__(256) void k5_bpm_kernel(const uint32_t *__restrict_
 extern "C" int fsv_bpm_windows_dev(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wtask *tasks_dev, uint32_t n_tasks,
                                    fsv_wres *res_dev)
 {
+    return fsv_bpm_windows_dev_n(ctx, store_dev, tasks_dev, n_tasks, nullptr, res_dev);
+}
+
+// n_dev != NULL: n_tasks is only the bound the grid is sized for; the kernel reads the actual count from the device
+int fsv_bpm_windows_dev_n(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wtask *tasks_dev, uint32_t n_tasks, const uint32_t *n_dev,
+                          fsv_wres *res_dev)
+{
     if (!ctx || !store_dev || (!tasks_dev && n_tasks) || (!res_dev && n_tasks)) return FSV_EINVAL;
     if (n_tasks == 0) return FSV_OK;
     FSV_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k5_bpm_kernel, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store_dev, tasks_dev,
-                       n_tasks, res_dev);
+                       n_tasks, res_dev, n_dev);
     FSV_HIP(ctx, hipGetLastError());
     return FSV_OK;
 }
