@@ -62,6 +62,27 @@ def cpu_baseline(n_regions, first_index):
     return out
 
 
+def source_sha():
+    """digest of the HIP sources + the C ABI header: profiles/*_pmc_*.json carry the digest of the code they were measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for d, ext in (("focalsv_amd/csrc", (".hip", ".h")), ("include", (".h",))):
+        files += [os.path.join(ROOT, d, f) for f in sorted(os.listdir(os.path.join(ROOT, d))) if f.endswith(ext)]
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest_profile(suffix):
+    """newest profiles/*<suffix> (names sort by round and letter) -> (file name, parsed JSON) or (None, None)"""
+    try:
+        fs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))
+        return (fs[-1], json.load(open(os.path.join(ROOT, "profiles", fs[-1])))) if fs else (None, None)
+    except Exception:
+        return None, None
+
+
 def sum_stats(dicts):
     """field-wise sum of the lanes' statistics dictionaries (nested kernel tables included)"""
     out = {}
@@ -79,10 +100,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--holdout", type=int, default=256, help="regions of a disjoint seed range (indices 5000...) scored against planted truth, untimed (0 = skip)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=256, help="regions per GPU (BASELINE.json configs[1]: 256)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "0")),
-                    help="concurrent lanes per GPU (contexts / streams / host threads); 0 = 3..7, whichever wastes least of the last round of --steps")
+                    help="concurrent lanes per GPU (contexts / streams / host threads); 0 = 3")
     ap.add_argument("--lane-mode", choices=["split", "steps"], default=os.environ.get("FSV_BENCH_LANE_MODE", "steps"),
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
     ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
@@ -124,11 +146,12 @@ def main():
     if args.lanes <= 0:
         # K steps over L lanes take ceil(K / L) rounds: pick the lane count whose last round is fullest, weighted by what that many
         # lanes sustain (measured regions/s at a multiple of L steps: 3: 1980, 4: 2110, 5: 2150, 6: 2165, 7: 2190)
-        rate = {3: 1980, 4: 2110, 5: 2150, 6: 2165, 7: 2190}
-        args.lanes = max(rate, key=lambda l: (args.steps / (-(-args.steps // l) * l)) * rate[l]) if args.lane_mode == "steps" else 2
+        args.lanes = 3 if args.lane_mode == "steps" else 2
     lanes = max(1, min(args.lanes, n))
     ctxs = [_lib.Context(local) for _ in range(lanes)]
-    by_steps = args.lane_mode == "steps" and lanes > 1
+    # "steps": every lane takes whole steps and only runs their GPU half; the host half (Python SV logic) of a batch runs on its own
+    # thread.  This also holds for a single lane (one stream, one batch on the GPU at a time).
+    by_steps = args.lane_mode == "steps"
     # reads resident in HBM before timing starts ("steps": one copy of the whole batch, read by every lane)
     batches = [pipeline.upload_regions(ctxs[0], inputs)] if by_steps else [pipeline.upload_regions(c, inputs[k::lanes]) for k, c in enumerate(ctxs)]
 
@@ -214,58 +237,92 @@ def main():
         a = avg([x[0] for x in stats_acc])
         l = avg([x[1] for x in stats_acc]) if stats_acc[-1][1] else {}
         kern = a.get("kernels", {})
-        # the dominant kernel is picked from one lane running alone (untimed, after the timed region): with several lanes the
-        # kernels of different lanes share the GPU and their durations in the timed region stretch unevenly
-        solo_kern = {}
-        if lanes > 1 and kern:
-            solo_kern = [pipeline.run_hot_path(ctxs[0], batches[0]) for _ in range(2)][-1].asm_stats.get("kernels", {})
+        # one lane alone, untimed, after the timed region: the kernels' own durations (in the timed region the lanes' kernels share
+        # the GPU and stretch unevenly).  The dominant kernel is picked from this pass.
+        solo_kern = [pipeline.run_hot_path(ctxs[0], batches[0]) for _ in range(2)][-1].asm_stats.get("kernels", {}) if kern else {}
+        PEAK_HBM = 8000.0          # GB/s, MI355X_MICROARCH.md
+        PEAK_LANE_OPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: one 32-bit VALU op per lane and cycle
+        sha = source_sha()
+        pmc_name, pmc = newest_profile("_pmc_hbm_traffic.json")
+        sq_name, sq = newest_profile("_pmc_sq.json")
+        alias = {"k_sketch": ["k_sketch_fast", "k_sketch"], "k5_bpm": ["k5_bpm_kernel"], "k_path_dp": ["k_path_sb", "k_path_dp", "k_path_indel1"],
+                 "k_uniq": ["k_uniq"], "k_chain": ["k_chain"]}
+
+        def prof_rows(table, name):
+            """profile rows of the kernels a library statistic covers (template instances together)"""
+            if not table:
+                return []
+            names = alias.get(name, [name])
+            return [v for k2, v in table.get("kernels", {}).items() if any(k2 == n or k2.startswith(n + "<") for n in names)]
+
+        def kernel_line(name):
+            k, so = kern.get(name), solo_kern.get(name)
+            if not k or not k["launches"]:
+                return None
+            nl = max(1, k["launches"])
+            bytes_pl = k["algo_bytes"] / nl
+            d = {"launches_per_step": round(k["launches"], 2), "ms_per_step": round(k["ms"], 3), "avg_launch_ms": round(k["ms"] / nl, 4),
+                 "algo_bytes_per_launch": int(bytes_pl), "GBps": round(bytes_pl / (k["ms"] / nl * 1e-3) / 1e9, 2) if k["ms"] > 0 else None}
+            if so and so["ms"] > 0 and so["launches"]:
+                sl = so["ms"] / so["launches"]
+                d["solo_avg_launch_ms"] = round(sl, 4)
+                d["solo_GBps"] = round(so["algo_bytes"] / so["launches"] / (sl * 1e-3) / 1e9, 2)
+                d["solo_frac_hbm"] = round(d["solo_GBps"] / PEAK_HBM, 5)
+                rows = prof_rows(sq, name)
+                if rows and sq.get("source_sha") == sha:
+                    valu = sum(r["SQ_INSTS_VALU"] for r in rows) / max(1, sq.get("steps", 1))      # wave instructions per step
+                    d["valu_lane_ops_per_s"] = round(valu * 64 / (so["ms"] * 1e-3), 1)
+                    d["valu_frac_of_peak"] = round(valu * 64 / (so["ms"] * 1e-3) / PEAK_LANE_OPS, 4)
+                    wc = sum(r["SQ_WAVE_CYCLES"] for r in rows)
+                    if wc:
+                        d["sq_wait_any"] = round(sum(r["SQ_WAIT_ANY"] for r in rows) / wc, 3)
+                        d["sq_wait_inst_any"] = round(sum(r["SQ_WAIT_INST_ANY"] for r in rows) / wc, 3)
+                        d["sq_active_inst_any"] = round(sum(r["SQ_ACTIVE_INST_ANY"] for r in rows) / wc, 3)
+            rows = prof_rows(pmc, name)
+            if rows and pmc.get("source_sha") == sha:
+                d["traffic_per_launch"] = int(sum(r["fetch_bytes_x2"] + r["write_bytes"] for r in rows) / max(1, pmc.get("steps", 1)) / nl)
+            return d
+
+        kernels = {name: kernel_line(name) for name in kern}
+        kernels = {k2: v for k2, v in kernels.items() if v}
         pick = solo_kern or kern
-        dom_name = max(pick.items(), key=lambda kv: kv[1]["ms"])[0] if pick else None
-        dom = (dom_name, kern.get(dom_name)) if dom_name and dom_name in kern else (None, None)
-        peak = 8000.0
+        dom = max(pick.items(), key=lambda kv: kv[1]["ms"])[0] if pick else None
         roof = None
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this
-        # process); FETCH_SIZE carries the gfx950 x2 correction for streaming reads, see profiles/*_pmc_hbm_traffic.json
-        traffic = None
-        try:
-            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json"))
-            pk = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))["kernels"]
-            alias = {"k_sketch": "k_sketch_fast", "k5_bpm": "k5_bpm_kernel"}
-            name = alias.get(dom[0], dom[0]) if dom[0] else None
-            es = [v for k2, v in pk.items() if k2 == name or k2.startswith(name + "<")] if name else []   # template instances together
-            if es:
-                traffic = int(sum(e["fetch_bytes_x2"] + e["write_bytes"] for e in es) / max(1, sum(e["launches"] for e in es)))
-        except Exception:
-            traffic = None
-        if dom[0]:
-            k = dom[1]
-            ach = (k["algo_bytes"] / max(1, k["launches"])) / (k["ms"] / max(1, k["launches"]) * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 6),
-                    "traffic": traffic, "launches_per_step": k["launches"], "avg_launch_ms": round(k["ms"] / max(1, k["launches"]), 4),
-                    "algo_bytes_per_launch": int(k["algo_bytes"] / max(1, k["launches"])),
-                    "note": "algorithmic bytes = what the kernel's formulation must read and write (DESIGN.md section 3 table); this path is integer DP / "
-                            "join work served from LDS and L2, so the HBM fraction is small by construction (SURVEY.md 7)"}
-        if roof and lanes > 1:
-            # with several lanes the kernels of different lanes share the GPU, so a launch's duration in the timed region is not
-            # the kernel's own speed; one lane alone (untimed, after the timed region) gives the undisturbed figure
-            solo = solo_kern.get(dom[0])
-            if solo and solo["ms"] > 0:
-                s_ach = (solo["algo_bytes"] / max(1, solo["launches"])) / (solo["ms"] / max(1, solo["launches"]) * 1e-3) / 1e9
-                roof["exclusive"] = {"achieved": round(s_ach, 3), "frac": round(s_ach / peak, 6), "avg_launch_ms": round(solo["ms"] / max(1, solo["launches"]), 4),
-                                     "algo_bytes_per_launch": int(solo["algo_bytes"] / max(1, solo["launches"])),
-                                     "note": "one lane alone, untimed pass after the timed region"}
-                roof["note"] += f"; achieved/frac above are from the timed region where {lanes} lanes overlap on the GPU"
+        if dom and dom in kernels:
+            kd = kernels[dom]
+            wait, issue = kd.get("sq_wait_any"), kd.get("sq_wait_inst_any")
+            limiter = None if wait is None else ("latency: waves parked in s_waitcnt / barriers" if wait >= max(0.4, issue or 0) else
+                                                 "instruction issue" if (issue or 0) >= 0.35 else "mixed")
+            roof = {"bound": "hbm", "kernel": dom, "achieved": kd["GBps"], "peak": PEAK_HBM, "unit": "GB/s",
+                    "frac": round((kd["GBps"] or 0) / PEAK_HBM, 6), "traffic": kd.get("traffic_per_launch"),
+                    "launches_per_step": kd["launches_per_step"], "avg_launch_ms": kd["avg_launch_ms"], "algo_bytes_per_launch": kd["algo_bytes_per_launch"],
+                    "exclusive": {"avg_launch_ms": kd.get("solo_avg_launch_ms"), "achieved": kd.get("solo_GBps"), "frac": kd.get("solo_frac_hbm"),
+                                  "note": "one lane alone, untimed pass after the timed region"},
+                    "measured_limiter": limiter,
+                    "valu": {"achieved_lane_ops_per_s": kd.get("valu_lane_ops_per_s"), "peak": PEAK_LANE_OPS, "frac": kd.get("valu_frac_of_peak"),
+                             "note": "SQ_INSTS_VALU x 64 / the kernel's solo time / 78.6e12 (SURVEY.md 7: the binding roof of the integer DP kernels)"},
+                    "sources": {"algo_bytes": "per launch, from the task counts the library reports (DESIGN.md section 3: window x 212 B, K6 window x 324 B, k_chain = "
+                                              "unique minimizers x 32 B + overlap slots x 56 B + task records x 32 B): SURVEY.md 8(d) streamed-operand model",
+                                "durations": "HIP events on the lanes' streams over the timed region (achieved) / one lane alone (exclusive)",
+                                "traffic": f"profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 (gfx950), per launch" if kd.get("traffic_per_launch") else
+                                           f"null: profiles/{pmc_name} was measured on other sources (digest {pmc.get('source_sha') if pmc else None} != {sha})",
+                                "sq": f"profiles/{sq_name}" if kd.get("sq_wait_any") is not None else None},
+                    "note": "bound is what the contract asks to price against; this is an integer join / DP path served from LDS and L2, nowhere near the HBM roof by "
+                            "construction (SURVEY.md 7, 8d) -- measured_limiter and valu say what it is bound by"}
         out = {
             "metric": "target regions/sec (50 kb, 30x HiFi)", "value": round(world * n * args.steps / dt, 3), "unit": "regions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{n} synthetic 50 kb regions per GPU, 30x HiFi-like reads U(10k,20k), 0.2% error, seed 1000+i "
                                    "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather; {lanes} concurrent lanes (streams) per GPU, " + ("each taking whole steps (one batch in flight per lane, the host half of a batch on its own thread)" if by_steps else "each half of every step's batch")},
             "sv_vs_truth": {"truth": len(truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok, "tp_within_1bp_of_left_aligned_truth": tp1},
             "stage_ms": {k: round(v, 2) for k, v in a.items() if k.startswith("ms_")},
-            "kernel_ms": {k: [round(v["ms"], 2), int(round(v["launches"]))] for k, v in kern.items()},
+            "kernels": kernels,
             "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},
-            "lanes": lanes, "lane_mode": args.lane_mode if lanes > 1 else "single",
+            "lanes": lanes, "lane_mode": args.lane_mode,
+            # whole-batch passes of the hot path this process ran (warm-up + priming + timed + the two one-lane passes): what a profiler's
+            # per-kernel sums over the process have to be divided by
+            "hot_path_passes": (args.warmup + priming if by_steps else args.warmup) + args.steps + (2 if kern else 0),
             "lane_priming_steps": priming,
             "host_ms": res.host_ms,
             # companion compute figure (SURVEY.md 8d): banded DP column-steps of K5 + K6 (windows x their x_len, 31-row bands)
@@ -291,6 +348,23 @@ def main():
                           "regions_per_s_with_serial_upload": round(world * n / (dt / args.steps + up_ms * 1e-3), 1)}
         except Exception as e:   # a measurement extra: never let it take the bench line down
             out["h2d"] = {"error": str(e)}
+        if args.holdout > 0:
+            # planted truth on a seed range the kernels were never tuned on (region indices 5000...: every 8th carries a tandem-repeat
+            # block), one untimed pass: +-1 bp of the left-aligned truth, exact SVLEN, genotype
+            hold = [synth.make_region(5000 + i, start=(5000 + i) * 60000) for i in range(args.holdout)]
+            hb = pipeline.upload_regions(ctxs[0], [pipeline.region_from_synth(r) for r in hold])
+            try:
+                hr = pipeline.run_hot_path(ctxs[0], hb)
+            finally:
+                hb.free(ctxs[0])
+            htruth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in hold for t in r.truth]
+            htols = [synth.position_tolerance(r, t) for r in hold for t in r.truth]
+            hcalls = pipeline.parse_calls(hr.lines)
+            h1 = pipeline.match_truth(hcalls, htruth, bp_tol=1, len_tol=0.0, left_shift_ok=0)
+            h2 = pipeline.match_truth(hcalls, htruth, bp_tol=1, len_tol=0.0, left_shift_ok=0, tols=htols)
+            out["sv_vs_truth_holdout"] = {"regions": args.holdout, "first_index": 5000, "truth": len(htruth), "tp": h2[0], "fp": h2[1], "fn": h2[2], "gt_ok": h2[3],
+                                          "tp_strictly_within_1bp": h1[0],
+                                          "note": "tp allows a haplotype-2 SNP within 3 bp of a breakpoint to be absorbed into the gap (synth.position_tolerance)"}
         if args.cpu_sample > 0:
             cb = cpu_baseline(args.cpu_sample, 0)
             # SV calls of the GPU path against the CPU path (oracle contigs + oracle alignments + the same host logic) on the sampled

@@ -364,8 +364,8 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         FSV_HIP(ctx, hipGetLastError());
         const uint32_t grid = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 8u * (uint32_t)ctx->n_cu);
         TRY(ensure(ctx, d_cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
-        hipLaunchKernelGGL(k_path_sb, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
-                           (const uint32_t *)d_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)d_paths.p, (uint4 *)d_cols_sb.p);
+        hipLaunchKernelGGL(k_path_sb<false>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+                           (const uint32_t *)d_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)d_paths.p, (uint4 *)d_cols_sb.p, (unsigned long long *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
         const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 2u * (uint32_t)ctx->n_cu);
         TRY(ensure(ctx, d_cols, (size_t)gridg * 64 * (FSV_WINDOW + 2) * 3 * 8));
@@ -534,11 +534,23 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             W.dp_rec.push_back(W.kt.begin(ctx, KN_PATH_DP, 0));
             {
                 int per_cu = 0;
-                FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_sb, 64, 0));
+                FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_sb<false>, 64, 0));
                 const uint32_t grid = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, per_cu) * (uint32_t)ctx->n_cu);
                 TRY(ensure(ctx, W.cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
-                hipLaunchKernelGGL(k_path_sb, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p,
-                                   (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)W.paths.p, (uint4 *)W.cols_sb.p);
+                if (getenv("FSV_K6_STAMPS")) {   // diagnostic: where a k_path_sb wave spends its cycles (never in a measured run)
+                    DevBuf &sb = W.tmp;
+                    TRY(ensure(ctx, sb, 64));
+                    FSV_HIP(ctx, hipMemsetAsync(sb.p, 0, 64, ctx->stream));
+                    hipLaunchKernelGGL(k_path_sb<true>, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p,
+                                       (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)W.paths.p, (uint4 *)W.cols_sb.p, (unsigned long long *)sb.p);
+                    unsigned long long h[4] = {0, 0, 0, 0};
+                    FSV_HIP(ctx, hipMemcpyAsync(h, sb.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+                    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    fprintf(stderr, "[fsv] k_path_sb round %d: %llu waves, cycles per wave: forward %.0f, walk %.0f, finish %.0f (grid %u)\n", round, h[3],
+                            h[3] ? (double)h[0] / h[3] : 0.0, h[3] ? (double)h[1] / h[3] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0, grid);
+                } else
+                hipLaunchKernelGGL(k_path_sb<false>, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p,
+                                   (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)W.paths.p, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
                 FSV_HIP(ctx, hipGetLastError());
                 // the general kernel's lists are short (rescue windows, distances above 7): two blocks per CU are plenty
                 const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 2u * (uint32_t)ctx->n_cu), stride = gridg * 64;

@@ -1107,10 +1107,13 @@ struct SubbandSink {
 
 __device__ __forceinline__ uint32_t quad_elem(const uint4 &q, int e) { return e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w; }
 
+// STAMP: diagnostic build only (FSV_K6_STAMPS=1): shader-clock cycles of the three phases summed per wave into `stamps`
+template <bool STAMP>
 __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res,
                                                 const uint32_t *__restrict__ dp_list, const uint32_t *__restrict__ n_dev,
-                                                fsv_wpath *__restrict__ paths, uint4 *__restrict__ cols)
+                                                fsv_wpath *__restrict__ paths, uint4 *__restrict__ cols, unsigned long long *__restrict__ stamps)
 {
+    unsigned long long t_fwd = 0, t_walk = 0, t_fin = 0, t0 = 0, t1 = 0, t2 = 0;
     __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
     const int lane64 = threadIdx.x;
     const uint32_t n_list = *n_dev;
@@ -1128,7 +1131,9 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
         sink.lmask = band == 1 ? 1u : (1u << (band - 1)) - 1u;
         sink.a0 = sink.a1 = sink.a2 = sink.a3 = 0;
         fsv_wres r;
+        if (STAMP) t0 = __builtin_amdgcn_s_memtime();
         bpm_run32(store, t, r, sink);
+        if (STAMP) t1 = __builtin_amdgcn_s_memtime();
         if (r.err != err || r.end_site != end) { P->state = 0; continue; }   // cannot happen: the same DP as K5
         for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
         int cur = err, ci = n - 1, plen = 0, start = end, rel = FSV_SB_MAXERR, dir = 0;
@@ -1155,8 +1160,11 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
             }
         }
         if (plen & 15) s_ops[plen >> 4][lane64] = acc;
+        if (STAMP) t2 = __builtin_amdgcn_s_memtime();
         path_finish(store, t, P, s_ops, lane64, ci + 1, dir, plen, start, end, err);
+        if (STAMP) { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); t_fwd += t1 - t0; t_walk += t2 - t1; t_fin += t3 - t2; }
     }
+    if (STAMP && lane64 == 0) { atomicAdd(&stamps[0], t_fwd); atomicAdd(&stamps[1], t_walk); atomicAdd(&stamps[2], t_fin); atomicAdd(&stamps[3], 1ull); }
 }
 
 // ------------------------------------------------------------------------------------------------ k_consensus

@@ -632,13 +632,15 @@ def parse_calls(lines: Sequence[str]):
     return out
 
 
-def match_truth(calls, truth, bp_tol: int = 1, len_tol: float = 0.02, left_shift_ok: int = 0):
+def match_truth(calls, truth, bp_tol: int = 1, len_tol: float = 0.02, left_shift_ok: int = 0, tols=None):
     """truth: [(chrom, type, pos0, len, gt)] -> (tp, fp, fn, gt_ok).  A call matches when type agrees, |SVLEN diff| <= len_tol
-    and the position is within bp_tol of the truth position, or up to `left_shift_ok` bases to its left (a left-aligned
-    gap inside a repeat is the same allele)."""
+    and the position is within bp_tol of the truth position (tols[i] for truth i when given), or up to `left_shift_ok` bases to
+    its left (a left-aligned gap inside a repeat is the same allele)."""
     used = [False] * len(calls)
     tp = gt_ok = 0
-    for (chrom, typ, pos, ln, gt) in truth:
+    for ti, (chrom, typ, pos, ln, gt) in enumerate(truth):
+        if tols is not None:
+            bp_tol = tols[ti]
         hit = None
         for i, c in enumerate(calls):
             if used[i] or c["chrom"] != chrom or c["type"] != typ:

@@ -67,14 +67,8 @@ LEFT_SHIFT_REGRESSIONS = (367, 423, 559, 703, 791, 823, 1039, 1175, 1359)
 
 
 def sv_position_tolerance(region, t, hap):
-    """+-1 bp of the left-aligned truth.  Where a haplotype-2 SNP (every 1 kb from 500, synth.make_region) lies within 3 bp
-    of a breakpoint, the best-scoring alignment absorbs the SNP into the gap (one mismatch saved, same haplotype sequence):
-    the call may then sit up to that many bases further left."""
-    if hap != 1:
-        return 1
-    snps = range(500, len(region.ref), 1000)
-    d = min(abs(e - s) for e in (t.pos_left, t.pos_left + (t.length if t.svtype == "DEL" else 0)) for s in snps)
-    return 1 + (d if d <= 3 else 0)
+    """+-1 bp of the left-aligned truth; on haplotype 2 a SNP next to a breakpoint may be absorbed into the gap (synth.position_tolerance)"""
+    return synth.position_tolerance(region, t) if hap == 1 else 1
 
 
 def check_planted(region, hap, aln):

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repository root: the bench line, the rocprofv3 kernel statistics of the same
+# command, and the counter passes (each on its own: --pmc never together with other trace domains), into gpurun_out/prof_<tag>/.
+#   bash tools/profile_round.sh <tag> ; then, anywhere:  python tools/fold_profiles.py gpurun_out/prof_<tag> <tag> 1
+set -e -o pipefail
+tag=${1:-r02_x}
+out=gpurun_out/prof_$tag
+rm -rf $out && mkdir -p $out
+export TMPDIR=/tmp
+python3 bench.py > $out/bench.json 2> $out/bench.err
+echo "bench done"; tail -c 400 $out/bench.json; echo
+python3 bench.py --lanes 1 > $out/bench_1lane.json 2> $out/bench_1lane.err
+echo "1-lane bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --cpu-sample 0 --holdout 0 > $out/stats.log 2>&1
+echo "stats done"
+one="python3 bench.py --lanes 1 --steps 1 --warmup 0 --cpu-sample 0 --holdout 0"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $one > $out/fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- $one > $out/write.log 2>&1
+echo "write done"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $out/sq -- $one > $out/sq.log 2>&1
+echo "sq done"
+# keep what is merged back small: the per-dispatch traces are large, the folded tables are what gets committed
+find $out -name "*kernel_trace.csv" -size +20M -delete || true
+du -sh $out
