@@ -943,6 +943,29 @@ __global__ __launch_bounds__(256) void k_path_indel1(const uint32_t *__restrict_
     if (!done) { if (r.err <= FSV_SB_MAXERR) dp_list2[atomicAdd(n_list2, 1u)] = tid; else dp_list3[atomicAdd(n_list3, 1u)] = tid; }
 }
 
+// base access through one cached 16-base word (forward position >> 4 is the key)
+struct XBaseCache {
+    uint32_t w = 0; int idx = -1;
+    __device__ __forceinline__ uint32_t get(const uint32_t *__restrict__ store, uint32_t word_off, int pos)
+    {
+        const int wi = pos >> 4;
+        if (wi != idx) { w = store[word_off + (uint32_t)wi]; idx = wi; }
+        return (w >> ((pos & 15) << 1)) & 3u;
+    }
+};
+struct YBaseCache {   // task_ybase: window column c of the (strand-oriented) target, 4 outside the read
+    uint32_t w = 0; int idx = -1;
+    __device__ __forceinline__ uint32_t get(const uint32_t *__restrict__ store, const fsv_wtask &t, int c)
+    {
+        const int p = t.y_start - t.k + c;
+        if (p < 0 || p >= t.y_len) return 4u;
+        const int q = t.y_rev ? (t.y_len - 1 - p) : p, wi = q >> 4;
+        if (wi != idx) { w = store[t.y_word + (uint32_t)wi]; idx = wi; }
+        const uint32_t b = (w >> ((q & 15) << 1)) & 3u;
+        return t.y_rev ? 3u - b : b;
+    }
+};
+
 // The end of K6, shared by the two DP kernels: the all-match rest of the walk, generate_cigar's end trimming and greedy gap
 // left-shift (Correct.cpp:1302-1536) on the path in LDS (2 bits per op, end-to-start), and the record.
 #define TMP(i) ((s_ops[(i) >> 4][lane64] >> (((i) & 15) << 1)) & 3u)
@@ -958,6 +981,7 @@ __device__ __forceinline__ void path_finish(const uint32_t *__restrict__ store, 
         for (int i = 0; i < plen && TMP(i) == 1; i++) { TMP_SET(i, 3); end--; stop = i; }
         for (int i = plen - 1; i >= 0 && TMP(i) == 1; i--) { TMP_SET(i, 3); start++; }
         int xi = 0, yi = 0;
+        XBaseCache xc; YBaseCache yc;
         for (int i = plen - 1; i > stop;) {
             // runs of match / mismatch ops are skipped a path word at a time: a gap op is a field with its high bit set
             const int f = i & 15;
@@ -971,7 +995,9 @@ __device__ __forceinline__ void path_finish(const uint32_t *__restrict__ store, 
             if (op == 3) y2--; else x2--;
             for (; pi < plen && x2 >= 0 && y2 >= 0; pi++, x2--, y2--) {
                 const uint32_t pv = TMP(pi);
-                const bool same = fsv_base_fwd(store, t.x_word, t.x_start + x2) == task_ybase(store, t, start + y2);
+                // the shift reads bases at falling positions: one 16-base word per 16 steps instead of two dependent global loads
+                // per step (a gap inside a homopolymer travels a long way, and the whole wave waits for its slowest lane)
+                const bool same = xc.get(store, t.x_word, t.x_start + x2) == yc.get(store, t, start + y2);
                 if (pv >= 2 || (pv == 0 && !same)) break;
                 if (pv == 1 && same) { TMP_SET(pi - 1, 0); err--; }
                 else TMP_SET(pi - 1, pv);
@@ -1137,27 +1163,33 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
         if (r.err != err || r.end_site != end) { P->state = 0; continue; }   // cannot happen: the same DP as K5
         for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
         int cur = err, ci = n - 1, plen = 0, start = end, rel = FSV_SB_MAXERR, dir = 0;
+        uint32_t acc = 0;
+        // The walk, a quad of columns per phase: every lane walks until it leaves its current quad (four column steps plus its
+        // "up" steps), then all lanes move one quad down together.  Three quads rotate through registers and the one just left
+        // is refilled with the quad three below, so a quad is requested two phases before it is walked and no lane ever waits
+        // for a load another lane has just issued (with a per-lane "switch when I cross" every crossing waited out the full
+        // memory latency of the neighbour's request: 1 500 cycles per step, FSV_K6_STAMPS).
         int qi = ci >> 2;
-        uint4 cq = slot[(size_t)qi * 64], nq = make_uint4(0, 0, 0, 0);
-        if (qi > 0) nq = slot[(size_t)(qi - 1) * 64];
-        uint32_t w = quad_elem(cq, ci & 3), acc = 0;
-        while (ci >= 0 && cur != 0) {
-            const uint32_t code = ((w >> rel) & 1u) | (((w >> (16 + rel)) & 1u) << 1);
-            acc |= code << ((plen & 15) << 1);
-            if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
-            plen++;
-            cur -= (int)(code != 0u);
-            start -= (int)(code != 3u);
-            rel += (int)(code == 3u) - (int)(code == 2u);
-            dir = (int)code;
-            if (code != 2u) {          // the column is done; its left neighbour's word is already here
-                ci--;
-                if ((ci & 3) == 3) {   // into the quad below: it was requested when this one was entered
-                    cq = nq; qi--;
-                    if (qi > 0) nq = slot[(size_t)(qi - 1) * 64];
-                }
-                w = quad_elem(cq, ci & 3);
+        auto quad = [&](int q) { return q >= 0 ? slot[(size_t)q * 64] : make_uint4(0, 0, 0, 0); };
+        uint4 qa = quad(qi), qb = quad(qi - 1), qc = quad(qi - 2);
+        auto phase = [&](const uint4 &q4) {
+            while (cur != 0 && ci >= 0 && (ci >> 2) == qi) {
+                const uint32_t w = quad_elem(q4, ci & 3);
+                const uint32_t code = ((w >> rel) & 1u) | (((w >> (16 + rel)) & 1u) << 1);
+                acc |= code << ((plen & 15) << 1);
+                if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
+                plen++;
+                cur -= (int)(code != 0u);
+                start -= (int)(code != 3u);
+                rel += (int)(code == 3u) - (int)(code == 2u);
+                ci -= (int)(code != 2u);      // "up" stays in its column
+                dir = (int)code;
             }
+        };
+        while (__any(cur != 0 && ci >= 0)) {
+            phase(qa); qi--; qa = quad(qi - 2);
+            phase(qb); qi--; qb = quad(qi - 2);
+            phase(qc); qi--; qc = quad(qi - 2);
         }
         if (plen & 15) s_ops[plen >> 4][lane64] = acc;
         if (STAMP) t2 = __builtin_amdgcn_s_memtime();
