@@ -38,6 +38,8 @@ class ReadSets(C.Structure):
 SET_UNPHASED = 1
 # return / status codes of include/focalsv_hip.h
 OK, ENODEV, EINVAL, ENOMEM, EHIP, ECAP, EUNSUP = 0, -1, -2, -3, -4, -5, -6
+# set_status warning bits (FSV_W_*)
+W_MZ_TRUNC, W_ANCHOR_TRUNC, W_NO_LAYOUT, W_INS_EVENTS, W_WINDOW_KEPT, W_INTERNAL = 1, 2, 4, 8, 16, 32
 
 
 class Contigs(C.Structure):

@@ -164,6 +164,43 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
     }
 }
 
+// ------------------------------------------------------------------------------------------------ seed thinning
+// Windows beyond ~760 kb would need a minimizer window above 255 to keep a seed list below ALN_AMAX; instead w stays 255 and
+// every m-th minimizer by hash survives, on the reference window and its contigs alike (oracle/aln.c does the same).  One
+// block per sequence compacts its raw list in place (the order of a raw list is arbitrary: k_uniq sorts).
+__global__ __launch_bounds__(256) void k_thin_seeds(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
+                                                    const uint16_t *__restrict__ thin)
+{
+    __shared__ uint32_t s_n, s_base;
+    const uint32_t r = blockIdx.x, m = thin[r];
+    if (m <= 1) return;
+    fsv_mz *a = mz + mz_off[r];
+    const uint32_t n = min(mz_cnt[r], mz_off[r + 1] - mz_off[r]);
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        fsv_mz v; v.hash = 0; v.pos = 0; v.rev = 0; v.span = 0; v.pad = 0;
+        bool keep = false;
+        if (i < n) { v = a[i]; keep = (v.hash >> 11) % (uint64_t)m == 0; }
+        // rank inside the chunk: wave ballots, the waves' counts added up through LDS
+        const uint64_t bal = __ballot(keep);
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        __shared__ uint32_t s_w[4];
+        if (lane == 0) s_w[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();          // also: every thread has read its a[i] before anyone overwrites a slot at or below it
+        uint32_t off = 0;
+        for (uint32_t k2 = 0; k2 < wv; k2++) off += s_w[k2];
+        if (threadIdx.x == 0) s_base = s_n;
+        __syncthreads();
+        if (keep) a[s_base + off + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = v;     // destination index <= i: only slots already read
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = s_base + s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mz_cnt[r] = s_n;
+}
+
 // ------------------------------------------------------------------------------------------------ events
 // query base of the strand-oriented contig
 __device__ __forceinline__ uint32_t qbase(const uint32_t *__restrict__ store, uint32_t qw, int lenq, int rev, int p) { return fsv_base_at(store, qw, lenq, rev, p); }
@@ -464,9 +501,9 @@ __global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ sto
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 struct AlnWs {
-    DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, ev_packed, ev_count, tasks, bt, rows, cg, cg_n, scores, gaps, gap_shift;
+    DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, ev_packed, ev_count, tasks, bt, rows, cg, cg_n, scores, gaps, gap_shift, thin;
     fsv_aln_stats stats;
-    std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores, &gaps, &gap_shift}; }
+    std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores, &gaps, &gap_shift, &thin}; }
 };
 
 void aln_ws_free(fsv_ctx *ctx)
@@ -712,15 +749,20 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
         group_len[contig_ref[p]] = std::max(group_len[contig_ref[p]], slen[n_refs + p]);
         pair_q[p] = n_refs + p; pair_t[p] = contig_ref[p];
     }
+    // seeds of long windows: w grows with the longest sequence of the group; beyond w = 255 (~760 kb: the whole-genome BED has a
+    // 1.15 Mb region) the minimizers are thinned by hash instead (k_thin_seeds), so any window below 2^23 bases is aligned
+    std::vector<uint16_t> thin(nr, 1);
+    bool any_thin = false;
     for (uint32_t r = 0; r < n_refs; r++) {
         uint64_t w = std::max<uint64_t>((uint64_t)P.w, group_len[r] / 3000 + 1);
-        wper[r] = (uint8_t)std::min<uint64_t>(w, 255);
+        if (w > 255) { thin[r] = (uint16_t)std::min<uint64_t>((w + 254) / 255, 65535); any_thin = true; w = 255; }
+        wper[r] = (uint8_t)w;
     }
     for (uint32_t p = 0; p < np; p++) {
         const uint32_t r = contig_ref[p];
         const uint64_t L = group_len[r];
-        wper[n_refs + p] = wper[r];
-        if (L / 3000 + 1 > 255 || L >= (1u << 24) || (!(P.k & 1) && L / 3000 + 1 > 64)) pre_status[p] = FSV_EUNSUP; // the replay kernel (even k) holds w <= 64
+        wper[n_refs + p] = wper[r]; thin[n_refs + p] = thin[r];
+        if (L >= (1u << 23) || (!(P.k & 1) && L / 3000 + 1 > 64)) pre_status[p] = FSV_EUNSUP; // the replay kernel (even k) holds w <= 64
         else if (slen[n_refs + p] < (uint64_t)P.k || slen[r] < (uint64_t)P.k) pre_status[p] = 1;
     }
     Timer tseed(ctx);
@@ -770,6 +812,12 @@ extern "C" int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint6
                            (uint32_t *)W.mz_cnt.p, nr, P.w, P.k, 0, (uint32_t *)W.warn.p, (const uint8_t *)W.wper.p, w_max, lds_words);
     }
     FSV_HIP(ctx, hipGetLastError());
+    if (any_thin) {
+        TRY(upload(ctx, W.thin, thin));
+        hipLaunchKernelGGL(k_thin_seeds, dim3(nr), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (uint32_t *)W.mz_cnt.p,
+                           (const uint16_t *)W.thin.p);
+        FSV_HIP(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(k_uniq<ALN_AMAX>, dim3(nr), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p, (uint32_t *)W.mz_cnt.p,
                        (uint32_t *)W.warn.p);
     FSV_HIP(ctx, hipGetLastError());

@@ -53,7 +53,7 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
        CT_MZ_LO = 10, CT_MZ_HI = 11, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, set_cols, trans, read_flag, changed,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, set_cols, trans, read_flag, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -67,7 +67,7 @@ struct AsmWs {
     void *h_pin = nullptr; size_t h_pin_cap = 0; // pinned host staging (exact hits)
     std::vector<DevBuf *> all()
     {
-        return {&store[0], &store[1], &cols_sb, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
+        return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
                 &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &set_cols, &trans, &read_flag, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
@@ -392,15 +392,9 @@ extern "C" int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out)
     return FSV_OK;
 }
 
-extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params *params, fsv_contigs *out)
+// one chunk of read sets through the whole assembly (what fsv_assemble_batch was before it learnt to split a batch)
+static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params &P, fsv_contigs *out)
 {
-    if (!ctx || !sets || !out || !sets->store_dev || !sets->word_off || !sets->read_len || !sets->set_start) return FSV_EINVAL;
-    if (!out->seq || !out->off || !out->set || !out->n_reads || !out->set_status) return FSV_EINVAL;
-    fsv_asm_params P;
-    if (params) P = *params; else fsv_asm_default_params(&P);
-    if (P.k < 1 || P.k > 63 || P.w < 1 || P.w > 64 || P.lookback != 64 || P.n_rounds < 0 || P.n_rounds > 16 || P.min_anchors < 1)
-        return fsv_fail(ctx, FSV_EINVAL, "fsv_asm_params out of range (k<=63, w<=64, lookback==64)");
-    FSV_HIP(ctx, hipSetDevice(ctx->device));
     AsmWs &W = *ws_get(ctx);
     memset(&W.stats, 0, sizeof(W.stats));
     W.kt.reset();
@@ -824,6 +818,104 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         W.stats.kernels[r.k].launches++;
         W.stats.kernels[r.k].algo_bytes += r.bytes;
     }
+    return FSV_OK;
+}
+
+// Work a set brings: its window-task bound (every read's windows against every other read) and its ordered pairs.
+static void set_cost(const fsv_readsets *sets, uint32_t s, uint64_t &tasks, uint64_t &pairs, uint64_t &bases)
+{
+    const uint64_t ns = sets->set_start[s + 1] - sets->set_start[s];
+    uint64_t nw = 0; bases = 0;
+    for (uint32_t r = sets->set_start[s]; r < sets->set_start[s + 1]; r++) { nw += ((uint64_t)sets->read_len[r] + FSV_WINDOW - 1) / FSV_WINDOW; bases += (uint64_t)sets->read_len[r]; }
+    tasks = ns > 1 ? nw * (ns - 1) : 0;
+    pairs = ns > 1 ? ns * (ns - 1) : 0;
+}
+
+extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params *params, fsv_contigs *out)
+{
+    if (!ctx || !sets || !out || !sets->store_dev || !sets->word_off || !sets->read_len || !sets->set_start) return FSV_EINVAL;
+    if (!out->seq || !out->off || !out->set || !out->n_reads || !out->set_status) return FSV_EINVAL;
+    fsv_asm_params P;
+    if (params) P = *params; else fsv_asm_default_params(&P);
+    if (P.k < 1 || P.k > 63 || P.w < 1 || P.w > 64 || P.lookback != 64 || P.n_rounds < 0 || P.n_rounds > 16 || P.min_anchors < 1)
+        return fsv_fail(ctx, FSV_EINVAL, "fsv_asm_params out of range (k<=63, w<=64, lookback==64)");
+    FSV_HIP(ctx, hipSetDevice(ctx->device));
+    AsmWs &W = *ws_get(ctx);
+    out->n_contigs = 0; out->off[0] = 0;
+    if (sets->n_reads == 0 || sets->n_sets == 0) { for (uint32_t s = 0; s < sets->n_sets; s++) out->set_status[s] = 0; memset(&W.stats, 0, sizeof(W.stats)); return FSV_OK; }
+    if (sets->set_start[0] != 0 || sets->set_start[sets->n_sets] != sets->n_reads) return fsv_fail(ctx, FSV_EINVAL, "set_start must span [0, n_reads]");
+    for (uint32_t s = 0; s < sets->n_sets; s++) if (sets->set_start[s + 1] < sets->set_start[s]) return fsv_fail(ctx, FSV_EINVAL, "set_start not monotone");
+    // Read sets are independent, so a batch that is too large for one pass -- 32-bit pair / task / offset indices, or a workspace
+    // beyond the budget (FSV_ASM_BUDGET_GB, default 40 % of the device's memory: ~200 B per window task, ~200 B per read pair,
+    // ~48 B per base) -- is cut into runs of consecutive sets that go through one after the other; the caller sees one call.
+    // (Round 1 returned FSV_EUNSUP and left the splitting to the caller.)
+    const char *env = getenv("FSV_ASM_BUDGET_GB");
+    const double budget = (env && atof(env) > 0 ? atof(env) : 0.4 * (double)ctx->hbm_bytes / 1e9) * 1e9;
+    std::vector<uint32_t> cut{0};
+    {
+        uint64_t tk = 0, pr = 0, bs = 0;
+        for (uint32_t s = 0; s < sets->n_sets; s++) {
+            uint64_t t1, p1, b1;
+            set_cost(sets, s, t1, p1, b1);
+            if (t1 >= (1ull << 31) || p1 >= (1ull << 31) || b1 + b1 / 4 >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "a single read set exceeds the 2^31 window-task / pair bound");
+            const bool over = tk + t1 >= (1ull << 31) || pr + p1 >= (1ull << 31) || (bs + b1) + (bs + b1) / 4 >= (1ull << 32) ||     /* minimizer slots: one per base + slack, 32-bit offsets */
+                              (double)(tk + t1) * 200.0 + (double)(pr + p1) * 200.0 + (double)(bs + b1) * 48.0 > budget;
+            if (over && s > cut.back()) { cut.push_back(s); tk = pr = bs = 0; }
+            tk += t1; pr += p1; bs += b1;
+        }
+        cut.push_back(sets->n_sets);
+    }
+    if (cut.size() == 2) return assemble_chunk(ctx, sets, P, out);
+    fsv_asm_stats total; memset(&total, 0, sizeof(total));
+    uint64_t used = 0; uint32_t nc = 0;
+    std::vector<uint64_t> all_off{0};
+    for (size_t c = 0; c + 1 < cut.size(); c++) {
+        const uint32_t s0 = cut[c], s1 = cut[c + 1], r0 = sets->set_start[s0], r1 = sets->set_start[s1];
+        std::vector<uint32_t> sub_start(s1 - s0 + 1);
+        for (uint32_t s = s0; s <= s1; s++) sub_start[s - s0] = sets->set_start[s] - r0;
+        fsv_readsets sub = *sets;
+        sub.word_off = sets->word_off + r0; sub.read_len = sets->read_len + r0; sub.set_start = sub_start.data();
+        sub.n_reads = r1 - r0; sub.n_sets = s1 - s0; sub.set_flags = sets->set_flags ? sets->set_flags + s0 : nullptr;
+        fsv_contigs part = *out;
+        part.seq = out->seq + used; part.seq_cap = out->seq_cap - used; part.off = out->off + nc; part.set = out->set + nc; part.n_reads = out->n_reads + nc;
+        part.contig_cap = out->contig_cap - nc; part.set_status = out->set_status + s0; part.n_contigs = 0;
+        const uint64_t keep = out->off[nc];          // part.off[0] is this slot: the chunk writes 0 there
+        TRY(assemble_chunk(ctx, &sub, P, &part));
+        out->off[nc] = keep;
+        for (uint32_t i = 0; i < part.n_contigs; i++) { out->set[nc + i] += s0; out->off[nc + i + 1] += used; }
+        // the contigs stay on the device for the aligner (fsv_align_batch(contig_seq = NULL)): gather the chunks' contigs in one buffer
+        const uint64_t bytes = part.n_contigs ? out->off[nc + part.n_contigs] - used : 0;
+        if (bytes) {
+            if (W.contig_all.cap < used + bytes + 16) {
+                DevBuf bigger;
+                TRY(ensure(ctx, bigger, std::max<uint64_t>((used + bytes) * 2, 1u << 20)));
+                if (used) FSV_HIP(ctx, hipMemcpyAsync(bigger.p, W.contig_all.p, used, hipMemcpyDeviceToDevice, ctx->stream));
+                FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (W.contig_all.p) FSV_HIP(ctx, hipFree(W.contig_all.p));
+                W.contig_all = bigger;
+            }
+            FSV_HIP(ctx, hipMemcpyAsync((char *)W.contig_all.p + used, W.contig_out.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        used += bytes; nc += part.n_contigs;
+        // statistics: sums over the chunks
+        const fsv_asm_stats &st = W.stats;
+        total.n_pairs += st.n_pairs; total.n_overlaps += st.n_overlaps; total.n_windows += st.n_windows; total.n_windows_matched += st.n_windows_matched;
+        total.n_paths += st.n_paths; total.n_path_dp += st.n_path_dp; total.dp_columns += st.dp_columns; total.algo_bytes += st.algo_bytes;
+        total.n_exact_overlaps += st.n_exact_overlaps; total.n_inexact_candidates += st.n_inexact_candidates; total.n_path_indel1 += st.n_path_indel1;
+        total.ms_sketch += st.ms_sketch; total.ms_chain += st.ms_chain; total.ms_verify += st.ms_verify; total.ms_path += st.ms_path;
+        total.ms_consensus += st.ms_consensus; total.ms_final += st.ms_final; total.ms_total += st.ms_total;
+        total.n_kernels = st.n_kernels;
+        for (uint32_t k = 0; k < st.n_kernels; k++) {
+            memcpy(total.kernels[k].name, st.kernels[k].name, sizeof(st.kernels[k].name));
+            total.kernels[k].ms += st.kernels[k].ms; total.kernels[k].launches += st.kernels[k].launches; total.kernels[k].algo_bytes += st.kernels[k].algo_bytes;
+        }
+    }
+    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->n_contigs = nc;
+    W.stats = total;
+    W.n_reads = 0; W.cur_store = nullptr;        // fsv_asm_fetch_reads serves single-pass batches only
+    ctx->last_contigs_dev = nc ? (const char *)W.contig_all.p : nullptr;
+    ctx->last_contig_off.assign(out->off, out->off + nc + 1);
     return FSV_OK;
 }
 

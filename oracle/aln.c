@@ -342,8 +342,26 @@ int orc_align_contig_multi(const char *contig, int lenq, const char *ref, int le
     char *q = NULL;
     const char *Q;
     if (max_rec > ORC_ALN_MAX_REC) max_rec = ORC_ALN_MAX_REC;
-    nq = orc_unique_sorted(mq, orc_sketch(contig, lenq, w, P->k, 0, mq, lenq + 8));
-    nt = orc_unique_sorted(mt, orc_sketch(ref, lent, w, P->k, 0, mt, lent + 8));
+    {
+        /* long windows: fewer seeds, as fsv_align_batch picks them -- the minimizer window grows with the longer of the two
+         * sequences (one seed list of a 50 kb .. 760 kb window stays below the 8 192 the chaining tile holds), and beyond
+         * w = 255 the minimizers are thinned by their hash instead (every m-th survives on both sequences alike) */
+        const int L = lenq > lent ? lenq : lent;
+        int m = 1;
+        if (L / 3000 + 1 > w) w = L / 3000 + 1;
+        if (w > 255) { m = (w + 254) / 255; w = 255; }
+        nq = orc_sketch(contig, lenq, w, P->k, 0, mq, lenq + 8);
+        nt = orc_sketch(ref, lent, w, P->k, 0, mt, lent + 8);
+        if (m > 1) {
+            int j = 0;
+            for (i = 0; i < nq; i++) if ((mq[i].hash >> 11) % (uint64_t)m == 0) mq[j++] = mq[i];
+            nq = j; j = 0;
+            for (i = 0; i < nt; i++) if ((mt[i].hash >> 11) % (uint64_t)m == 0) mt[j++] = mt[i];
+            nt = j;
+        }
+        nq = orc_unique_sorted(mq, nq);
+        nt = orc_unique_sorted(mt, nt);
+    }
     cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nq + 1) * 2); ct = cq + nq + 1;
     n_rec = orc_aln_chains(mq, nq, lenq, mt, nt, P, &rev, cq, ct, nq, chain_n, max_rec);
     free(mq); free(mt);
