@@ -96,6 +96,128 @@ def sum_stats(dicts):
     return out
 
 
+def load_bed(which, limit):
+    """region lines (chrom, start, end) of the reference's auto-mode BED out of the committed fixtures: 'chr21' = its 377 chr21
+    lines (BASELINE.json configs[2]), 'genome' = all 26 834 (configs[3]); limit > 0 keeps every k-th line so that about `limit` remain"""
+    import gzip
+    rows = [l.split() for l in gzip.open(os.path.join(ROOT, "tests", "golden", "bed_whole_genome.bed.gz"), "rt")]
+    rows = [(c, int(a), int(b)) for c, a, b in rows if which == "genome" or c == which]
+    if limit and len(rows) > limit:
+        step = len(rows) / float(limit)
+        rows = [rows[int(i * step)] for i in range(limit)]
+    return rows
+
+
+def run_bed(args):
+    """--workload bed: the region set is fixed (strong scaling) and uneven (14 kb .. 1.1 Mb lines), so the ranks share it through
+    pipeline.RegionQueue -- the heavy 75 % dealt statically by work, the tail handed out in batches from one shared cursor -- every
+    rank streams its batches over its lanes (pipeline.run_stream, read stores uploaded inside the timed region), and one RCCL
+    gather of the VCF lines ends the job (pipeline.gather_vcf).  Synthetic reads are laid over the BED lines (seed 20000 + line)."""
+    import torch
+    import torch.distributed as dist
+    from focalsv_amd import _lib, pipeline, synth
+    from focalsv_amd.readsets import concat_packed, pack_sets
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("FSV_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", local)
+    rows = load_bed(args.bed, args.bed_limit)
+    margin = 15000
+    work = [(b - a + 2 * margin) for _, a, b in rows]            # read bases scale with the window width
+    rq = pipeline.RegionQueue(work, batch=args.bed_batch)
+    mine = sorted(set(rq.static) | set(rq.tail))                  # what this rank may be asked for: its static share and any tail batch
+    t0 = time.perf_counter()
+    made = {}
+    for i in mine:
+        c, a, b = rows[i]
+        made[i] = pipeline.region_from_synth(synth.make_region(20000 + i, width=b - a + 2 * margin, chrom=c, start=max(0, a - margin)))
+    # every region's reads packed to 2 bits on the host beforehand (what the BAM reader hands over on real data): a batch is then a
+    # concatenation of its regions' stores, whichever regions the queue deals
+    packed = {i: pack_sets([made[i].reads_hp1, made[i].reads_hp2]) for i in mine}
+    t_synth = time.perf_counter() - t0
+    lanes = max(1, args.lanes or 3)
+    ctxs = [_lib.Context(local) for _ in range(lanes)]
+
+    def host_batch(idx):
+        regions = [made[i] for i in idx]
+        return pipeline.HostBatch(regions, concat_packed([packed[i] for i in idx]), [ri for ri in range(len(idx)) for _ in (1, 2)], [1, 2] * len(idx))
+
+    def producer():
+        for idx in rq.batches():
+            taken.append(len(idx))
+            yield host_batch(idx)
+
+    def fence():
+        for c in ctxs:
+            c.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # warm-up: one small batch per lane (workspace allocation), untimed
+    warm = [host_batch(mine[:min(len(mine), 4)]) for _ in range(lanes)]
+    pipeline.run_stream(ctxs, warm, keep_results=False)
+    taken, lines, failed, asm_ms = [], [], [], [0.0]
+
+    def on_result(i, r):
+        lines.extend(r.lines); failed.extend(r.failed_regions); asm_ms[0] += r.asm_stats.get("ms_total", 0.0)
+
+    fence()
+    t0 = time.perf_counter()
+    pipeline.run_stream(ctxs, producer(), on_result=on_result, keep_results=False)
+    t_compute = time.perf_counter() - t0
+    all_lines = pipeline.gather_vcf(lines) if world > 1 else sorted(lines, key=pipeline._vcf_key)
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, t_compute], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    per = torch.tensor([sum(taken), rq.n_static_batches, rq.n_stolen_batches, len(lines)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    per_all = [torch.zeros_like(per) for _ in range(world)]
+    t_all = [torch.zeros_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_all, per); dist.all_gather(t_all, t)
+    else:
+        per_all, t_all = [per], [t]
+    dt_max = max(float(x[0]) for x in t_all)
+    if rank == 0:
+        n = len(rows)
+        # planted truth of every region (generated again here only for scoring, after the timed region)
+        calls = pipeline.parse_calls(all_lines)
+        out = {"metric": "target regions/sec (real BED widths, 30x HiFi)", "value": round(n / dt_max, 2), "unit": "regions/s", "n_gpus": world,
+               "steps": 1, "warmup": 1, "ms_per_step": round(dt_max * 1e3, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u32", "data": "synthetic",
+               "config": {"workload": f"--workload bed: {n} lines of the reference's auto-mode BED ({args.bed}" + (f", every {26834 // max(1, n)}th line" if args.bed == 'genome' and args.bed_limit else "") +
+                                      f"), window = line +- {margin} bp, widths {min(work)}..{max(work)}, synthetic 30x HiFi-like reads; BASELINE.json configs[{2 if args.bed != 'genome' else 3}]",
+                          "parallelism": f"RegionQueue over {world} rank(s): heaviest 75 % static by work, tail in batches of {args.bed_batch} from a shared cursor; {lanes} lanes per GPU; one VCF gather ({backend})"},
+               "ranks": [{"rank": k, "regions": int(p[0]), "static_batches": int(p[1]), "stolen_batches": int(p[2]), "vcf_lines": int(p[3]),
+                          "seconds": round(float(tt[0]), 3), "seconds_before_gather": round(float(tt[1]), 3)} for k, (p, tt) in enumerate(zip(per_all, t_all))],
+               "calls": len(calls), "regions_failed": len(set(failed)), "untimed_synth_and_pack_seconds_rank0": round(t_synth, 1),
+               "read_store_upload": "inside the timed region (HostBatch per batch, H2D on the lane that takes it)"}
+        if args.bed_score:
+            sc_truth, sc_tols = [], []
+            for i, (c, a, b) in enumerate(rows):
+                r = synth.make_region(20000 + i, width=b - a + 2 * margin, chrom=c, start=max(0, a - margin), depth_per_hap=0.2)
+                sc_truth += [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for t in r.truth]
+                sc_tols += [synth.position_tolerance(r, t) for t in r.truth]
+            tp, fp, fn, gt_ok = pipeline.match_truth(calls, sc_truth, bp_tol=1, len_tol=0.0, tols=sc_tols)
+            out["sv_vs_truth"] = {"truth": len(sc_truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok,
+                                  "note": "windows of neighbouring BED lines overlap once the margins are added: an SV planted in the shared stretch of one region is "
+                                          "not carried by the other region's haplotypes, so fn / fp counts here are an upper bound of the path's own misses"}
+        print(json.dumps(out))
+    fence()
+    for c in ctxs:
+        c.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +231,16 @@ def main():
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
     ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
     ap.add_argument("--cpu-sample", type=int, default=8, help="regions the CPU baseline runs (0 = skip)")
+    ap.add_argument("--workload", choices=["synthetic256", "bed"], default="synthetic256",
+                    help="synthetic256: BASELINE.json configs[1], weak scaling (the default the driver runs); bed: real BED widths over a work-stealing region "
+                         "queue, strong scaling (configs[2] / configs[3])")
+    ap.add_argument("--bed", default="chr21", help="bed workload: 'genome' or a chromosome name of the committed BED fixture")
+    ap.add_argument("--bed-limit", type=int, default=0, help="bed workload: keep about this many lines (evenly spaced); 0 = all")
+    ap.add_argument("--bed-batch", type=int, default=64, help="bed workload: regions per batch")
+    ap.add_argument("--bed-score", type=int, default=1, help="bed workload: score the gathered calls against the planted truth (untimed)")
     args = ap.parse_args()
+    if args.workload == "bed":
+        return run_bed(args)
 
     import numpy as np
     import torch

@@ -101,3 +101,60 @@ def test_region_queue_gloo_world2_covers_every_region_once():
 def test_region_queue_single_process():
     rq = pipeline.RegionQueue([3, 1, 2, 9, 9], batch=2)
     assert sorted(i for b in rq.batches() for i in b) == [0, 1, 2, 3, 4]
+
+
+def _bed_worker(rank, world, port, q):
+    """the bed workload's control flow around a stand-in for the GPU call: RegionQueue -> run_stream lanes -> gather_vcf"""
+    import gzip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = [l.split() for l in gzip.open(os.path.join(root, "tests", "golden", "bed_whole_genome.bed.gz"), "rt")]
+    rows = [(c, int(a), int(b)) for c, a, b in rows][::20]                 # every 20th line of the whole-genome BED: 1 342 regions, 14 kb .. 1.1 Mb
+    work = [b - a + 30000 for _, a, b in rows]
+
+    class Pending:
+        def __init__(self, lines):
+            self.lines = lines
+
+        def finish(self):
+            r = type("R", (), {})()
+            r.lines = self.lines
+            return r
+
+    def launch(ctx, batch, **kw):        # "calls" one SV at the start of every region of the batch
+        import time
+        time.sleep(0.0005 * len(batch) * (3 if rank == 1 else 1))           # rank 1 is the slow one
+        return Pending(["%s\t%d\tr%d\tA\tAT\t20\tPASS\tSVLEN=1;SVTYPE=INS\tGT\t0/1\n" % (rows[i][0], rows[i][1], i) for i in batch])
+
+    pipeline.launch_hot_path = launch
+    rq = pipeline.RegionQueue(work, batch=16)
+    lines = []
+    pipeline.run_stream(["lane0", "lane1"], rq.batches(), on_result=lambda i, r: lines.extend(r.lines), keep_results=False)
+    out = pipeline.gather_vcf(lines)
+    q.put((rank, len(lines), rq.n_static_batches, rq.n_stolen_batches, [l.split('\t')[2] for l in out] if rank == 0 else None,
+           [(l.split('\t')[0], int(l.split('\t')[1])) for l in out] if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bed_workload_control_flow_gloo_world2():
+    """bench.py --workload bed without the GPU: the uneven whole-genome region set over two ranks -- every region called exactly
+    once, the gathered VCF in (chromosome, position) order, the fast rank taking more of the shared tail"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    ids, keys = res[0][4], res[0][5]
+    assert sorted(ids) == sorted("r%d" % i for i in range(1342))
+    num = lambda c: int(c[3:])
+    assert keys == sorted(keys, key=lambda k: (num(k[0]), k[1]))
+    assert res[0][1] + res[1][1] == 1342
+    assert res[0][3] > res[1][3]            # stolen batches: the fast rank drained more of the tail
