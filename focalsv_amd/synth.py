@@ -38,6 +38,7 @@ class Region:
     truth: List[TruthSV] = field(default_factory=list)
     # what the region-cropped read BAM would say about every read: (0-based window position, BAM cigar, is_reverse)
     read_aln: Tuple[List[tuple], List[tuple]] = field(default_factory=lambda: ([], []))
+    note: str = ""
 
 
 def _rand_seq(rng, n):
@@ -248,6 +249,47 @@ def make_region(i: int, width: int = 50_000, profile: str = "hifi", depth_per_ha
         t.pos_left = left_align(ref, t.svtype, t.pos, t.length, np.frombuffer(t.seq.encode(), dtype=np.uint8) if t.svtype == "INS" else None)
     truth.sort(key=lambda t: t.pos)
     return Region(i, chrom, start, ref.tobytes(), (hap1.tobytes(), hap2.tobytes()), (r1, r2), truth, (a1, a2))
+
+
+def make_repeat_region(i: int, width: int = 60_000, depth: float = 15.0, err: float = 0.002):
+    """one haplotype with INTERSPERSED repeats (what the uniform-random windows of make_region lack): copies of one element --
+    0.3 .. 6 kb, 2 .. 8 copies, either strand, each copy 0 .. 5 % diverged from the master (substitutions and small indels) --
+    placed at random in a random window; seed 70000 + i.  -> Region with reads only in reads[0], and .note describing the layout"""
+    rng = np.random.default_rng(70000 + i)
+    ref = _rand_seq(rng, width)
+    div = float(rng.choice([0.0, 0.005, 0.01, 0.02, 0.05]))
+    kind = i % 3      # 0, 1: dispersed copies of one element; 2: many short copies (Alu-like) plus a tandem array of a long unit
+    if kind < 2:
+        elen = int(np.exp(rng.uniform(np.log(300), np.log(6000))))
+        ncopy = int(rng.integers(2, 9))
+    else:
+        elen = int(rng.integers(250, 400))
+        ncopy = int(rng.integers(15, 41))
+    master = _rand_seq(rng, elen)
+    grid = np.arange(2000, width - elen - 2000, max(elen + 200, (width - 4000) // (ncopy + 1)))
+    spots = sorted(int(x) for x in rng.choice(grid, size=min(ncopy, len(grid)), replace=False))
+    ncopy = len(spots)
+    pieces, last = [], 0
+    for sp in spots:
+        copy = _add_errors(rng, master, div)
+        if rng.random() < 0.5:
+            copy = _COMP[copy][::-1]
+        pieces += [ref[last:sp], copy]
+        last = sp
+    pieces.append(ref[last:])
+    note2 = ""
+    if kind == 2:
+        unit = _rand_seq(rng, int(rng.integers(100, 500)))
+        nrep = int(rng.integers(4, 16))
+        pieces.append(np.concatenate([_add_errors(rng, unit, div) for _ in range(nrep)]))
+        pieces.append(_rand_seq(rng, 6000))
+        note2 = " + tandem %d bp x %d" % (unit.size, nrep)
+    hap = np.concatenate(pieces)
+    lo, hi = min(10_000, max(1000, width // 2)), min(20_000, width)
+    reads = _sample_reads(rng, hap, depth, lo, hi, err, min(3000, max(500, width // 8)))
+    r = Region(i, "chr21", 0, hap.tobytes(), (hap.tobytes(), b""), (reads, []), [])
+    r.note = "element %d bp x %d copies, %.1f %% diverged%s" % (elen, ncopy, div * 100, note2)
+    return r
 
 
 def write_region_dir(region: Region, out_dir: str) -> str:

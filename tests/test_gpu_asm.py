@@ -146,3 +146,20 @@ def test_unphased_sets_give_both_haplotypes(ctx, golden_dir):
         got = sorted((len(c), hashlib.md5(canon(c)).hexdigest()) for c, cs in zip(contigs, cset) if cs == si)
         exp = sorted({(c["len"], c["md5"]) for h in ("hap1", "hap2") for c in gold[key][h]})
         assert got == exp
+
+
+def test_repeat_rich_sets_equal_hifiasm(ctx, golden_dir):
+    """the 36 read sets with interspersed repeats of tests/golden/hifiasm_repeats.json through fsv_assemble_batch in one call:
+    corrected reads md5 for md5 the reference's hifiasm --write-ec reads (three known one-base read-end differences), contigs
+    identical (where hifiasm itself collapses a repeat copy: the planted haplotype)"""
+    from tests.test_oracle_asm import check_repeat_set
+    gold = json.load(open(os.path.join(golden_dir, "hifiasm_repeats.json")))["sets"]
+    regions = [synth.make_repeat_region(g["index"]) for g in gold]
+    sets = [r.reads[0] for r in regions]
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets)
+    assert (status == 0).all()
+    k = 0
+    for si, (g, r) in enumerate(zip(gold, regions)):
+        corrected = reads[k:k + len(sets[si])]
+        k += len(sets[si])
+        check_repeat_set(g, [c for c, cs in zip(contigs, cset) if cs == si], corrected, r.haps[0])
