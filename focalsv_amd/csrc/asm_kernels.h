@@ -523,53 +523,108 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         for (int i = lane; i < n; i += 64) { s_aux[i] = (uint16_t)(i == 0 ? 0xffff : i - 1); s_f[i] = (dp_t)(i == n - 1 ? A.k_score + acc : 0); }
         __syncthreads();
     } else {
-        // The 64 predecessors live in registers, lane l = anchor i-1-l: after anchor i is settled every lane hands its anchor to
-        // the next lane (DPP wave_shr, lane 0 takes the new one), so an iteration has no LDS round trip on its critical path --
-        // only the broadcast read of the next anchor, requested one iteration ahead, and the stores of f / predecessor.
-        int rq = 0, rt = 0, rind = 0, rsl = 0, rf = 0;
-        key_t knext = s_key[0];
-        for (int i = 0; i < n; i++) {
-            const key_t ki = knext;
-            if (i + 1 < n) knext = s_key[i + 1];
-            const int qe = (int)((uint64_t)ki >> KSH), te = (int)((uint64_t)ki & KMASK);
-            const int j = i - 1 - lane;
-            int cand = -1, ti = 0, tl = 0;
-            if (j >= 0) {
-                const int dq = qe - rq, dt = te - rt;
-                if (dq > 0 && dt > 0) {
-                    const int gap = dq > dt ? dq - dt : dt - dq;
-                    ti = rind + gap; tl = rsl + dq;
-                    // 64-bit divisions cost ~150 VALU ops on gfx950; the operands fit 32 bits for every read below 2^17 bases
-                    // (ti <= tl*bw/1000 <= 2621, sc <= 63): same quotient either way
-                    if (tl < (1 << 17) && gap < (1 << 17) && A.bw <= 20) {
-                        if ((uint32_t)ti * 1000u <= (uint32_t)tl * (uint32_t)A.bw) {
-                            int sc = min(min(dq, dt), A.k_score);
-                            if (ti) sc -= (int)(((uint32_t)ti * (uint32_t)sc * 1000u) / ((uint32_t)tl * (uint32_t)A.bw));
-                            cand = sc + rf;
-                        }
-                    } else if ((long long)ti * 1000 <= (long long)tl * A.bw) {
-                        int sc = min(min(dq, dt), A.k_score);
-                        if (ti) sc -= (int)(((long long)ti * sc * 1000) / ((long long)tl * A.bw));
-                        cand = sc + rf;
+        // Reads with errors: the anchors leave the diagonal at every indel, and the DP of the reference (Hash_Table.cpp:425-616 as
+        // restated in oracle/asm.c: look back 64 anchors, link to the best-scoring predecessor, the nearer one on ties) is a chain
+        // of n dependent steps.  But it almost always links an anchor to the one just before it, so 64 anchors are settled at once:
+        //   hypothesis   every anchor of the block links to its predecessor; the chain's indel sum, span and score are then
+        //                prefix sums over the block (three wave scans);
+        //   proof        cand(i, j) <= f[j] + k for any other predecessor j, so only the j with f[j] + k > f[i] can beat the
+        //                hypothesis (usually none, or i-2): those candidates are evaluated exactly as the DP does;
+        //   repair       the first anchor whose hypothesis fails (an illegal link, a better candidate) and the few behind it go
+        //                through the sequential step -- the 64 predecessors in registers, lane l = anchor i-1-l, handed on by
+        //                DPP wave_shr -- and the blocks resume after them.
+        // By induction over the anchors the result is the sequential DP's, bit for bit (tests/test_gpu_asm.py against the oracle).
+        dp_t *const s_sl = SHORT ? (dp_t *)s_chain : (dp_t *)(s_rest + 8 * (size_t)AMAX);   // chain span per anchor (free arrays during the DP)
+        const int kk = A.k_score;
+        // candidate (i <- j): score or -1, with the chain's indel sum / span it would give
+        auto eval = [&](int qe, int te, int qj, int tj, int indj, int slj, int fj, int &ti, int &tl) -> int {
+            const int dq = qe - qj, dt = te - tj;
+            if (dq <= 0 || dt <= 0) return -1;
+            const int gap = dq > dt ? dq - dt : dt - dq;
+            ti = indj + gap; tl = slj + dq;
+            // 64-bit divisions cost ~150 VALU ops on gfx950; the operands fit 32 bits for every read below 2^17 bases
+            // (ti <= tl*bw/1000 <= 2621, sc <= 63): same quotient either way
+            if (tl < (1 << 17) && gap < (1 << 17) && A.bw <= 20) {
+                if ((uint32_t)ti * 1000u > (uint32_t)tl * (uint32_t)A.bw) return -1;
+                int sc = min(min(dq, dt), kk);
+                if (ti) sc -= (int)(((uint32_t)ti * (uint32_t)sc * 1000u) / ((uint32_t)tl * (uint32_t)A.bw));
+                return sc + fj;
+            }
+            if ((long long)ti * 1000 > (long long)tl * A.bw) return -1;
+            int sc = min(min(dq, dt), kk);
+            if (ti) sc -= (int)(((long long)ti * sc * 1000) / ((long long)tl * A.bw));
+            return sc + fj;
+        };
+        auto scan_add = [&](int v) { for (int off = 1; off < 64; off <<= 1) { const int o2 = __shfl_up(v, off, 64); if (lane >= off) v += o2; } return v; };
+        if (lane == 0) { s_f[0] = (dp_t)kk; s_aux[0] = 0xffff; s_ind[0] = 0; s_sl[0] = 0; }
+        __syncthreads();
+        int i0 = 1;
+        while (i0 < n) {
+            const int nb = min(64, n - i0), i = i0 + lane;
+            const bool in = lane < nb;
+            int qe = 0, te = 0, dq = 0, dt = 0, gap = 0;
+            if (in) { qe = KEY_Q(i); te = KEY_T(i); dq = qe - KEY_Q(i - 1); dt = te - KEY_T(i - 1); gap = dq > dt ? dq - dt : dt - dq; }
+            const int ti = (int)s_ind[i0 - 1] + scan_add(gap), tl = (int)s_sl[i0 - 1] + scan_add(dq);
+            bool legal = in && dq > 0 && dt > 0;
+            int sc = 0;
+            if (legal) {
+                int t2, l2;
+                const int c = eval(qe, te, qe - dq, te - dt, ti - gap, tl - dq, 0, t2, l2);
+                legal = c >= 0; sc = c;
+            }
+            const int fi = (int)s_f[i0 - 1] + scan_add(legal ? sc : 0);
+            bool bad = in && !(legal && fi > kk);
+            __syncthreads();
+            if (in) { s_f[i] = (dp_t)fi; s_ind[i] = (dp_t)ti; s_sl[i] = (dp_t)tl; }
+            __syncthreads();
+            for (int d = 2; d <= 64; d++) {
+                const int j = i - d;
+                const bool live = in && !bad && j >= 0;
+                if (!__any(live)) break;
+                int fj = 0;
+                if (live) fj = (int)s_f[j];
+                const bool need = live && fj + kk > fi;
+                if (__any(need)) {
+                    if (need) {
+                        int t2, l2;
+                        if (eval(qe, te, KEY_Q(j), KEY_T(j), (int)s_ind[j], (int)s_sl[j], fj, t2, l2) > fi) bad = true;
                     }
                 }
             }
-            // pack so that the max prefers the higher score, then the nearer predecessor
-            const int packed = cand < 0 ? -1 : cand * 64 + (63 - lane);
-            const int bestp = wave_max_i32(packed);
-            const int bests = bestp < 0 ? -1 : bestp >> 6;
-            int nf = A.k_score, nind = 0, nsl = 0, npred = 0xffff;
-            if (bests > A.k_score) {
-                const int wl = 63 - (bestp & 63);
-                nf = bests; npred = i - 1 - wl;
-                nind = __builtin_amdgcn_readlane(ti, wl); nsl = __builtin_amdgcn_readlane(tl, wl);
+            const uint64_t badm = __ballot(bad);
+            const int good = badm ? (int)__ffsll((long long)badm) - 1 : nb;     // anchors i0 .. i0 + good - 1 stand
+            if (lane < good) s_aux[i] = (uint16_t)(i - 1);
+            __syncthreads();
+            i0 += good;
+            if (good == nb) continue;
+            // sequential steps for the anchor that broke the hypothesis and up to seven behind it
+            const int s1 = min(n, i0 + 8);
+            int rq = 0, rt = 0, rind = 0, rsl = 0, rf = 0;
+            { const int j = i0 - 1 - lane; if (j >= 0) { rq = KEY_Q(j); rt = KEY_T(j); rind = (int)s_ind[j]; rsl = (int)s_sl[j]; rf = (int)s_f[j]; } }
+            for (int is = i0; is < s1; is++) {
+                const int qe2 = KEY_Q(is), te2 = KEY_T(is);
+                const int j = is - 1 - lane;
+                int cand = -1, ti2 = 0, tl2 = 0;
+                if (j >= 0) cand = eval(qe2, te2, rq, rt, rind, rsl, rf, ti2, tl2);
+                // pack so that the max prefers the higher score, then the nearer predecessor
+                const int packed = cand < 0 ? -1 : cand * 64 + (63 - lane);
+                const int bestp = wave_max_i32(packed);
+                const int bests = bestp < 0 ? -1 : bestp >> 6;
+                int nf = kk, nind = 0, nsl = 0, npred = 0xffff;
+                if (bests > kk) {
+                    const int wl = 63 - (bestp & 63);
+                    nf = bests; npred = is - 1 - wl;
+                    nind = __builtin_amdgcn_readlane(ti2, wl); nsl = __builtin_amdgcn_readlane(tl2, wl);
+                }
+                if (lane == 0) { s_f[is] = (dp_t)nf; s_aux[is] = (uint16_t)npred; s_ind[is] = (dp_t)nind; s_sl[is] = (dp_t)nsl; }
+                rq = __builtin_amdgcn_update_dpp(qe2, rq, 0x138, 0xF, 0xF, false);    // wave_shr:1, lane 0 <- the new anchor
+                rt = __builtin_amdgcn_update_dpp(te2, rt, 0x138, 0xF, 0xF, false);
+                rind = __builtin_amdgcn_update_dpp(nind, rind, 0x138, 0xF, 0xF, false);
+                rsl = __builtin_amdgcn_update_dpp(nsl, rsl, 0x138, 0xF, 0xF, false);
+                rf = __builtin_amdgcn_update_dpp(nf, rf, 0x138, 0xF, 0xF, false);
             }
-            if (lane == 0) { s_f[i] = (dp_t)nf; s_aux[i] = (uint16_t)npred; }
-            rq = __builtin_amdgcn_update_dpp(qe, rq, 0x138, 0xF, 0xF, false);    // wave_shr:1, lane 0 <- the new anchor
-            rt = __builtin_amdgcn_update_dpp(te, rt, 0x138, 0xF, 0xF, false);
-            rind = __builtin_amdgcn_update_dpp(nind, rind, 0x138, 0xF, 0xF, false);
-            rsl = __builtin_amdgcn_update_dpp(nsl, rsl, 0x138, 0xF, 0xF, false);
-            rf = __builtin_amdgcn_update_dpp(nf, rf, 0x138, 0xF, 0xF, false);
+            __syncthreads();
+            i0 = s1;
         }
         __syncthreads();
     }
