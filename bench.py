@@ -447,6 +447,8 @@ def main():
             "config": {"workload": f"{n} synthetic 50 kb regions per GPU, 30x HiFi-like reads U(10k,20k), 0.2% error, seed 1000+i "
                                    "(BASELINE.json configs[1])", "regions_per_gpu": n, "parallelism": f"regions sharded over {world} GPU(s), RCCL VCF gather; {lanes} concurrent lanes (streams) per GPU, " + ("each taking whole steps (one batch in flight per lane, the host half of a batch on its own thread)" if by_steps else "each half of every step's batch")},
             "sv_vs_truth": {"truth": len(truth), "tp": tp, "fp": fp, "fn": fn, "gt_ok": gt_ok, "tp_within_1bp_of_left_aligned_truth": tp1},
+            "aligner_parity": "unpinned against minimap2 2.24 (absent from the reference tree and this image): chaining / z-drop are this project's own; pinned: "
+                              "the DP recurrence (in-tree ksw2 goldens), mm_fix_cigar's gap left-alignment as published, planted truth",
             "stage_ms": {k: round(v, 2) for k, v in a.items() if k.startswith("ms_")},
             "kernels": kernels,
             "align_ms": {k: round(v, 2) for k, v in l.items() if k.startswith("ms_")},
