@@ -27,7 +27,7 @@ assert WPATH_DTYPE.itemsize == 128
 
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final",
-                                         "min_contig_reads")]
+                                         "min_contig_reads", "win_rate_pm", "k_cap", "accept_err_pm")]
 
 
 class ReadSets(C.Structure):
@@ -128,6 +128,7 @@ def load():
         "fsv_bpm_windows": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp]),
         "fsv_bpm_paths": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp]),
         "fsv_asm_default_params": (None, [C.POINTER(AsmParams)]),
+        "fsv_asm_ont_params": (None, [C.POINTER(AsmParams)]),
         "fsv_assemble_batch_bound": (C.c_int, [C.POINTER(ReadSets), u64p, u32p]),
         "fsv_assemble_batch": (C.c_int, [vp, C.POINTER(ReadSets), C.POINTER(AsmParams), C.POINTER(Contigs)]),
         "fsv_asm_last_stats": (C.c_int, [vp, C.POINTER(AsmStats)]),
@@ -290,6 +291,12 @@ class Context:
     def default_asm_params(self):
         p = AsmParams()
         self._lib.fsv_asm_default_params(C.byref(p))
+        return p
+
+    def ont_asm_params(self):
+        """the error model for ONT-profile reads (fsv_asm_ont_params)"""
+        p = AsmParams()
+        self._lib.fsv_asm_ont_params(C.byref(p))
         return p
 
     def upload(self, arr):

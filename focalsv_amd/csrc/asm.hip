@@ -49,11 +49,11 @@ struct Span {
 
 // per-round block of device counters (one 64-byte slot per correction round + one for the final pass, zeroed once per batch and
 // read back with the round's one synchronisation or at the end): u32 indices
-enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4, CT_COLS_HI = 5, CT_DP_WIDE = 6, CT_DP_SB = 7, CT_DP_GEN = 8,
+enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4, CT_COLS_HI = 5, CT_DP_WIDE = 6, CT_DP_SB = 7, CT_DP_GEN = 8, CT_DP_XW = 9,
        CT_MZ_LO = 10, CT_MZ_HI = 11, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, set_cols, trans, read_flag, changed,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, trans, read_flag, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -68,7 +68,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &set_cols, &trans, &read_flag, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &trans, &read_flag, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -107,11 +107,12 @@ template <class T> int upload(fsv_ctx *ctx, DevBuf &b, const std::vector<T> &v)
     return FSV_OK;
 }
 
-uint8_t thr_for_len_host(int x_len)
+uint8_t thr_for_len_host(int x_len, int rate_pm)
 {
     // verify_window: threshold = x_len * max_ov_diff_ec (0.04 as a double, truncated), Adjust_Threshold (Correct.h:39)
-    if (x_len == FSV_WINDOW) return FSV_K_FULL;
-    int t = (int)(x_len * 0.04);
+    const double rate = rate_pm / 1000.0;       // 40 / 1000.0 is the double 0.04
+    if (x_len == FSV_WINDOW) return rate_pm == 40 ? FSV_K_FULL : (uint8_t)(int)(FSV_WINDOW * rate);
+    int t = (int)(x_len * rate);
     if (t == 0 && x_len >= 4) t = 1;
     return (uint8_t)t;
 }
@@ -310,6 +311,16 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
     if (!p) return;
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
+    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30;
+}
+
+extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
+{
+    if (!p) return;
+    fsv_asm_default_params(p);
+    p->k = 15; p->w = 10; p->hpc = 0;           // 15-mers survive 10 % error often enough to seed (20 % of them per read); no HPC: indel errors dominate
+    p->bw_ec = 150; p->bw_final = 50;           // chains of noisy reads drift by several per cent between anchors
+    p->win_rate_pm = 250; p->k_cap = FSV_K_WIDE; p->accept_err_pm = 300;   // two 10 % reads differ by ~20 %: k = 93 for a full window
 }
 
 extern "C" int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap)
@@ -330,11 +341,15 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
 {
     if (!ctx || !store || (!tasks && n_tasks) || (!res && n_tasks) || (!paths && n_tasks)) return FSV_EINVAL;
     if (n_tasks == 0) return FSV_OK;
-    for (uint32_t i = 0; i < n_tasks; i++)
-        if (tasks[i].k > FSV_K_MAX || tasks[i].x_len == 0 || tasks[i].x_len > FSV_WINDOW) return fsv_fail(ctx, FSV_EINVAL, "task k/x_len out of range");
+    int kmax = 0;
+    for (uint32_t i = 0; i < n_tasks; i++) {
+        if (tasks[i].k > FSV_K_WIDE || tasks[i].x_len == 0 || tasks[i].x_len > FSV_WINDOW) return fsv_fail(ctx, FSV_EINVAL, "task k/x_len out of range");
+        kmax = std::max<int>(kmax, tasks[i].k);
+    }
+    const int k_cap = kmax > FSV_K_MAX ? kmax : FSV_K_MAX;     // a threshold above 31 anywhere: K5 of the whole list through the wide kernel
     FSV_HIP(ctx, hipSetDevice(ctx->device));
-    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_list2, d_list3, d_wide, d_cnt, d_cols, d_cols_sb;
-    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_list2, &d_list3, &d_wide, &d_cnt, &d_cols, &d_cols_sb}) if (b->p) (void)hipFree(b->p); };
+    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_list2, d_list3, d_wide, d_xwide, d_cnt, d_cols, d_cols_sb, d_cols_wide;
+    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_list2, &d_list3, &d_wide, &d_xwide, &d_cnt, &d_cols, &d_cols_sb, &d_cols_wide}) if (b->p) (void)hipFree(b->p); };
     int rc = FSV_OK;
     auto run = [&]() -> int {
         std::vector<fsv_wtask> t(tasks, tasks + n_tasks);
@@ -347,16 +362,16 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         TRY(upload(ctx, d_ovl, std::vector<fsv_ovl>{o}));
         TRY(ensure(ctx, d_res, (size_t)n_tasks * sizeof(fsv_wres)));
         TRY(ensure(ctx, d_paths, (size_t)n_tasks * sizeof(fsv_wpath)));
-        for (DevBuf *b : {&d_list, &d_list2, &d_list3, &d_wide}) TRY(ensure(ctx, *b, (size_t)n_tasks * 4));
+        for (DevBuf *b : {&d_list, &d_list2, &d_list3, &d_wide, &d_xwide}) TRY(ensure(ctx, *b, (size_t)n_tasks * 4));
         TRY(ensure(ctx, d_cnt, CT_SLOT * 4));
         uint32_t *ct = (uint32_t *)d_cnt.p;
         FSV_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, CT_SLOT * 4, ctx->stream));
         FSV_HIP(ctx, hipMemsetAsync(d_paths.p, 0, (size_t)n_tasks * sizeof(fsv_wpath), ctx->stream));
         // the same launches as a correction round of fsv_assemble_batch (device-side list lengths, no host round trip in between)
-        TRY(fsv_bpm_windows_dev(ctx, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, n_tasks, (fsv_wres *)d_res.p));
+        TRY(fsv_bpm_windows_dev_n(ctx, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, n_tasks, nullptr, (fsv_wres *)d_res.p, k_cap));
         hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_ovl *)d_ovl.p,
                            (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p, n_tasks, (fsv_wpath *)d_paths.p, (uint32_t *)d_list.p,
-                           ct + CT_DP, (uint32_t *)d_wide.p, ct + CT_DP_WIDE, true, (const uint32_t *)nullptr);
+                           ct + CT_DP, (uint32_t *)d_wide.p, ct + CT_DP_WIDE, true, (const uint32_t *)nullptr, (uint32_t *)d_xwide.p, ct + CT_DP_XW);
         FSV_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
                            (const fsv_wres *)d_res.p, (const uint32_t *)d_list.p, 0u, (fsv_wpath *)d_paths.p, (uint32_t *)d_list2.p, ct + CT_DP_SB,
@@ -375,6 +390,13 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(gridg), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
                            (const uint32_t *)d_wide.p, 0u, 0u, (fsv_wpath *)d_paths.p, (uint64_t *)d_cols.p, gridg * 64, (const uint32_t *)(ct + CT_DP_WIDE));
         FSV_HIP(ctx, hipGetLastError());
+        if (kmax > FSV_K_MAX) {
+            const uint32_t gridw = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 4u * (uint32_t)ctx->n_cu);
+            TRY(ensure(ctx, d_cols_wide, (size_t)gridw * FSV_WINDOW * 2 * FSV_WL * 64 * 4));
+            hipLaunchKernelGGL(k_path_wide, dim3(gridw), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+                               (const uint32_t *)d_xwide.p, (const uint32_t *)(ct + CT_DP_XW), (fsv_wpath *)d_paths.p, (uint32_t *)d_cols_wide.p, k_cap);
+            FSV_HIP(ctx, hipGetLastError());
+        }
         FSV_HIP(ctx, hipMemcpyAsync(res, d_res.p, (size_t)n_tasks * sizeof(fsv_wres), hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipMemcpyAsync(paths, d_paths.p, (size_t)n_tasks * sizeof(fsv_wpath), hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -426,7 +448,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     for (uint32_t r = 0; r < B.n_reads; r++) if (len[r] < 1 || len[r] >= (1 << 24)) return fsv_fail(ctx, FSV_EUNSUP, "read length must be in [1, 2^24)");
 
     std::vector<uint8_t> thr(FSV_WINDOW + 1);
-    for (int i = 0; i <= FSV_WINDOW; i++) thr[i] = thr_for_len_host(i);
+    for (int i = 0; i <= FSV_WINDOW; i++) thr[i] = thr_for_len_host(i, P.win_rate_pm);
     TRY(upload(ctx, W.thr_tab, thr));
     TRY(upload(ctx, W.set_start, B.set_start));
     TRY(upload(ctx, W.read_set, B.read_set));
@@ -468,6 +490,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     G.word_off = woff0;
     const uint32_t *store = sets->store_dev;
     uint64_t reads_in_bytes = 0;
+    const bool wide_bands = P.k_cap > FSV_K_MAX;   // the error model allows thresholds above hifiasm's 31: wide-band K5 / K6 / rescue
     bool short_reads = true;     // every read below 65 536 bases: k_chain's compact LDS layout
     for (uint32_t r = 0; r < B.n_reads; r++) { reads_in_bytes += (uint64_t)(len[r] + 3) / 4; if (len[r] >= 65536) short_reads = false; }
     TRY(ensure(ctx, W.counters, (size_t)(P.n_rounds + 1) * CT_SLOT * 4));
@@ -496,17 +519,23 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         TRY(ensure(ctx, W.dp_list2, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_list3, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_wide, (size_t)task_cap * 4));
+        TRY(ensure(ctx, W.dp_xwide, wide_bands ? (size_t)task_cap * 4 : 64));
         TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_ec, true, task_cap, ct, short_reads));
         W.stats.n_pairs += B.n_pairs;
         if (B.n_pairs) {
             Span tv(ctx, W.kt, ST_VERIFY);
             W.bpm_rec.push_back(W.kt.begin(ctx, KN_BPM, 0));
-            TRY(fsv_bpm_windows_dev_n(ctx, store, (const fsv_wtask *)W.tasks.p, task_cap, ct + CT_TASKS, (fsv_wres *)W.res.p));
+            TRY(fsv_bpm_windows_dev_n(ctx, store, (const fsv_wtask *)W.tasks.p, task_cap, ct + CT_TASKS, (fsv_wres *)W.res.p, P.k_cap));
             W.kt.end(ctx);
             W.rescue_rec.push_back(W.kt.begin(ctx, KN_RESCUE, (uint64_t)B.n_pairs * sizeof(fsv_ovl) * 2));
-            hipLaunchKernelGGL(k_rescue_accept, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
-                               B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)(ct + CT_COLS_LO),
-                               (uint4 *)W.ovl_c.p);
+            if (wide_bands)
+                hipLaunchKernelGGL(k_rescue_accept<true>, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
+                                   B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)(ct + CT_COLS_LO),
+                                   (uint4 *)W.ovl_c.p, P.k_cap, P.accept_err_pm);
+            else
+                hipLaunchKernelGGL(k_rescue_accept<false>, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
+                                   B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)(ct + CT_COLS_LO),
+                                   (uint4 *)W.ovl_c.p, P.k_cap, P.accept_err_pm);
             FSV_HIP(ctx, hipGetLastError());
             W.kt.end(ctx);
             tv.stop();
@@ -514,7 +543,8 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             W.fast_rec.push_back(W.kt.begin(ctx, KN_PATH_FAST, 0));
             hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
                                (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, task_cap, (fsv_wpath *)W.paths.p,
-                               (uint32_t *)W.dp_list.p, ct + CT_DP, (uint32_t *)W.dp_wide.p, ct + CT_DP_WIDE, false, (const uint32_t *)(ct + CT_TASKS));
+                               (uint32_t *)W.dp_list.p, ct + CT_DP, (uint32_t *)W.dp_wide.p, ct + CT_DP_WIDE, false, (const uint32_t *)(ct + CT_TASKS),
+                               (uint32_t *)W.dp_xwide.p, ct + CT_DP_XW);
             FSV_HIP(ctx, hipGetLastError());
             W.kt.end(ctx);
             // single-indel windows are settled without the DP (k_path_indel1); what is left goes to the sub-band kernel
@@ -555,6 +585,16 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
                 hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(gridg), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
                                    (const uint32_t *)W.dp_wide.p, 0u, 0u, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p, stride, (const uint32_t *)(ct + CT_DP_WIDE));
                 FSV_HIP(ctx, hipGetLastError());
+                if (wide_bands) {
+                    // bands above 63 rows: every gapped window of an ONT-profile batch; 1.15 MB of column scratch per persistent block
+                    int pc = 0;
+                    FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_path_wide, 64, 0));
+                    const uint32_t gridw = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, std::min(pc, 12)) * (uint32_t)ctx->n_cu);
+                    TRY(ensure(ctx, W.cols_wide, (size_t)gridw * FSV_WINDOW * 2 * FSV_WL * 64 * 4));
+                    hipLaunchKernelGGL(k_path_wide, dim3(gridw), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p,
+                                       (const uint32_t *)W.dp_xwide.p, (const uint32_t *)(ct + CT_DP_XW), (fsv_wpath *)W.paths.p, (uint32_t *)W.cols_wide.p, P.k_cap);
+                    FSV_HIP(ctx, hipGetLastError());
+                }
             }
             W.kt.end(ctx);
             tp.stop();
@@ -781,7 +821,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         if (sl == P.n_rounds) { W.stats.n_inexact_candidates = c[CT_INEXACT]; break; }
         W.stats.n_windows += c[CT_TASKS];
         W.stats.dp_columns += (uint64_t)c[CT_COLS_LO] | (uint64_t)c[CT_COLS_HI] << 32;      // rescue re-runs (k_rescue_accept)
-        W.stats.n_path_dp += (uint64_t)c[CT_DP_SB] + c[CT_DP_GEN] + c[CT_DP_WIDE];
+        W.stats.n_path_dp += (uint64_t)c[CT_DP_SB] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW];
         W.stats.n_path_indel1 += (uint64_t)c[CT_DP] - c[CT_DP_SB] - c[CT_DP_GEN];
         // algorithmic bytes of the round's launches, now that the counts are known: a window task is
         // 94 + 102 B of 2-bit operands + 16 B of result; a K6 window leaves a 128 B path record instead;
@@ -790,8 +830,8 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         const uint64_t nt = c[CT_TASKS];
         if ((size_t)sl < W.bpm_rec.size()) W.kt.recs[W.bpm_rec[sl]].bytes = nt * 212ull;
         if ((size_t)sl < W.rescue_rec.size()) W.kt.recs[W.rescue_rec[sl]].bytes += nt * 16ull;
-        if ((size_t)sl < W.fast_rec.size()) W.kt.recs[W.fast_rec[sl]].bytes = nt * (16ull + 196ull) + (nt - c[CT_DP] - c[CT_DP_WIDE]) * 128ull;
-        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = ((uint64_t)c[CT_DP_SB] + c[CT_DP_GEN] + c[CT_DP_WIDE]) * (196ull + 128ull);
+        if ((size_t)sl < W.fast_rec.size()) W.kt.recs[W.fast_rec[sl]].bytes = nt * (16ull + 196ull) + (nt - c[CT_DP] - c[CT_DP_WIDE] - c[CT_DP_XW]) * 128ull;
+        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = ((uint64_t)c[CT_DP_SB] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW]) * (196ull + 128ull);
         if ((size_t)sl < W.cons_rec.size()) W.kt.recs[W.cons_rec[sl]].bytes += nt * 128ull;
     }
     for (size_t i = 0; i < W.chain_rec.size(); i++) {
@@ -839,6 +879,8 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     if (params) P = *params; else fsv_asm_default_params(&P);
     if (P.k < 1 || P.k > 63 || P.w < 1 || P.w > 64 || P.lookback != 64 || P.n_rounds < 0 || P.n_rounds > 16 || P.min_anchors < 1)
         return fsv_fail(ctx, FSV_EINVAL, "fsv_asm_params out of range (k<=63, w<=64, lookback==64)");
+    if (P.k_cap < 1 || P.k_cap > FSV_K_WIDE || P.win_rate_pm < 1 || (int)(FSV_WINDOW * (P.win_rate_pm / 1000.0)) > P.k_cap || P.accept_err_pm < 0 || P.accept_err_pm > 1000)
+        return fsv_fail(ctx, FSV_EINVAL, "fsv_asm_params error model out of range (k_cap <= 95, 375 x win_rate_pm / 1000 <= k_cap)");
     FSV_HIP(ctx, hipSetDevice(ctx->device));
     AsmWs &W = *ws_get(ctx);
     out->n_contigs = 0; out->off[0] = 0;

@@ -769,18 +769,20 @@ __host__ __device__ inline size_t chain_lds_bytes(bool short_reads, int amax) { 
 // ------------------------------------------------------------------------------------------------ k_rescue_accept
 // One lane per overlap slot: right-extension rescue of unmatched windows (Correct.cpp:2655-2744),
 // then the 0.9 coverage filter and the 0.03 error-rate filter (Correct.cpp:2899-3021, 725).
-__device__ __forceinline__ int double_thr(int pre, int x_len)
+__device__ __forceinline__ int double_thr(int pre, int x_len, int k_cap)
 {
     if (pre == 0 && x_len >= 4) pre = 1;
     int t = pre * 2;
-    if (x_len >= 300 && t < FSV_K_MAX) t = FSV_K_MAX;
-    if (t > FSV_K_MAX) t = FSV_K_MAX;
+    if (x_len >= 300 && t < k_cap) t = k_cap;
+    if (t > k_cap) t = k_cap;
     return t;
 }
 
+// WIDE: the batch's error model allows thresholds above 31 (k_cap up to 95): the re-runs go through the wide-band BPM
+template <bool WIDE>
 __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict__ store, fsv_ovl *__restrict__ ovl, uint32_t n_pairs,
                                                       fsv_wtask *__restrict__ tasks, fsv_wres *__restrict__ res,
-                                                      unsigned long long *__restrict__ stat_cols, uint4 *__restrict__ ovl_c)
+                                                      unsigned long long *__restrict__ stat_cols, uint4 *__restrict__ ovl_c, int k_cap, int accept_err_pm)
 {
     const uint32_t p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n_pairs) return;
@@ -798,12 +800,13 @@ __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict
         for (int k2 = j + 1; k2 < o.n_win && R[k2].err < 0; k2++) {
             fsv_wtask u = T[k2];
             if (next >= u.y_len) break;
-            u.k = (uint8_t)double_thr(u.k, u.x_len);
+            u.k = (uint8_t)double_thr(u.k, u.x_len, k_cap);
             u.y_start = next;
             fsv_wres r;
-            if (!bpm_window_geometry(u, r)) break;
+            if (!bpm_window_geometry(u, r, k_cap)) break;
             if ((u.x_len + 2 * u.k - r.extra_begin - r.extra_end) + u.k < u.x_len) break;
-            bpm_run(store, u, r, BpmNoSink());
+            if (WIDE) { WideNoSink none; bpm_run_wide(store, u, r, none, k_cap); }
+            else bpm_run(store, u, r, BpmNoSink());
             cols += u.x_len;
             if (r.err < 0) break;
             T[k2] = u; R[k2] = r;
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict
     long long tlen = 0, terr = 0;
     for (int j = 0; j < o.n_win; j++) { tlen += T[j].x_len; terr += R[j].err >= 0 ? R[j].err : T[j].x_len; }
     o.align_len = align; o.err_sum = (int32_t)terr;
-    o.is_match = ((long long)(o.x_e - o.x_s + 1) * 9 <= (long long)align * 10 && terr * 100 <= tlen * 3) ? 1 : 0;
+    o.is_match = ((long long)(o.x_e - o.x_s + 1) * 9 <= (long long)align * 10 && terr * 1000 <= tlen * accept_err_pm) ? 1 : 0;
     ovl[p] = o;
     ovl_c[p] = make_uint4((uint32_t)o.x_s, (uint32_t)o.first_win, (uint32_t)o.n_win | (o.is_match ? 0x80000000u : 0u), 0u);
     if (cols) atomicAdd(stat_cols, cols);
@@ -836,7 +839,8 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
                                                    const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res, uint32_t n_tasks,
                                                    fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list, uint32_t *__restrict__ dp_count,
                                                    uint32_t *__restrict__ dp_wide, uint32_t *__restrict__ dp_count_wide, bool write_clean_ops,
-                                                   const uint32_t *__restrict__ n_dev)
+                                                   const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ dp_xwide = nullptr,
+                                                   uint32_t *__restrict__ dp_count_xwide = nullptr)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_dev) n_tasks = *n_dev;   // the grid covers the task bound; the count stays on the device (no host round trip)
@@ -879,7 +883,8 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
         // thresholds of the rescue pass) in lists of their own, so that each launch is homogeneous
         P->state = 2;
         if (t.k <= 15) dp_list[atomicAdd(dp_count, 1u)] = tid;
-        else dp_wide[atomicAdd(dp_count_wide, 1u)] = tid;
+        else if (t.k <= FSV_K_MAX) dp_wide[atomicAdd(dp_count_wide, 1u)] = tid;
+        else dp_xwide[atomicAdd(dp_count_xwide, 1u)] = tid;     // bands above 63 rows (k_path_wide)
         return;
     }
     // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops (3) and
@@ -1029,6 +1034,9 @@ __device__ __forceinline__ void path_finish(const uint32_t *__restrict__ store, 
                                             int lane64, int col, int dir, int plen, int start, int end, int err)
 {
     if (col > 0) { start -= col; plen += col; dir = 0; } // the rest of the path is matches: the fields are already 0
+    // a record holds FSV_PATH_CAP ops (x_len + k <= 406 for hifiasm's thresholds: never reached); a longer path -- a wide-band
+    // window with more than 41 inserted bases -- leaves the window without a path, as oracle/asm.c:window_path does
+    if (plen > FSV_PATH_CAP) { P->state = 0; return; }
     if (dir != 3) start++;
     // generate_cigar: TMP is stored end-to-start
     if (err > 0) {
@@ -1252,6 +1260,72 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
         if (STAMP) { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); t_fwd += t1 - t0; t_walk += t2 - t1; t_fin += t3 - t2; }
     }
     if (STAMP && lane64 == 0) { atomicAdd(&stamps[0], t_fwd); atomicAdd(&stamps[1], t_walk); atomicAdd(&stamps[2], t_fin); atomicAdd(&stamps[3], 1ull); }
+}
+
+// ---- K6 for wide bands (k > 31, up to 95): the ONT profile ---------------------------------------------------------------------
+// The walk codes of k_path_sb for every band row: two planes x six 32-bit limbs per column (48 B) in a per-lane slice of an HBM
+// scratch ([block][column][12][lane]).  The distance of such a window is of the order of its band (tens of errors), so there is
+// no narrow sub-band to keep, and the walk reads the two words of its row's limb at every step.  First version: correct, not
+// tuned (the forward pass is ~130 lane-ops per column, the walk a dependent load per step).
+struct WideCodeSink {
+    uint32_t *cols; uint32_t lane; int band;
+    __device__ __forceinline__ void operator()(int col, const uint32_t *d0, const uint32_t *hp, const uint32_t *vp)
+    {
+        uint32_t *c = cols + (size_t)col * 2 * FSV_WL * 64 + lane;
+#pragma unroll
+        for (int l = 0; l < FSV_WL; l++) {
+            const uint32_t u = vp[l] << 1 | (l ? vp[l - 1] >> 31 : 0u);
+            // the top band row has no left neighbour
+            const int tb = band - 1 - 32 * l;
+            const uint32_t lm = band == 1 ? 1u : (tb >= 32 ? 0xffffffffu : (tb <= 0 ? 0u : ((1u << tb) - 1u)));
+            const uint32_t lf = hp[l] & lm;
+            c[(size_t)l * 64] = ~d0[l] | (lf & ~u);              // low code bit
+            c[(size_t)(FSV_WL + l) * 64] = d0[l] & (u | lf);     // high code bit
+        }
+    }
+};
+
+__global__ __launch_bounds__(64) void k_path_wide(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res,
+                                                  const uint32_t *__restrict__ dp_list, const uint32_t *__restrict__ n_dev,
+                                                  fsv_wpath *__restrict__ paths, uint32_t *__restrict__ cols, int k_cap)
+{
+    __shared__ uint32_t s_ops[28][64];
+    const int lane64 = threadIdx.x;
+    const uint32_t n_list = *n_dev;
+    uint32_t *slot = cols + (size_t)blockIdx.x * FSV_WINDOW * 2 * FSV_WL * 64;
+    for (uint32_t li = blockIdx.x * 64 + threadIdx.x; li < n_list; li += gridDim.x * 64) {
+        const uint32_t tid = dp_list[li];
+        const fsv_wtask t = tasks[tid];
+        const fsv_wres r0 = res[tid];
+        fsv_wpath *P = paths + tid;
+        const int n = t.x_len, k = t.k, band = 2 * k + 1;
+        const int end = r0.end_site, err = r0.err;
+        WideCodeSink sink{slot, (uint32_t)lane64, band};
+        fsv_wres r;
+        bpm_run_wide(store, t, r, sink, k_cap);
+        if (r.err != err || r.end_site != end) { P->state = 0; continue; }   // cannot happen: the same DP as K5
+        for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
+        int cur = err, ci = n - 1, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
+        uint32_t acc = 0;
+        bool fits = true;
+        while (ci >= 0 && cur != 0) {
+            const uint32_t *c = slot + (size_t)ci * 2 * FSV_WL * 64 + lane64;
+            const int lm = row >> 5, bt = row & 31;
+            const uint32_t code = ((c[(size_t)lm * 64] >> bt) & 1u) | (((c[(size_t)(FSV_WL + lm) * 64] >> bt) & 1u) << 1);
+            if (plen >= 28 * 16 - 1) { fits = false; break; }        // the path buffer holds 448 ops; such a path is dropped below anyway
+            acc |= code << ((plen & 15) << 1);
+            if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
+            plen++;
+            cur -= (int)(code != 0u);
+            start -= (int)(code != 3u);
+            row += (int)(code == 3u) - (int)(code == 2u);
+            ci -= (int)(code != 2u);
+            dir = (int)code;
+        }
+        if (plen & 15) s_ops[plen >> 4][lane64] = acc;
+        if (!fits) { P->state = 0; continue; }
+        path_finish(store, t, P, s_ops, lane64, ci + 1, dir, plen, start, end, err);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_consensus

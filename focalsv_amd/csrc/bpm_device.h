@@ -35,11 +35,11 @@ __device__ __forceinline__ uint32_t bpm_ywin_base(const uint32_t *__restrict__ s
 }
 
 // determine_overlap_region (Correct.cpp:203-250): false = window geometrically impossible
-__device__ __forceinline__ bool bpm_window_geometry(const fsv_wtask &t, fsv_wres &r)
+__device__ __forceinline__ bool bpm_window_geometry(const fsv_wtask &t, fsv_wres &r, int k_cap = FSV_K_MAX)
 {
     const int n = t.x_len, k = t.k, wlen = n + 2 * k;
     r.end_site = -1; r.err = -1; r.y_beg = -1; r.extra_begin = -1; r.extra_end = -1;
-    if (t.y_start < 0 || t.y_len <= t.y_start || t.y_len - t.y_start + 2 * k + FSV_K_MAX < wlen) return false;
+    if (t.y_start < 0 || t.y_len <= t.y_start || t.y_len - t.y_start + 2 * k + k_cap < wlen) return false;
     int ys = t.y_start - k, olen = min(wlen, t.y_len - ys);
     r.extra_end = (int16_t)(wlen - olen);
     r.extra_begin = 0;
@@ -285,5 +285,124 @@ __device__ __forceinline__ void bpm_run32(const uint32_t *__restrict__ store, co
     BpmState s; s.eq0 = s.eq1 = s.eq2 = s.eq3 = 0; s.vp = vp; s.vn = vn;
     int best;
     r.end_site = bpm_pick_end(s, err, n, k, best);
+    r.err = best;
+}
+
+// ---- wide bands: k <= 95 (191 rows) in six 32-bit limbs ----------------------------------------------------------------
+// For reads whose windows differ by more than 8 % (BASELINE configs[4], ONT-profile reads: the reference hands those to
+// Flye; its own BPM stops at 63 rows).  The same recurrence, end-site rule and early exit on a 192-bit word -- restated on
+// 256 bits in oracle/bpm.c (orc_bpm_wide), which is checked against a plain banded DP and against the 64-bit functions where
+// both apply.  Limb l holds band rows 32 l .. 32 l + 31.
+#define FSV_WL 6
+#define FSV_K_WIDE 95
+
+struct WideNoSink {
+    __device__ __forceinline__ void operator()(int, const uint32_t *, const uint32_t *, const uint32_t *) {}
+};
+
+// the end-site scan of bpm_pick_end on limbs
+__device__ __forceinline__ int bpm_pick_end_wide(const uint32_t *vp, const uint32_t *vn, int err, int n, int k, int &best_out)
+{
+    int best = -1, site = -1, e = err, ungapped = -1;
+    if (e <= k) { best = e; site = n - 1; }
+    for (int i = 0; i < 2 * k;) {
+        e += (int)((vp[i >> 5] >> (i & 31)) & 1u);
+        e -= (int)((vn[i >> 5] >> (i & 31)) & 1u);
+        ++i;
+        if (e <= k && (best < 0 || e <= best)) { best = e; site = n - 1 + i; }
+        if (i == k) ungapped = e;
+    }
+    if (best >= 0 && k > 0 && ungapped == best) site = n - 1 + k;
+    best_out = best;
+    return best < 0 ? -1 : site;
+}
+
+// Sink sees every column: (column, D0, HP of the column, VP after it), six limbs each.
+template <class Sink>
+__device__ __forceinline__ void bpm_run_wide(const uint32_t *__restrict__ store, const fsv_wtask &t, fsv_wres &r, Sink &sink, int k_cap)
+{
+    if (!bpm_window_geometry(t, r, k_cap)) return;
+    const int n = t.x_len, k = t.k;
+    const int win0 = t.y_start - k;
+    // y planes over the 2k+17 rows of a 16-column block: seven limbs (bit b = row win0 + blk + b)
+    uint32_t ylo[FSV_WL + 1], yhi[FSV_WL + 1], yv[FSV_WL + 1], vp[FSV_WL], vn[FSV_WL], bandm[FSV_WL];
+#pragma unroll
+    for (int l = 0; l <= FSV_WL; l++) { ylo[l] = yhi[l] = yv[l] = 0u; }
+#pragma unroll
+    for (int l = 0; l < FSV_WL; l++) {
+        vp[l] = vn[l] = 0u;
+        const int lo = 32 * l, nb = 2 * k + 1 - lo;     // band rows in this limb
+        bandm[l] = nb >= 32 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
+    }
+    // rows 0 .. 2k, 16 at a time: chunk c covers rows 16c .. 16c+15 = half of limb c >> 1
+#pragma unroll
+    for (int c = 0; c < 2 * FSV_WL; c++) {
+        const int b16 = 16 * c;
+        if (b16 <= 2 * k) {
+            const Bases16 y = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + b16);
+            const uint32_t m = (1u << min(16, 2 * k + 1 - b16)) - 1u;
+            const int sh = (c & 1) * 16;
+            ylo[c >> 1] |= (compress_even16(y.bits) & m) << sh;
+            yhi[c >> 1] |= (compress_even16(y.bits >> 1) & m) << sh;
+            yv[c >> 1] |= (y.valid & m) << sh;
+        }
+    }
+    int err = 0;
+    uint32_t xb = fetch16_x(store, t.x_word, t.x_start);
+    Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1);
+    const int top = 2 * k + 1, tl = top >> 5, ts = top & 31;     // where a block's 16 new rows enter the planes
+    for (int blk = 0; blk < n; blk += 16) {
+        const uint32_t xn = fetch16_x(store, t.x_word, t.x_start + blk + 16);
+        const Bases16 yn = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1 + blk + 16);
+        {
+            const uint64_t lo = (uint64_t)compress_even16(yb.bits) << ts, hi = (uint64_t)compress_even16(yb.bits >> 1) << ts,
+                           v = (uint64_t)(yb.valid & 0xffffu) << ts;
+#pragma unroll
+            for (int l = 0; l <= FSV_WL; l++) {
+                if (l == tl) { ylo[l] |= (uint32_t)lo; yhi[l] |= (uint32_t)hi; yv[l] |= (uint32_t)v; }
+                if (l == tl + 1) { ylo[l] |= (uint32_t)(lo >> 32); yhi[l] |= (uint32_t)(hi >> 32); yv[l] |= (uint32_t)(v >> 32); }
+            }
+        }
+        const int lim = min(16, n - blk);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j < lim) {
+                const uint32_t c0 = (uint32_t)(((int32_t)(xb << (31 - 2 * j))) >> 31), c1 = (uint32_t)(((int32_t)(xb << (30 - 2 * j))) >> 31);
+                uint32_t d0[FSV_WL], hp[FSV_WL];
+                uint32_t carry = 0u;
+#pragma unroll
+                for (int l = 0; l < FSV_WL; l++) {
+                    // the column's match mask: the planes shifted down by j (bits from the limb above fill in)
+                    const uint32_t pl = j ? (ylo[l] >> j | ylo[l + 1] << (32 - j)) : ylo[l], ph = j ? (yhi[l] >> j | yhi[l + 1] << (32 - j)) : yhi[l],
+                                   pv = j ? (yv[l] >> j | yv[l + 1] << (32 - j)) : yv[l];
+                    const uint32_t eq = ~(pl ^ c0) & ~(ph ^ c1) & pv & bandm[l];
+                    const uint32_t x = eq | vn[l];
+                    const uint32_t a = x & vp[l];
+                    const uint32_t s1 = vp[l] + a, s2 = s1 + carry;
+                    carry = (uint32_t)(s1 < a) | (uint32_t)(s2 < s1);
+                    d0[l] = (s2 ^ vp[l]) | x;
+                    hp[l] = vn[l] | ~(vp[l] | d0[l]);
+                }
+#pragma unroll
+                for (int l = 0; l < FSV_WL; l++) {
+                    const uint32_t hn = vp[l] & d0[l];
+                    const uint32_t sh = d0[l] >> 1 | (l + 1 < FSV_WL ? d0[l + 1] << 31 : 0u);
+                    vn[l] = sh & hp[l];
+                    vp[l] = hn | ~(sh | hp[l]);
+                }
+                err += (int)(~d0[0] & 1u);
+                sink(blk + j, d0, hp, vp);
+            }
+        }
+        if (err - 2 * k > k) return;     // as bpm_run32: once per block, same outcome
+#pragma unroll
+        for (int l = 0; l <= FSV_WL; l++) {   // slide the planes 16 rows down
+            const uint32_t up_lo = l < FSV_WL ? ylo[l + 1] : 0u, up_hi = l < FSV_WL ? yhi[l + 1] : 0u, up_v = l < FSV_WL ? yv[l + 1] : 0u;
+            ylo[l] = ylo[l] >> 16 | up_lo << 16; yhi[l] = yhi[l] >> 16 | up_hi << 16; yv[l] = yv[l] >> 16 | up_v << 16;
+        }
+        xb = xn; yb = yn;
+    }
+    int best;
+    r.end_site = bpm_pick_end_wide(vp, vn, err, n, k, best);
     r.err = best;
 }

@@ -57,5 +57,6 @@ __device__ __forceinline__ uint32_t fsv_base_at(const uint32_t *__restrict__ sto
 static inline unsigned fsv_grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 // K5 with the task count left on the device (k5_bpm.hip): n_tasks sizes the grid, *n_dev is the count the kernel uses
+// k_cap: the largest threshold of the batch's error model (31 = hifiasm's; above it every window goes through the wide-band kernel)
 int fsv_bpm_windows_dev_n(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wtask *tasks_dev, uint32_t n_tasks, const uint32_t *n_dev,
-                          fsv_wres *res_dev);
+                          fsv_wres *res_dev, int k_cap);

@@ -15,6 +15,7 @@
 // This is integer-ALU bound: ~30 VALU ops per DP column per lane in the 32-bit form (bpm_run32: bands up to 31 rows,
 // every first-pass window), ~50 in the 64-bit one.
 #include "bpm_device.h"
+#include <algorithm>
 
 namespace {
 
@@ -56,21 +57,41 @@ __global__ __launch_bounds__(256) void k5_bpm_kernel(const uint32_t *__restrict_
     res[tid] = r;
 }
 
+// K5 for wide bands (k up to FSV_K_WIDE = 95, 191 rows in six 32-bit limbs): every window of a batch whose error model allows
+// thresholds above 31 (fsv_asm_params.k_cap > 31: the ONT profile) goes through this kernel, whatever its own k
+__global__ __launch_bounds__(256) void k5_bpm_wide_kernel(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
+                                                          uint32_t n_tasks, fsv_wres *__restrict__ res, const uint32_t *__restrict__ n_dev, int k_cap)
+{
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n_tasks = *n_dev;
+    if (tid >= n_tasks) return;
+    const fsv_wtask t = tasks[tid];
+    fsv_wres r;
+    WideNoSink none;
+    bpm_run_wide(store, t, r, none, k_cap);
+    res[tid] = r;
+}
+
 } // namespace
 
 extern "C" int fsv_bpm_windows_dev(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wtask *tasks_dev, uint32_t n_tasks,
                                    fsv_wres *res_dev)
 {
-    return fsv_bpm_windows_dev_n(ctx, store_dev, tasks_dev, n_tasks, nullptr, res_dev);
+    return fsv_bpm_windows_dev_n(ctx, store_dev, tasks_dev, n_tasks, nullptr, res_dev, FSV_K_MAX);
 }
 
 // n_dev != NULL: n_tasks is only the bound the grid is sized for; the kernel reads the actual count from the device
 int fsv_bpm_windows_dev_n(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wtask *tasks_dev, uint32_t n_tasks, const uint32_t *n_dev,
-                          fsv_wres *res_dev)
+                          fsv_wres *res_dev, int k_cap)
 {
     if (!ctx || !store_dev || (!tasks_dev && n_tasks) || (!res_dev && n_tasks)) return FSV_EINVAL;
     if (n_tasks == 0) return FSV_OK;
+    if (k_cap > FSV_K_WIDE) return fsv_fail(ctx, FSV_EUNSUP, "window thresholds above 95 (bands above 191 rows) are not built");
     FSV_HIP(ctx, hipSetDevice(ctx->device));
+    if (k_cap > FSV_K_MAX)
+        hipLaunchKernelGGL(k5_bpm_wide_kernel, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store_dev, tasks_dev,
+                           n_tasks, res_dev, n_dev, k_cap);
+    else
     hipLaunchKernelGGL(k5_bpm_kernel, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store_dev, tasks_dev,
                        n_tasks, res_dev, n_dev);
     FSV_HIP(ctx, hipGetLastError());
@@ -81,8 +102,12 @@ extern "C" int fsv_bpm_windows(fsv_ctx *ctx, const uint32_t *store, size_t store
                                uint32_t n_tasks, fsv_wres *res)
 {
     if (!ctx || !store || (!tasks && n_tasks) || (!res && n_tasks)) return FSV_EINVAL;
-    for (uint32_t i = 0; i < n_tasks; i++)
-        if (tasks[i].k > FSV_K_MAX || tasks[i].x_len == 0 || tasks[i].x_len > FSV_WINDOW) return fsv_fail(ctx, FSV_EINVAL, "task k/x_len out of range");
+    int kmax = 0;
+    for (uint32_t i = 0; i < n_tasks; i++) {
+        if (tasks[i].k > FSV_K_WIDE || tasks[i].x_len == 0 || tasks[i].x_len > FSV_WINDOW) return fsv_fail(ctx, FSV_EINVAL, "task k/x_len out of range");
+        kmax = std::max<int>(kmax, tasks[i].k);
+    }
+    const int k_cap = kmax > FSV_K_MAX ? kmax : FSV_K_MAX;     // a threshold above 31 anywhere: the whole list through the wide kernel
     void *d_store = nullptr, *d_tasks = nullptr, *d_res = nullptr;
     int rc = FSV_OK;
     FSV_HIP(ctx, hipSetDevice(ctx->device));
@@ -92,7 +117,7 @@ extern "C" int fsv_bpm_windows(fsv_ctx *ctx, const uint32_t *store, size_t store
     }
     if (rc == FSV_OK) rc = fsv_h2d(ctx, d_store, store, store_words * 4);
     if (rc == FSV_OK) rc = fsv_h2d(ctx, d_tasks, tasks, (size_t)n_tasks * sizeof(fsv_wtask));
-    if (rc == FSV_OK) rc = fsv_bpm_windows_dev(ctx, (const uint32_t *)d_store, (const fsv_wtask *)d_tasks, n_tasks, (fsv_wres *)d_res);
+    if (rc == FSV_OK) rc = fsv_bpm_windows_dev_n(ctx, (const uint32_t *)d_store, (const fsv_wtask *)d_tasks, n_tasks, nullptr, (fsv_wres *)d_res, k_cap);
     if (rc == FSV_OK) rc = fsv_d2h(ctx, res, d_res, (size_t)n_tasks * sizeof(fsv_wres));
     (void)hipFree(d_store); (void)hipFree(d_tasks); (void)hipFree(d_res);
     return rc;

@@ -48,6 +48,7 @@ extern "C" {
 #define FSV_WINDOW          375 /* hifiasm WINDOW, Hash_Table.h:9 */
 #define FSV_K_FULL           15 /* hifiasm THRESHOLD, Hash_Table.h:13 */
 #define FSV_K_MAX            31 /* hifiasm THRESHOLD_MAX_SIZE, Hash_Table.h:17 */
+#define FSV_K_WIDE           95 /* widest threshold of the wide-band kernels (191 rows in six 32-bit limbs): ONT-profile reads */
 
 typedef struct fsv_ctx fsv_ctx;
 
@@ -93,7 +94,7 @@ typedef struct fsv_wtask {
     int32_t  y_start;  /* chain-predicted partner of x_start in y's strand coordinates (before the -k pad) */
     int32_t  y_len;    /* length of read y */
     uint16_t x_len;    /* 1..FSV_WINDOW */
-    uint8_t  k;        /* error threshold, band = 2k+1, <= FSV_K_MAX */
+    uint8_t  k;        /* error threshold, band = 2k+1, <= FSV_K_MAX (hifiasm) or <= FSV_K_WIDE (wide-band kernels) */
     uint8_t  y_rev;    /* 1: y is read on its reverse-complement strand */
     uint32_t ovl;      /* caller tag: overlap id */
     uint32_t win;      /* caller tag: window index inside the overlap */
@@ -152,8 +153,16 @@ typedef struct fsv_asm_params {
     int32_t bw_ec;            /* chain indel budget per mille in correction rounds, 20 (hifiasm 0.02) */
     int32_t bw_final;         /* ... in the final overlap pass, 0 = co-linear anchors only */
     int32_t min_contig_reads; /* chains of fewer reads are dropped, as hifiasm's asg_cut_tip(max_short_tip = 3) does (Overlaps.cpp:4666): 4 */
+    /* error model: hifiasm's constants for HiFi reads; fsv_asm_ont_params() raises them for ONT-profile reads (10 % error), where the
+     * reference runs Flye / Shasta instead (run_assembly.py:74-100) */
+    int32_t win_rate_pm;      /* window threshold = x_len x this / 1000: 40 (max_ov_diff_ec 0.04: k = 15 = FSV_K_FULL for a full window) */
+    int32_t k_cap;            /* largest threshold the rescue pass doubles to: 31 = FSV_K_MAX (THRESHOLD_MAX_SIZE); at most FSV_K_WIDE */
+    int32_t accept_err_pm;    /* an overlap is used when its error rate is at most this / 1000: 30 (Correct.cpp:725) */
 } fsv_asm_params;
 void fsv_asm_default_params(fsv_asm_params *p);
+/* ONT-profile reads (BASELINE configs[4]: ~10 % error): k = 15, w = 10 without homopolymer compression, chain indel budget 0.15 / 0.05,
+ * windows up to 25 % apart (k = 93: wide-band K5 / K6), overlaps up to 30 % error.  Parity unpinned: the reference has Flye here. */
+void fsv_asm_ont_params(fsv_asm_params *p);
 
 typedef struct fsv_mz {       /* ha_mz1_t, htab.h:8-13 */
     uint64_t hash;

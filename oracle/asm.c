@@ -48,26 +48,36 @@ static void revcomp_inplace(char *s, int n)
 /* base of read y at strand coordinate p */
 static inline char ybase(const char *y, int ylen, int rev, int p) { return rev ? comp(y[ylen - 1 - p]) : y[p]; }
 
-int orc_thr_for_len(int x_len)
+int orc_thr_for_len_p(const orc_asm_params *P, int x_len)
 {
     /* verify_window: threshold = x_len * max_ov_diff_ec (0.04), Adjust_Threshold (Correct.h:39) */
     int t;
-    if (x_len == ORC_WINDOW) return ORC_K_FULL;
-    t = (int)(x_len * 0.04);
+    const double rate = P->win_rate_pm / 1000.0;      /* 40 / 1000.0 is the double 0.04 */
+    if (x_len == ORC_WINDOW) return P->win_rate_pm == 40 ? ORC_K_FULL : (int)(ORC_WINDOW * rate);
+    t = (int)(x_len * rate);
     if (t == 0 && x_len >= 4) t = 1;
     return t;
 }
 
-int orc_double_thr(int pre, int x_len)
+int orc_double_thr_p(const orc_asm_params *P, int pre, int x_len)
 {
     /* double_error_threshold, Correct.cpp:658-676 */
     int t;
     if (pre == 0 && x_len >= 4) pre = 1;
     t = pre * 2;
-    if (x_len >= 300 && t < ORC_K_MAX) t = ORC_K_MAX;
-    if (t > ORC_K_MAX) t = ORC_K_MAX;
+    if (x_len >= 300 && t < P->k_cap) t = P->k_cap;
+    if (t > P->k_cap) t = P->k_cap;
     return t;
 }
+
+static const orc_asm_params *hifi_params(void)
+{
+    static orc_asm_params P; static int init = 0;
+    if (!init) { orc_asm_default_params(&P); init = 1; }
+    return &P;
+}
+int orc_thr_for_len(int x_len) { return orc_thr_for_len_p(hifi_params(), x_len); }
+int orc_double_thr(int pre, int x_len) { return orc_double_thr_p(hifi_params(), pre, x_len); }
 
 /* ---------------------------------------------------------------- S2: unique-in-read minimizers sorted by hash */
 static int mz_cmp(const void *a, const void *b)
@@ -213,11 +223,11 @@ static int32_t diag_at(const int32_t *cq, const int32_t *ct, int n, int32_t x)
 
 /* ---------------------------------------------------------------- S4: one window */
 /* determine_overlap_region + fill_subregion + K5.  Returns 1 when the window is geometrically valid. */
-static int window_verify(const char *x, const char *y, int ylen, int rev, orc_win *w, char *ybuf)
+static int window_verify(const char *x, const char *y, int ylen, int rev, orc_win *w, char *ybuf, int k_cap)
 {
     int n = w->x_len, k = w->k, wlen = n + 2 * k, j, win0, err;
     w->end_site = -1; w->err = -1; w->y_beg = -1; w->extra_begin = -1; w->extra_end = -1;
-    if (w->y_start < 0 || ylen <= w->y_start || ylen - w->y_start + 2 * k + ORC_K_MAX < wlen) return 0;
+    if (w->y_start < 0 || ylen <= w->y_start || ylen - w->y_start + 2 * k + k_cap < wlen) return 0;
     win0 = w->y_start - k;
     {
         int ys = win0, olen = wlen < ylen - ys ? wlen : ylen - ys;
@@ -226,7 +236,7 @@ static int window_verify(const char *x, const char *y, int ylen, int rev, orc_wi
         w->y_beg = ys;
     }
     for (j = 0; j < wlen; j++) { int p = win0 + j; ybuf[j] = (p < 0 || p >= ylen) ? 'N' : ybase(y, ylen, rev, p); }
-    w->end_site = orc_bpm(ybuf, wlen, x + w->x_start, n, k, &err);
+    w->end_site = k <= ORC_K_MAX ? orc_bpm(ybuf, wlen, x + w->x_start, n, k, &err) : orc_bpm_wide(ybuf, wlen, x + w->x_start, n, k, &err);
     w->err = err;
     if (err < 0) w->end_site = -1;
     return 1;
@@ -249,11 +259,19 @@ static void window_path(const char *x, const char *y, int ylen, int rev, orc_win
         plen = n;
     } else if (!orc_try_cigar(ybuf, x + w->x_start, n, end, err, tmp, &start, &plen)) {
         int e2;
-        end = orc_bpm_path(ybuf, wlen, x + w->x_start, n, k, &e2, &start, &plen, tmp, cols);
+        end = k <= ORC_K_MAX ? orc_bpm_path(ybuf, wlen, x + w->x_start, n, k, &e2, &start, &plen, tmp, cols)
+                             : orc_bpm_path_wide(ybuf, wlen, x + w->x_start, n, k, &e2, &start, &plen, tmp, cols);
         err = e2;
     }
     if (err > 0) nrun = orc_generate_cigar(tmp, plen, n, x + w->x_start, ybuf, &start, &end, &err, rl, ro);
     else { nrun = 1; rl[0] = n; ro[0] = 0; }
+    pl = 0;
+    for (i = 0; i < nrun; i++) pl += rl[i];
+    if (pl > ORC_PATH_REC) {   /* the 128-byte path record of the HIP path holds 416 ops (x_len + k <= 406 for hifiasm's thresholds: never
+                                  reached); a longer path -- a wide-band window with more than 41 inserted bases -- leaves the window unused */
+        w->path_len = 0; w->err = -1;
+        return;
+    }
     pl = 0;
     for (i = 0; i < nrun; i++) for (j = 0; j < rl[i]; j++) w->path[pl++] = ro[i];
     w->path_len = (int16_t)pl;
@@ -384,13 +402,13 @@ static void free_sketch(const readset *R, orc_mz **uq, int *nuq)
 
 /* Build + verify + rescue + accept + path every window of every overlap of the set.
  * Returns the window array (owned by caller); ov[].first_win/n_win index into it. */
-static orc_win *align_overlaps(const readset *R, orc_ovl *ov, int n_ov, const int32_t *cq, const int32_t *ct, int *n_win_out)
+static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ovl *ov, int n_ov, const int32_t *cq, const int32_t *ct, int *n_win_out)
 {
     int i, j, total = 0, wi;
     orc_win *W;
-    char ybuf[ORC_WINDOW + 2 * ORC_K_MAX + 8];
-    uint64_t cols[5 * (ORC_WINDOW + 4)];
-    uint8_t tmp[2 * ORC_WINDOW + 4 * ORC_K_MAX + 16];
+    char ybuf[ORC_WINDOW + 2 * ORC_K_WIDE + 8];
+    static __thread uint64_t cols[5 * 4 * (ORC_WINDOW + 4)];
+    uint8_t tmp[2 * ORC_WINDOW + 4 * ORC_K_WIDE + 16];
     int rl[2 * ORC_WINDOW + 64];
     uint8_t ro[2 * ORC_WINDOW + 64];
     for (i = 0; i < n_ov; i++) {
@@ -411,9 +429,9 @@ static orc_win *align_overlaps(const readset *R, orc_ovl *ov, int n_ov, const in
             w->ovl = (uint32_t)i; w->win = (uint32_t)j;
             w->x_start = gs > o->x_s ? gs : o->x_s;
             w->x_len = (int16_t)((ge < o->x_e ? ge : o->x_e) - w->x_start + 1);
-            w->k = (uint8_t)orc_thr_for_len(w->x_len);
+            w->k = (uint8_t)orc_thr_for_len_p(P, w->x_len);
             w->y_start = w->x_start + diag_at(cq + o->chain_off, ct + o->chain_off, o->n_chain, w->x_start);
-            window_verify(x, y, ylen, o->rev, w, ybuf);
+            window_verify(x, y, ylen, o->rev, w, ybuf, P->k_cap);
             if (w->err >= 0) o->align_len += w->x_len;
         }
         /* rescue, right-extension pass (Correct.cpp:2655-2744) */
@@ -425,9 +443,9 @@ static orc_win *align_overlaps(const readset *R, orc_ovl *ov, int n_ov, const in
             for (k2 = j + 1; k2 < o->n_win && W[o->first_win + k2].err < 0; k2++) {
                 orc_win *u = &W[o->first_win + k2], trial = *u;
                 if (next >= ylen) break;
-                trial.k = (uint8_t)orc_double_thr(u->k, u->x_len);
+                trial.k = (uint8_t)orc_double_thr_p(P, u->k, u->x_len);
                 trial.y_start = next;
-                if (!window_verify(x, y, ylen, o->rev, &trial, ybuf)) break;
+                if (!window_verify(x, y, ylen, o->rev, &trial, ybuf, P->k_cap)) break;
                 if ((trial.x_len + 2 * trial.k - trial.extra_begin - trial.extra_end) + trial.k < trial.x_len) break;
                 if (trial.err < 0) break;
                 trial.rescued = 1;
@@ -444,7 +462,7 @@ static orc_win *align_overlaps(const readset *R, orc_ovl *ov, int n_ov, const in
             terr += w->err >= 0 ? w->err : w->x_len;
         }
         o->err_sum = (int32_t)terr;
-        if ((int64_t)(o->x_e - o->x_s + 1) * 9 <= (int64_t)o->align_len * 10 && terr * 100 <= tlen * 3) o->is_match = 1;
+        if ((int64_t)(o->x_e - o->x_s + 1) * 9 <= (int64_t)o->align_len * 10 && terr * 1000 <= tlen * P->accept_err_pm) o->is_match = 1;
         if (!o->is_match) continue;
         for (j = 0; j < o->n_win; j++) {
             orc_win *w = &W[o->first_win + j];
@@ -601,7 +619,7 @@ static void correction_round(readset *R, const orc_asm_params *P, int do_rc, orc
     int *nlen = (int *)malloc(sizeof(int) * (size_t)R->n);
     sketch_set(R, P, &uq, &nuq);
     collect_overlaps(R, P, P->bw_ec, uq, nuq, &ov, &cq, &ct, &n_ov);
-    W = align_overlaps(R, ov, n_ov, cq, ct, &n_win);
+    W = align_overlaps(R, P, ov, n_ov, cq, ct, &n_win);
     if (P->diploid) { /* unphased read set: overlaps between the two haplotypes leave the consensus (is_match = 2 as in hifiasm) */
         uint8_t *trans = (uint8_t *)calloc((size_t)n_ov + 1, 1);
         int i;
@@ -631,6 +649,7 @@ void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->diploid = 0;
+    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30;
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),

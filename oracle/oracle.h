@@ -14,7 +14,9 @@ typedef struct {
 #define ORC_WINDOW 375
 #define ORC_K_FULL 15
 #define ORC_K_MAX  31
-#define ORC_PATH_CAP 448
+#define ORC_PATH_CAP 512
+#define ORC_PATH_REC 416   /* ops a path record of the HIP path holds (FSV_PATH_CAP) */
+#define ORC_K_WIDE 127   /* widest band of the 256-bit restatement (oracle/bpm.c); the HIP path holds k <= 95 */
 
 typedef struct {
     int32_t k, w, hpc;        /* minimizer scheme: 51, 51, 1 (hifiasm defaults, CommandLines.cpp:109-166) */
@@ -28,6 +30,10 @@ typedef struct {
                                  budget lets into the chain and shifts the exact-overlap interval by one) */
     int32_t min_contig_reads; /* chains of fewer reads are dropped (asg_cut_tip with max_short_tip = 3, Overlaps.cpp:4666): 4 */
     int32_t diploid;          /* 1: unphased read set -- overlaps that carry the other allele at a heterozygous column are kept out of the consensus */
+    /* error model (hifiasm: fixed for HiFi reads; raised for the ONT profile of BASELINE configs[4], where the reference has Flye) */
+    int32_t win_rate_pm;      /* window threshold = x_len x this / 1000: 40 (max_ov_diff_ec 0.04 -> k = 15 for a full window) */
+    int32_t k_cap;            /* largest threshold the rescue pass doubles to: 31 (THRESHOLD_MAX_SIZE, Hash_Table.h:9-22) */
+    int32_t accept_err_pm;    /* an overlap is used when its error rate is at most this / 1000: 30 (Correct.cpp:725) */
 } orc_asm_params;
 
 typedef struct {
@@ -54,6 +60,8 @@ typedef struct {
 
 int orc_thr_for_len(int x_len);
 int orc_double_thr(int pre, int x_len);
+int orc_thr_for_len_p(const orc_asm_params *P, int x_len);
+int orc_double_thr_p(const orc_asm_params *P, int pre, int x_len);
 int orc_unique_sorted(orc_mz *mz, int n);
 int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, int lent, const orc_asm_params *P,
                    int bw_per_mille, orc_ovl *o, int32_t *chain_qe, int32_t *chain_te, int chain_cap);
@@ -95,6 +103,9 @@ int orc_align_contig_multi(const char *contig, int lenq, const char *ref, int le
                            uint32_t *cigar, int cigar_cap, int max_rec);
 int orc_sketch(const char *s, int len, int w, int k, int hpc, orc_mz *out, int cap);
 int orc_bpm(const char *y, int m, const char *x, int n, int k, int *err);
+int orc_bpm_wide(const char *y, int m, const char *x, int n, int k, int *err);
+int orc_bpm_path_wide(const char *y, int m, const char *x, int n, int k, int *err, int *start_site, int *path_len, uint8_t *path, uint64_t *cols);
+int orc_banded_dp_plain(const char *y, int m, const char *x, int n, int k, uint8_t *ends);
 int orc_bpm_path(const char *y, int m, const char *x, int n, int k, int *err, int *start_site, int *path_len,
                  uint8_t *path, uint64_t *cols);
 int orc_try_cigar(const char *y, const char *x, int n, int end_site, int error, uint8_t *path, int *start_site, int *path_len);

@@ -20,18 +20,34 @@ def lib():
 
 
 def bpm(x: str, y: str, k: int):
+    """K5: (end site, err); bands above 63 rows (k > 31) through the 256-bit restatement"""
     err = C.c_int(0)
-    site = lib().orc_bpm(y.encode(), len(y), x.encode(), len(x), k, C.byref(err))
+    fn = lib().orc_bpm if k <= 31 else lib().orc_bpm_wide
+    site = fn(y.encode(), len(y), x.encode(), len(x), k, C.byref(err))
     return site, err.value
 
 
-def bpm_path(x: str, y: str, k: int):
+def bpm_wide(x: str, y: str, k: int):
+    err = C.c_int(0)
+    site = lib().orc_bpm_wide(y.encode(), len(y), x.encode(), len(x), k, C.byref(err))
+    return site, err.value
+
+
+def banded_dp_plain(x: str, y: str, k: int):
+    """plain O(n x band) DP with the semantics of the banded BPM -> (best distance, [end offsets 0..2k that attain it])"""
+    ends = (C.c_uint8 * (2 * k + 1))()
+    best = lib().orc_banded_dp_plain(y.encode(), len(y), x.encode(), len(x), k, ends)
+    return best, [i for i in range(2 * k + 1) if ends[i]]
+
+
+def bpm_path(x: str, y: str, k: int, wide: bool = False):
     """-> (end_site, err, start_site, path_digits) ; path stored end-to-start like the reference"""
     n = len(x)
     err, start, plen = C.c_int(0), C.c_int(-1), C.c_int(0)
     path = (C.c_uint8 * (n + len(y) + 16))()
-    cols = (C.c_uint64 * (5 * (n + 2)))()
-    site = lib().orc_bpm_path(y.encode(), len(y), x.encode(), n, k, C.byref(err), C.byref(start), C.byref(plen), path, cols)
+    cols = (C.c_uint64 * (20 * (n + 2)))()
+    fn = lib().orc_bpm_path if (k <= 31 and not wide) else lib().orc_bpm_path_wide
+    site = fn(y.encode(), len(y), x.encode(), n, k, C.byref(err), C.byref(start), C.byref(plen), path, cols)
     if err.value < 0:
         return site, -1, None, None
     return site, err.value, start.value, bytes(path[: plen.value])
@@ -72,7 +88,8 @@ def sketch(seq: str, w=51, k=51, hpc=1):
 
 
 class AsmParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "diploid")]
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "diploid",
+                                         "win_rate_pm", "k_cap", "accept_err_pm")]
 
 
 def default_params():

@@ -116,3 +116,23 @@ def test_k5_exact_diagonal_shortcut_in_repeats(ctx):
     for c, r in zip(cases, res):
         site, err = O.bpm(c["x"], c["y"], c["k"])
         assert (int(r["err"]), int(r["end_site"]) if err >= 0 else -1) == (err, site if err >= 0 else -1), c
+
+
+def test_k5_wide_bands_vs_oracle(ctx):
+    """bands above 63 rows (k up to 95, BASELINE configs[4]: ONT-profile windows ~20 % apart): the wide-band kernel against the
+    256-bit restatement (itself checked against a plain DP, tests/test_oracle_bpm.py); a list that holds one wide task runs
+    entirely through the wide kernel, so narrow thresholds are compared there too"""
+    from tests.test_oracle_bpm import _noisy_cases
+    cases = [c for c in _noisy_cases(21, 6000, [15, 31, 40, 63, 80, 93, 95]) if usable(c)]
+    cases[0]["k"] = min(cases[0]["k"], 31)
+    words, tasks = tasks_from_cases(cases)
+    res = ctx.bpm_windows(words, tasks)
+    n_hit = n_wide = 0
+    for c, r in zip(cases, res):
+        site, err = O.bpm(c["x"], c["y"], c["k"])
+        assert int(r["err"]) == err, c
+        if err >= 0:
+            n_hit += 1
+            n_wide += c["k"] > 31
+            assert int(r["end_site"]) == site, c
+    assert n_hit > 2000 and n_wide > 1000
