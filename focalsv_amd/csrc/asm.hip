@@ -163,7 +163,7 @@ int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len,
 // sketch + per-read index + chaining on the current store; fills ws.ovl (and ws.tasks when emit_tasks).  Nothing here waits
 // for the GPU: launches are sized from the read lengths the host already has, counts stay in the round's counter slot `ct`.
 int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, const uint32_t *store, const fsv_asm_params &P, int bw,
-                  bool emit_tasks, uint32_t task_cap, uint32_t *ct, bool short_reads, const uint32_t *only_changed = nullptr)
+                  bool emit_tasks, uint32_t task_cap, uint32_t *ct, bool short_reads, bool wide_anchors, const uint32_t *only_changed = nullptr)
 {
     Span ts(ctx, W.kt, ST_SKETCH);
     TRY(ensure(ctx, W.mz, (size_t)G.mz_off[B.n_reads] * sizeof(fsv_mz)));
@@ -223,7 +223,7 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     // LDS per pair: the anchor arrays for FSV_AMAX entries -- 12 B each in the compact layout (every read of the batch below
     // 65 536 bases), so the tile no longer has to be cut to the batch's longest list to keep several pairs per CU
     A.upair_tab = (const uint4 *)W.upair_tab.p; A.pair_list = nullptr; A.n_list_dev = nullptr;
-    A.amax = FSV_AMAX;
+    A.amax = wide_anchors ? FSV_AMAX_WIDE : FSV_AMAX;
     // algorithmic bytes of the launch are filled in when the batch ends (they need the counts this launch leaves on the device)
     W.chain_rec.push_back(W.kt.begin(ctx, KN_CHAIN, 0));
     if (short_reads) hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A.amax), ctx->stream, A);
@@ -311,16 +311,18 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
     if (!p) return;
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
-    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30;
+    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1;
 }
 
 extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
 {
     if (!p) return;
     fsv_asm_default_params(p);
-    p->k = 15; p->w = 10; p->hpc = 0;           // 15-mers survive 10 % error often enough to seed (20 % of them per read); no HPC: indel errors dominate
+    p->k = 15; p->w = 15; p->hpc = 0;           // 15-mers survive 10 % error often enough to seed (20 % of them per read); no HPC: indel errors dominate
     p->bw_ec = 150; p->bw_final = 50;           // chains of noisy reads drift by several per cent between anchors
     p->win_rate_pm = 250; p->k_cap = FSV_K_WIDE; p->accept_err_pm = 300;   // two 10 % reads differ by ~20 %: k = 93 for a full window
+    p->bw_rechain = 50;                         // corrected reads keep a 1-base indel every few kb
+    p->min_contig_reads = 2;                    // reads of 10-30 kb tile a 50 kb window with three or four uncontained reads: hifiasm's tip rule (4) would drop them
 }
 
 extern "C" int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap)
@@ -520,7 +522,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         TRY(ensure(ctx, W.dp_list3, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_wide, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_xwide, wide_bands ? (size_t)task_cap * 4 : 64));
-        TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_ec, true, task_cap, ct, short_reads));
+        TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_ec, true, task_cap, ct, short_reads, wide_bands));
         W.stats.n_pairs += B.n_pairs;
         if (B.n_pairs) {
             Span tv(ctx, W.kt, ST_VERIFY);
@@ -632,7 +634,8 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             FSV_HIP(ctx, hipGetLastError());
         }
         W.cons_rec.push_back(W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_gwin * (96 + 448)));
-        hipLaunchKernelGGL(k_consensus, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
+        if (wide_bands) hipLaunchKernelGGL(k_consensus<FSV_EV_CAP_WIDE>, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
+        else hipLaunchKernelGGL(k_consensus<FSV_EV_CAP>, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);
         hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
@@ -682,7 +685,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         FSV_HIP(ctx, hipMemcpyAsync(W.ovl_prev.p, W.ovl.p, (size_t)B.n_pairs * sizeof(fsv_ovl), hipMemcpyDeviceToDevice, ctx->stream));
     }
     // reads the last round left untouched keep that round's minimizer lists (the last round does not reverse-complement)
-    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0, ctf, short_reads, P.n_rounds > 0 ? (const uint32_t *)W.changed.p : nullptr));
+    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0, ctf, short_reads, wide_bands, P.n_rounds > 0 ? (const uint32_t *)W.changed.p : nullptr));
     trace("overlaps");
     const fsv_hit *hraw = nullptr;
     std::vector<uint32_t> hit_first(B.n_sets + 1, 0);
@@ -708,7 +711,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
                                (const uint8_t *)W.exact_flag.p, (const fsv_ovl *)W.ovl_prev.p, B.n_upairs, (uint32_t *)W.inexact_list.p, n_list_dev);
             FSV_HIP(ctx, hipGetLastError());
             ChainArgs A2 = W.last_chain;
-            A2.bw = 1; A2.emit_tasks = 0; A2.pair_list = (const uint32_t *)W.inexact_list.p; A2.n_list_dev = n_list_dev;
+            A2.bw = P.bw_rechain; A2.emit_tasks = 0; A2.pair_list = (const uint32_t *)W.inexact_list.p; A2.n_list_dev = n_list_dev;
             // timed like the other k_chain launches (a profiler counts it too)
             W.kt.begin(ctx, KN_CHAIN, 0);
             if (short_reads) hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A2.amax), ctx->stream, A2);

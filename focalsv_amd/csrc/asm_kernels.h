@@ -17,12 +17,14 @@
 #include <type_traits>
 
 #define FSV_AMAX       1024  // anchors per read pair held in LDS
+#define FSV_AMAX_WIDE  4096  // ... for ONT-profile batches: k = 15 minimizers every ~8 bases, corrected reads share all of them (a 25 kb overlap: ~3 000)
 #define FSV_UQ_MAX     4096  // minimizers per read sorted in LDS
 #define FSV_PATH_CAP    416  // ops per window path: x_len (<= 375) + y-only ops (<= k <= 31)
 #define FSV_CW_STRIDE   448  // bytes reserved per corrected grid window
 #define FSV_INS_MAXLEN   12
 #define FSV_SB_MAXERR    7   // k_path_sb: distances it holds in one word per column (2 x 7 + 1 rows x 2 bits)
 #define FSV_SB_QUADS ((FSV_WINDOW + 3) / 4)
+#define FSV_EV_CAP_WIDE 2048 // ... for ONT-profile batches (wide bands): ~25 inserted-base events per overlap and window
 #define FSV_EV_CAP     256   // insertion events per grid window (HiFi at 30x: ~8; more sets the read's warning bit 8 and drops the excess)
 
 // fsv_wpath (include/focalsv_hip.h): 128 bytes per window task; state 2 = queued for the DP kernel (internal)
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     dp_t *const s_f = (dp_t *)s_rest, *const s_ind = s_f + AMAX;
     uint16_t *const s_aux = (uint16_t *)(s_rest + (SHORT ? 4 : 12) * (size_t)AMAX);   // long: t span | strand << 8; then the predecessor index
     uint16_t *const s_chain = s_aux + AMAX;
-    uint32_t *const s_strand = (uint32_t *)(s_rest + (SHORT ? 8 : 16) * (size_t)AMAX);  // SHORT only: one strand bit per anchor (128 B)
+    uint32_t *const s_strand = (uint32_t *)(s_rest + (SHORT ? 8 : 16) * (size_t)AMAX);  // SHORT only: one strand bit per anchor (AMAX / 8 B)
 #define KEY_Q(i) ((int)((uint64_t)s_key[i] >> KSH))
 #define KEY_T(i) ((int)((uint64_t)s_key[i] & KMASK))
 #define MAKE_KEY(q_, t_) ((key_t)(((uint64_t)(uint32_t)(q_) << KSH) | (uint64_t)(uint32_t)(t_)))
@@ -418,9 +420,9 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     uint32_t *s_tp = (uint32_t *)(s_rest + 8 * (size_t)AMAX);   // long layout only
     const bool t_in_lds = nt <= AMAX && lent < (1 << 23);
     const uint4 *mq4 = (const uint4 *)mq, *mt4 = (const uint4 *)mt;
-    constexpr int QR = FSV_AMAX / 64;   // AMAX <= FSV_AMAX
+    constexpr int QR = FSV_AMAX / 64;   // the query list sits in registers when it has at most FSV_AMAX entries (AMAX itself may be larger: FSV_AMAX_WIDE)
     uint4 qa[QR];
-    const bool q_in_regs = nq <= AMAX;
+    const bool q_in_regs = nq <= FSV_AMAX;
     if (q_in_regs) {
 #pragma unroll
         for (int u = 0; u < QR; u++) { const int i = u * 64 + lane; qa[u] = i < nq ? mq4[i] : make_uint4(0, 0, 0, 0); }
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
             s_th[i] = (uint64_t)b.x | (uint64_t)b.y << 32;
             if (!SHORT) s_tp[i] = b.z | (b.w & 0xffu) << 31 | ((b.w >> 8) & 0xffu) << 23; // pos < 2^23 | span << 23 | strand << 31
         }
-    if (SHORT) for (int i = lane; i < 32; i += 64) s_strand[i] = 0u;
+    if (SHORT) for (int i = lane; i < AMAX / 32; i += 64) s_strand[i] = 0u;
     __syncthreads();
     int n = 0, nrev = 0, nfwd = 0;
     auto lookup = [&](int i, const uint4 av) {
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
 }
 
 // LDS bytes of a k_chain block
-__host__ __device__ inline size_t chain_lds_bytes(bool short_reads, int amax) { return short_reads ? (size_t)amax * 12 + 128 : (size_t)amax * 24; }
+__host__ __device__ inline size_t chain_lds_bytes(bool short_reads, int amax) { return short_reads ? (size_t)amax * 12 + (size_t)amax / 8 : (size_t)amax * 24; }
 
 // ------------------------------------------------------------------------------------------------ k_rescue_accept
 // One lane per overlap slot: right-extension rescue of unmatched windows (Correct.cpp:2655-2744),
@@ -1368,6 +1370,8 @@ __global__ void k_gwin_tab(const uint32_t *__restrict__ gwin_read, const uint32_
     tab[gw] = make_uint4(r, pair_base[s] + (r - r0) * (ns - 1), ns - 1, gw - gwin_off[r]);
 }
 
+// EVC: insertion events a window can hold (HiFi at 30x: ~8 -> FSV_EV_CAP; ONT-profile reads: hundreds -> FSV_EV_CAP_WIDE)
+template <int EVC>
 __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
 {
     // Per-column votes of one 375-bp grid window.  A match op votes for the backbone's own base, so a lane (= one
@@ -1377,8 +1381,8 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     __shared__ uint32_t s_cnt[FSV_WINDOW + 1][3];  // per column, 16 bits each: votes for A C | G T that differ from the backbone | deleted, arrived-after-insertion
     __shared__ int32_t s_cov[FSV_WINDOW + 2];      // coverage difference array -> arrived
     __shared__ uint32_t s_path[64][27];            // per lane: the 26 op words of its window path (odd stride); reused as s_out
-    __shared__ uint16_t s_evcol[FSV_EV_CAP];
-    __shared__ uint32_t s_evkey[FSV_EV_CAP];
+    __shared__ uint16_t s_evcol[EVC];
+    __shared__ uint32_t s_evkey[EVC];
     __shared__ uint32_t s_evn, s_cover, s_anydev;   // s_anydev: some overlap deviates from the backbone somewhere in this window
     __shared__ uint32_t s_xraw[28];                // raw store words covering x[gs-16 .. gs+glen+16)
     __shared__ uint32_t s_scan[64];
@@ -1435,7 +1439,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                         uint32_t key = (uint32_t)gap << 24;
                         for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
                         uint32_t e = atomicAdd(&s_evn, 1u);
-                        if (e < FSV_EV_CAP) { s_evcol[e] = 0; s_evkey[e] = key; }
+                        if (e < (uint32_t)EVC) { s_evcol[e] = 0; s_evkey[e] = key; }
                     }
                 }
             }
@@ -1460,7 +1464,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                         const int yp = ry_start + p - n3;
                         for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
                         uint32_t e = atomicAdd(&s_evn, 1u);
-                        if (e < FSV_EV_CAP) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
+                        if (e < (uint32_t)EVC) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
                     }
                 }
                 n2 += L; p += L;
@@ -1493,8 +1497,8 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
     // fewer than three overlaps: the reference leaves the window alone; no deviation anywhere: every vote is for the backbone
     const bool verbatim = s_cover < 3u || s_anydev == 0u;
-    const uint32_t evn = min(s_evn, (uint32_t)FSV_EV_CAP);
-    if (s_evn > FSV_EV_CAP && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
+    const uint32_t evn = min(s_evn, (uint32_t)EVC);
+    if (s_evn > (uint32_t)EVC && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
     int arrived = before;
     bool differs = false;
     for (int c = c0; c < c1; c++) {

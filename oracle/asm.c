@@ -649,7 +649,7 @@ void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->diploid = 0;
-    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30;
+    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1;
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),
@@ -677,7 +677,7 @@ static int final_overlaps(const readset *R, const orc_asm_params *P, const orc_o
         for (i = 0; i < R->n * R->n; i++) slot[i] = -1;
         for (i = 0; i < n_prev; i++) slot[(size_t)prev[i].q * R->n + prev[i].t] = i;
         for (i = 0; i < m; i++) has[(size_t)ov[i].q * R->n + ov[i].t] = 1;
-        collect_overlaps(R, P, 1, uq, nuq, &ov2, &cq2, &ct2, &n2);
+        collect_overlaps(R, P, P->bw_rechain, uq, nuq, &ov2, &cq2, &ct2, &n2);
         ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)(m + n2 + 1));
         for (j = 0; j < n2; j++) {
             const orc_ovl *o = &ov2[j];

@@ -34,6 +34,7 @@ typedef struct {
     int32_t win_rate_pm;      /* window threshold = x_len x this / 1000: 40 (max_ov_diff_ec 0.04 -> k = 15 for a full window) */
     int32_t k_cap;            /* largest threshold the rescue pass doubles to: 31 (THRESHOLD_MAX_SIZE, Hash_Table.h:9-22) */
     int32_t accept_err_pm;    /* an overlap is used when its error rate is at most this / 1000: 30 (Correct.cpp:725) */
+    int32_t bw_rechain;       /* indel budget per mille when the final pass re-chains a pair without an exact overlap: 1 (max_ov_diff_final 0.001) */
 } orc_asm_params;
 
 typedef struct {
