@@ -1381,8 +1381,9 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     __shared__ uint32_t s_cnt[FSV_WINDOW + 1][3];  // per column, 16 bits each: votes for A C | G T that differ from the backbone | deleted, arrived-after-insertion
     __shared__ int32_t s_cov[FSV_WINDOW + 2];      // coverage difference array -> arrived
     __shared__ uint32_t s_path[64][27];            // per lane: the 26 op words of its window path (odd stride); reused as s_out
-    __shared__ uint16_t s_evcol[EVC];
+    __shared__ uint16_t s_evnext[EVC];             // insertion events of a column form a list: s_evhead[column] -> event -> s_evnext[event] ...
     __shared__ uint32_t s_evkey[EVC];
+    __shared__ uint32_t s_evhead[FSV_WINDOW + 1];
     __shared__ uint32_t s_evn, s_cover, s_anydev;   // s_anydev: some overlap deviates from the backbone somewhere in this window
     __shared__ uint32_t s_xraw[28];                // raw store words covering x[gs-16 .. gs+glen+16)
     __shared__ uint32_t s_scan[64];
@@ -1399,6 +1400,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((xlen + 15) >> 4)) ? A.store[xw + wi] : 0u; }
     for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
+    for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_evhead[i] = 0xffffu;
     if (lane == 0) { s_evn = 0; s_cover = 0; s_anydev = 0; }
     __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
@@ -1439,7 +1441,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                         uint32_t key = (uint32_t)gap << 24;
                         for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
                         uint32_t e = atomicAdd(&s_evn, 1u);
-                        if (e < (uint32_t)EVC) { s_evcol[e] = 0; s_evkey[e] = key; }
+                        if (e < (uint32_t)EVC) { s_evkey[e] = key; s_evnext[e] = (uint16_t)atomicExch(&s_evhead[0], e); }
                     }
                 }
             }
@@ -1464,7 +1466,7 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
                         const int yp = ry_start + p - n3;
                         for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
                         uint32_t e = atomicAdd(&s_evn, 1u);
-                        if (e < (uint32_t)EVC) { s_evcol[e] = (uint16_t)xp; s_evkey[e] = key; }
+                        if (e < (uint32_t)EVC) { s_evkey[e] = key; s_evnext[e] = (uint16_t)atomicExch(&s_evhead[xp], e); }
                     }
                 }
                 n2 += L; p += L;
@@ -1497,7 +1499,6 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
     // fewer than three overlaps: the reference leaves the window alone; no deviation anywhere: every vote is for the backbone
     const bool verbatim = s_cover < 3u || s_anydev == 0u;
-    const uint32_t evn = min(s_evn, (uint32_t)EVC);
     if (s_evn > (uint32_t)EVC && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
     int arrived = before;
     bool differs = false;
@@ -1512,11 +1513,11 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
             const int instot = (int)CNT_GET(c, 5u);
             if (instot) {
                 int bc = 0; uint32_t bk = 0;
-                for (uint32_t i = 0; i < evn; i++) {
-                    if (s_evcol[i] != c) continue;
+                // the most frequent inserted string of this column, the smaller key on a tie (the order of the list does not matter)
+                for (uint32_t i = s_evhead[c]; i != 0xffffu; i = s_evnext[i]) {
                     const uint32_t key = s_evkey[i];
                     int cn = 0;
-                    for (uint32_t j2 = 0; j2 < evn; j2++) cn += (s_evcol[j2] == c && s_evkey[j2] == key);
+                    for (uint32_t j2 = s_evhead[c]; j2 != 0xffffu; j2 = s_evnext[j2]) cn += (s_evkey[j2] == key);
                     if (cn > bc || (cn == bc && key < bk)) { bc = cn; bk = key; }
                 }
                 const int none = arrived - instot + 1, total = arrived + 1;

@@ -98,6 +98,14 @@ def default_params():
     return p
 
 
+def ont_params():
+    """the error model of fsv_asm_ont_params (focalsv_amd/csrc/asm.hip) for the oracle"""
+    p = default_params()
+    p.k, p.w, p.hpc, p.bw_ec, p.bw_final = 15, 15, 0, 150, 50
+    p.win_rate_pm, p.k_cap, p.accept_err_pm, p.bw_rechain, p.min_contig_reads = 250, 95, 300, 50, 2
+    return p
+
+
 def assemble(reads, params=None):
     """reads: list of bytes -> (contigs list[bytes], corrected list[bytes])"""
     p = params or default_params()

@@ -1,0 +1,54 @@
+"""BASELINE configs[4]: ONT-profile reads (10 % error, reads of 10-30 kb) through the whole hot path with fsv_asm_ont_params --
+wide-band K5 / K6 (bands of up to 191 rows), 4 096 anchors per pair, 2 048 insertion events per consensus window.  PARITY UNPINNED
+(the reference runs Flye / Shasta here, neither is in the tree or the image); pinned against this project's own oracle bit for bit
+and by planted truth."""
+import pytest
+
+from focalsv_amd import _lib, pipeline, synth
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ont():
+    regions = [synth.make_region(i, width=50000, profile="ont", start=i * 60000) for i in range(12)]
+    with _lib.Context(0) as ctx:
+        b = pipeline.upload_regions(ctx, [pipeline.region_from_synth(r) for r in regions])
+        try:
+            res = pipeline.run_hot_path(ctx, b, asm_params=ctx.ont_asm_params())
+        finally:
+            b.free(ctx)
+    return regions, res
+
+
+def test_one_contig_per_read_set(ont):
+    regions, res = ont
+    assert (res.set_status == 0).all() and (res.contig_status == 0).all()
+    per = {}
+    for ri, hp, c in res.contigs:
+        per.setdefault((ri, hp), []).append(len(c))
+    for ri, r in enumerate(regions):
+        for h in (0, 1):
+            assert len(per[(ri, h + 1)]) == 1
+            assert abs(per[(ri, h + 1)][0] - len(r.haps[h])) <= len(r.haps[h]) // 500      # residual errors: a missing base every ~2 kb
+
+
+def test_planted_svs(ont):
+    """type and genotype right, SVLEN within 2 %, position within 20 bp (inside the tandem-repeat block of every 8th region: anywhere
+    left of the planted position -- the contig's residual errors decide where in the repeat the gap sits)"""
+    regions, res = ont
+    calls = pipeline.parse_calls(res.lines)
+    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in regions for t in r.truth]
+    tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=20, len_tol=0.02, left_shift_ok=2000)
+    assert tp >= len(truth) - 1 and fp <= 1 and gt_ok >= tp - 1, (tp, fp, fn, gt_ok, len(truth))
+    strict = pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.0)[0]
+    assert strict >= len(truth) * 3 // 4, strict
+
+
+def test_contigs_equal_the_oracle(ont):
+    regions, res = ont
+    for ri in (0, 3):
+        for h in (0, 1):
+            oc, _ = O.assemble(regions[ri].reads[h], O.ont_params())
+            assert [c for r2, hp, c in res.contigs if r2 == ri and hp == h + 1] == oc

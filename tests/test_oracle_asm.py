@@ -128,3 +128,20 @@ def test_repeat_rich_sets_equal_hifiasm(golden_dir, idx):
     assert hashlib.md5(b"\n".join(r.reads[0])).hexdigest() == g["reads_md5"], "synthetic generator drifted"
     contigs, corrected = O.assemble(r.reads[0])
     check_repeat_set(g, contigs, corrected, r.haps[0])
+
+
+def test_ont_profile_read_set_assembles_and_carries_its_svs():
+    """BASELINE configs[4]: reads with 10 % error (synth profile 'ont').  The reference hands these to Flye / Shasta (absent): this
+    row is PARITY UNPINNED.  What is checked: with the ONT error model (k = 15 seeds, windows up to 25 % apart aligned by the
+    wide-band BPM, three rounds of the same column-vote consensus) one read set gives one contig within 0.1 % of the haplotype's
+    length whose alignment to the reference window shows the planted SVs and nothing else of 30 bp or more"""
+    from tests.test_oracle_aln import _events
+    r = synth.make_region(5, width=40000, profile="ont")
+    contigs, corrected = O.assemble(r.reads[0], O.ont_params())
+    assert len(contigs) == 1 and abs(len(contigs[0]) - len(r.haps[0])) <= len(r.haps[0]) // 1000
+    a = O.align_contig(contigs[0], r.ref)
+    ev = _events(a)
+    want = [(t.svtype, t.pos_left, t.length) for t in r.truth if t.hap & 1]
+    assert len(ev) == len(want)
+    for (k, p, n), (wk, wp, wn) in zip(sorted(ev, key=lambda e: e[1]), sorted(want, key=lambda e: e[1])):
+        assert k == wk and abs(p - wp) <= 5 and abs(n - wn) <= max(1, wn // 50), (ev, want)
