@@ -50,7 +50,7 @@ def _set_cost(reads) -> int:
     return (n - 1) * win * 176 + n * n * 72 + sum(len(r) for r in reads) * 24 if n > 1 else 4096
 
 
-def assemble_sets(ctx: _lib.Context, sets, logger=None, budget_bytes: Optional[int] = None, set_flags=None):
+def assemble_sets(ctx: _lib.Context, sets, logger=None, budget_bytes: Optional[int] = None, set_flags=None, params=None):
     """all read sets of a chromosome through fsv_assemble_batch, in as few batches as the device memory allows
     (FSV_BATCH_GB overrides the default budget of 64 GB of workspace per batch); a batch the library refuses as too large is
     halved and retried.  -> [(contigs, status)] per set, in input order."""
@@ -62,7 +62,7 @@ def assemble_sets(ctx: _lib.Context, sets, logger=None, budget_bytes: Optional[i
         b = pack_sets([sets[i] for i in idx])
         d = ctx.upload(b.words)
         try:
-            contigs, cset, cnr, st = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start, None,
+            contigs, cset, cnr, st = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start, params,
                                                          None if set_flags is None else [set_flags[i] for i in idx])
         finally:
             ctx.dev_free(d)
@@ -106,6 +106,32 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
         fas = [f for f in fas if not (os.path.exists(os.path.join(os.path.dirname(f), "HP1.fa")) and os.path.exists(os.path.join(os.path.dirname(f), "HP2.fa")))]
     logger.info(f"read sets to assemble: {len(fas)}")
     status: Dict[str, int] = {}
+    if fas and data_type != 0:
+        # CLR / ONT: the reference runs Flye on every PS*.fa (run_assembly.py:46-100, output <X>_flye/assembly.fasta; ONT falls back to
+        # Shasta, post_assembly.py:43-76).  Here the same assembler as for HiFi runs with the error model opened up
+        # (fsv_asm_ont_params: wide-band K5 / K6) and leaves its contigs where combine_fas_clr / _ont look for Flye's.
+        # Checkpoint as the reference's: a set whose assembly.fasta exists is skipped (run_assembly.py:65).
+        fas = [f for f in fas if not os.path.exists(os.path.join(f[:-3] + "_flye", "assembly.fasta"))] if skip_existing else fas
+        sets = [fasta.read_reads(f) for f in fas]
+        own = ctx is None
+        ctx = ctx or _lib.Context(device)
+        try:
+            per_set = assemble_sets(ctx, sets, logger, params=ctx.ont_asm_params())
+        finally:
+            if own:
+                ctx.close()
+        for f, (contigs, st) in zip(fas, per_set):
+            d = f[:-3] + "_flye"
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "assembly.fasta"), "w") as fw:       # Flye's layout: >contig_<n>, sequence folded at 60 columns
+                for n, c in enumerate(contigs, 1):
+                    t = c.decode()
+                    fw.write(">contig_%d\n" % n + "\n".join(t[i:i + 60] for i in range(0, len(t), 60)) + "\n")
+            status[f] = int(st)
+            if st:
+                logger.warning(f"{f}: assembly status {int(st)}")
+        combine_fas(regions_dir, logger, data_type)
+        return status
     if fas:
         if any('unphased' in os.path.basename(f) for f in fas):
             logger.info("unphased read sets go through the haplotype partition (FSV_SET_UNPHASED)")
@@ -137,14 +163,19 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
     return status
 
 
-def combine_fas(regions_dir: str, logger=None):
-    """combine_fas.py:10-35 (HiFi naming: *hp1.asm.p_ctg.gfa.fa / *hap1.p_ctg.gfa.fa)"""
+def combine_fas(regions_dir: str, logger=None, data_type: int = 0):
+    """combine_fas.py:10-35 (HiFi naming: *hp1.asm.p_ctg.gfa.fa / *hap1.p_ctg.gfa.fa); CLR / ONT: the <X>hp1_flye/assembly.fasta of
+    combine_fas_clr / combine_fas_ont (:37-111; no Shasta directories are written here)"""
     for fd in sorted(os.listdir(regions_dir)):
         d = os.path.join(regions_dir, fd)
         if not fd.startswith("Region") or not os.path.isdir(d):
             continue
         for hp, tags in ((1, ("hp1.asm.p_ctg.gfa.fa", "hap1.p_ctg.gfa.fa")), (2, ("hp2.asm.p_ctg.gfa.fa", "hap2.p_ctg.gfa.fa"))):
-            parts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(tags)]
+            if data_type != 0:
+                parts = [os.path.join(d, f, "assembly.fasta") for f in sorted(os.listdir(d)) if f.endswith("hp%d_flye" % hp)]
+                parts = [p for p in parts if os.path.exists(p)]
+            else:
+                parts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(tags)]
             with open(os.path.join(d, f"HP{hp}.fa"), 'w') as out:
                 for p in parts:
                     with open(p) as f:

@@ -134,3 +134,36 @@ def test_heterozygous_unphased_region(tmp_path):
     truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for t in r.truth]
     tp, fp, fn, gt = pipeline.match_truth(pipeline.parse_calls(raw), truth, bp_tol=1, len_tol=0.0)
     assert (tp, fp, fn, gt) == (len(truth), 0, 0, len(truth))
+
+
+def test_ont_region_directory_to_vcf(tmp_path):
+    """data type 2 (ONT), where the reference runs Flye per PS*.fa and combines <X>hpN_flye/assembly.fasta: the GPU assembler with the
+    ONT error model leaves its contigs in exactly those files, combine_fas_ont's naming gives HP1.fa / HP2.fa, and step 4 with the ONT
+    signature rules calls the planted SVs (+-20 bp, +-2 % SVLEN: contigs of 10 %-error reads keep a wrong base every ~2 kb)"""
+    out = str(tmp_path)
+    rs = [synth.make_region(i, start=10000 + i * 80000, profile="ont") for i in (1, 2)]
+    import random
+    rng = random.Random(8)
+    total = max(r.start + len(r.ref) for r in rs) + 20000
+    seq = [rng.choice("ACGT") for _ in range(total)]
+    for r in rs:
+        synth.write_region_dir(r, os.path.join(out, "regions"))
+        seq[r.start:r.start + len(r.ref)] = r.ref.decode()
+    ref_fa = os.path.join(out, "ref.fa")
+    with open(ref_fa, "w") as f:
+        f.write(">chr21\n" + fasta.fold("".join(seq), 60) + "\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    bam = write_reads_bam(os.path.join(out, "reads.bam"), rs, total)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "3_assembly.py"), "-bam", bam, "-chr", "21", "-r", ref_fa, "-o", out, "-d", "2"], env=env)
+    for r in rs:
+        d = os.path.join(out, "regions", "Region_chr21_S%d_E%d" % (r.start, r.start + 50000))
+        assert os.path.exists(os.path.join(d, "PS1_hp1_flye", "assembly.fasta")) and os.path.exists(os.path.join(d, "PS1_hp2_flye", "assembly.fasta"))
+        for hp, hap in ((1, r.haps[0]), (2, r.haps[1])):
+            ctg = list(fasta.read_fasta(os.path.join(d, "HP%d.fa" % hp)))
+            assert len(ctg) == 1 and abs(len(ctg[0][1]) - len(hap)) <= len(hap) // 500
+    vcf = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "4_sv_calling.py"), "-bam", bam, "-chr", "21", "-r", ref_fa, "-o", out, "-d", "2"],
+                                  env=env).decode().strip().splitlines()[-1]
+    raw = [l for l in open(os.path.join(out, "SV", "chr21", "dippav_raw_variant.vcf")) if l[0] != '#']
+    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in rs for t in r.truth]
+    tp, fp, fn, gt = pipeline.match_truth(pipeline.parse_calls(raw), truth, bp_tol=20, len_tol=0.02, left_shift_ok=2000)
+    assert tp == len(truth) and fp == 0, (tp, fp, fn, truth, pipeline.parse_calls(raw))
