@@ -476,3 +476,64 @@ def test_streamed_region_cut_equals_per_region_fetch(tmp_path):
         w0 += n
         r0 += nr
     assert sum(len(r.read_records) for r in streamed.regions) > 20
+
+
+# ---- files written by htslib: the fixtures of the svim-asm unit tests vendored in the reference tree -------------------------------
+# (focalsv/TRA_INV_DUP_call/Target/svim-asm-1.0.2/src/tests/chimeric_read*.bam / .sam, copied byte for byte into tests/golden/):
+# real BGZF / BAM from samtools, 93 reference sequences, noisy ~10 kb reads with 1 000-op CIGARs, float / int / string aux tags, SA
+# tags -- the one place where the reader is checked against a writer that is not tests/bam_writer.py.
+def _sam_records(path):
+    out = []
+    for l in open(path):
+        if l.startswith("@"):
+            continue
+        f = l.rstrip("\n").split("\t")
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        out.append({"qname": f[0], "flag": int(f[1]), "rname": f[2], "pos": int(f[3]) - 1, "mapq": int(f[4]), "cigar": f[5], "seq": f[9], "tags": tags})
+    return out
+
+
+def test_reader_against_htslib_written_bam_and_its_sam(golden_dir):
+    import os
+    import re
+    sam = _sam_records(os.path.join(golden_dir, "chimeric_read_errors.sam"))
+    refs = [l.split("\t")[1][3:] for l in open(os.path.join(golden_dir, "chimeric_read_errors.sam")) if l.startswith("@SQ")]
+    with B.BamFile(os.path.join(golden_dir, "chimeric_read_errors.bam")) as f:
+        assert f.references == refs and len(refs) == 93
+        got = f.fetch(until_eof=True, want_seq=7)
+        by_ref = f.fetch("chr21", 35346000, 35347000, want_seq=2)     # no .bai: whole-file scan, same records
+    assert len(got) == len(sam) == 2 and len(by_ref) == 2
+    for i, s in enumerate(sam):
+        seg = got.segment(i)
+        assert got.names[i] == s["qname"] and int(got.flag[i]) == s["flag"] and int(got.mapq[i]) == s["mapq"] and int(got.pos[i]) == s["pos"]
+        assert refs[int(got.ref_id[i])] == s["rname"]
+        assert "".join("%d%s" % (n, "MIDNSHP=X"[op]) for op, n in seg.cigar) == s["cigar"]
+        assert got.seq_text(i) == s["seq"] and int(got.l_seq[i]) == len(s["seq"])
+        ref_len = sum(int(n) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", s["cigar"]) if op in "MDN=X")
+        assert int(got.ref_end[i]) == s["pos"] + ref_len
+        assert got.sa_tag(i) == s["tags"]["SA"]
+        assert got.tag(i, "PS") is None and got.tag(i, "HP") is None
+        assert by_ref.seq_text(i) == s["seq"]
+    # the packed 2-bit copy of the bases equals a pack of the SAM text
+    import numpy as np
+    from focalsv_amd import readsets
+    ref = readsets.pack_sets([[s["seq"].encode() for s in sam]])
+    from focalsv_amd import output_fas
+    pk = output_fas.pack_record_sets(got, [[0, 1]])
+    n = int(ref.word_off[-1])
+    assert np.array_equal(pk.words[:n], ref.words[:n]) and np.array_equal(pk.read_len, ref.read_len)
+
+
+def test_reader_on_the_second_htslib_bam(golden_dir):
+    """chimeric_read.bam (no SAM beside it): four records of one read, primary + supplementary; the invariants pysam would give"""
+    import os
+    with B.BamFile(os.path.join(golden_dir, "chimeric_read.bam")) as f:
+        r = f.fetch(until_eof=True, want_seq=6)
+    assert len(r) == 4 and len(set(r.names)) == 1
+    assert [int(x) for x in r.flag] == [0, 2048, 2048, 2048][:4] or sorted(int(x) & 2048 for x in r.flag).count(2048) == 3
+    for i in range(4):
+        seg = r.segment(i)
+        q = sum(n for op, n in seg.cigar if op in (0, 1, 4, 7, 8))
+        assert q == int(r.l_seq[i]) == len(r.seq_text(i)) and set(r.seq_text(i)) <= set("ACGTN")
+        assert int(r.ref_end[i]) == int(r.pos[i]) + sum(n for op, n in seg.cigar if op in (0, 2, 3, 7, 8))
+        assert r.sa_tag(i).count(";") >= 1
