@@ -163,7 +163,7 @@ int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len,
 // sketch + per-read index + chaining on the current store; fills ws.ovl (and ws.tasks when emit_tasks).  Nothing here waits
 // for the GPU: launches are sized from the read lengths the host already has, counts stay in the round's counter slot `ct`.
 int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, const uint32_t *store, const fsv_asm_params &P, int bw,
-                  bool emit_tasks, uint32_t task_cap, uint32_t *ct, bool short_reads, bool wide_anchors, const uint32_t *only_changed = nullptr)
+                  bool emit_tasks, uint32_t task_cap, uint32_t *ct, bool short_reads, bool wide_anchors, int w, const uint32_t *only_changed = nullptr)
 {
     Span ts(ctx, W.kt, ST_SKETCH);
     TRY(ensure(ctx, W.mz, (size_t)G.mz_off[B.n_reads] * sizeof(fsv_mz)));
@@ -183,16 +183,16 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
         FSV_HIP(ctx, hipMemsetAsync(W.sk_low.p, 0, (total_words + B.n_reads + 8) * 4, ctx->stream));
         FSV_HIP(ctx, hipMemsetAsync(W.sk_high.p, 0, (total_words + B.n_reads + 8) * 4, ctx->stream));
         hipLaunchKernelGGL(k_sketch_fast, dim3(B.n_reads), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
-                           (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
+                           (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, w, P.k,
                            P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, (uint32_t *)W.sk_ends.p, (uint32_t *)W.sk_low.p, (uint32_t *)W.sk_high.p,
                            only_changed);
         FSV_HIP(ctx, hipGetLastError());
     } else {
         const uint32_t lds_words = std::min<uint32_t>(G.max_words, 8192u);
-        FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(P.w, lds_words)));
-        hipLaunchKernelGGL(k_sketch, dim3(B.n_reads), dim3(64), sketch_lds_bytes(P.w, lds_words), ctx->stream, store, (const uint32_t *)W.word_off.p,
-                           (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, P.w, P.k,
-                           P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, P.w, lds_words);
+        FSV_HIP(ctx, hipFuncSetAttribute((const void *)k_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_lds_bytes(w, lds_words)));
+        hipLaunchKernelGGL(k_sketch, dim3(B.n_reads), dim3(64), sketch_lds_bytes(w, lds_words), ctx->stream, store, (const uint32_t *)W.word_off.p,
+                           (const int32_t *)W.len.p, (const uint32_t *)W.mz_off.p, (fsv_mz *)W.mz.p, (uint32_t *)W.mz_cnt.p, B.n_reads, w, P.k,
+                           P.hpc, (uint32_t *)W.warn.p, (const uint8_t *)nullptr, w, lds_words);
         FSV_HIP(ctx, hipGetLastError());
     }
     W.kt.end(ctx);
@@ -311,7 +311,7 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
     if (!p) return;
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
-    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1;
+    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0;
 }
 
 extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
@@ -322,6 +322,7 @@ extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
     p->bw_ec = 150; p->bw_final = 50;           // chains of noisy reads drift by several per cent between anchors
     p->win_rate_pm = 250; p->k_cap = FSV_K_WIDE; p->accept_err_pm = 300;   // two 10 % reads differ by ~20 %: k = 93 for a full window
     p->bw_rechain = 50;                         // corrected reads keep a 1-base indel every few kb
+    p->w_later = 63;                            // after one round the reads are ~99 % accurate: sparser seeds keep a pair's anchors below 1 024
     p->min_contig_reads = 2;                    // reads of 10-30 kb tile a 50 kb window with three or four uncontained reads: hifiasm's tip rule (4) would drop them
 }
 
@@ -522,7 +523,10 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         TRY(ensure(ctx, W.dp_list3, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_wide, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_xwide, wide_bands ? (size_t)task_cap * 4 : 64));
-        TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_ec, true, task_cap, ct, short_reads, wide_bands));
+        // ONT-profile batches: dense seeds and 4 096-anchor tiles for the first round only (noisy reads share few minimizers, but nothing bounds
+        // them); from the second round on the reads are accurate and the sparser seeds keep a pair below 1 024 anchors
+        const int w_round = (round > 0 && P.w_later > 0) ? P.w_later : P.w;
+        TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_ec, true, task_cap, ct, short_reads, wide_bands && w_round == P.w, w_round));
         W.stats.n_pairs += B.n_pairs;
         if (B.n_pairs) {
             Span tv(ctx, W.kt, ST_VERIFY);
@@ -685,7 +689,10 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         FSV_HIP(ctx, hipMemcpyAsync(W.ovl_prev.p, W.ovl.p, (size_t)B.n_pairs * sizeof(fsv_ovl), hipMemcpyDeviceToDevice, ctx->stream));
     }
     // reads the last round left untouched keep that round's minimizer lists (the last round does not reverse-complement)
-    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0, ctf, short_reads, wide_bands, P.n_rounds > 0 ? (const uint32_t *)W.changed.p : nullptr));
+    const int w_final = P.w_later > 0 ? P.w_later : P.w;
+    // (the final pass keeps the lists of unchanged reads only when the last round sketched with the same window)
+    const bool keep_lists = P.n_rounds > 0 && (P.n_rounds > 1 || w_final == P.w);
+    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0, ctf, short_reads, wide_bands && w_final == P.w, w_final, keep_lists ? (const uint32_t *)W.changed.p : nullptr));
     trace("overlaps");
     const fsv_hit *hraw = nullptr;
     std::vector<uint32_t> hit_first(B.n_sets + 1, 0);
@@ -882,7 +889,8 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     if (params) P = *params; else fsv_asm_default_params(&P);
     if (P.k < 1 || P.k > 63 || P.w < 1 || P.w > 64 || P.lookback != 64 || P.n_rounds < 0 || P.n_rounds > 16 || P.min_anchors < 1)
         return fsv_fail(ctx, FSV_EINVAL, "fsv_asm_params out of range (k<=63, w<=64, lookback==64)");
-    if (P.k_cap < 1 || P.k_cap > FSV_K_WIDE || P.win_rate_pm < 1 || (int)(FSV_WINDOW * (P.win_rate_pm / 1000.0)) > P.k_cap || P.accept_err_pm < 0 || P.accept_err_pm > 1000)
+    if (P.k_cap < 1 || P.k_cap > FSV_K_WIDE || P.win_rate_pm < 1 || (int)(FSV_WINDOW * (P.win_rate_pm / 1000.0)) > P.k_cap || P.accept_err_pm < 0 || P.accept_err_pm > 1000 ||
+        P.w_later < 0 || P.w_later > 64)
         return fsv_fail(ctx, FSV_EINVAL, "fsv_asm_params error model out of range (k_cap <= 95, 375 x win_rate_pm / 1000 <= k_cap)");
     FSV_HIP(ctx, hipSetDevice(ctx->device));
     AsmWs &W = *ws_get(ctx);

@@ -159,6 +159,7 @@ typedef struct fsv_asm_params {
     int32_t k_cap;            /* largest threshold the rescue pass doubles to: 31 = FSV_K_MAX (THRESHOLD_MAX_SIZE); at most FSV_K_WIDE */
     int32_t accept_err_pm;    /* an overlap is used when its error rate is at most this / 1000: 30 (Correct.cpp:725) */
     int32_t bw_rechain;       /* indel budget per mille when the final pass re-chains a pair without an exact overlap: 1 (max_ov_diff_final 0.001) */
+    int32_t w_later;          /* minimizer window from the second correction round on; 0 = w throughout (hifiasm) */
 } fsv_asm_params;
 void fsv_asm_default_params(fsv_asm_params *p);
 /* ONT-profile reads (BASELINE configs[4]: ~10 % error): k = 15, w = 15 without homopolymer compression (a 30 kb read then has ~3 750 minimizers: below the 4 096 a list holds), chain indel budget 0.15 / 0.05,

@@ -379,7 +379,7 @@ static void collect_overlaps(const readset *R, const orc_asm_params *P, int bw, 
     *ovl_out = ov; *cq_out = cq; *ct_out = ct; *n_out = n;
 }
 
-static void sketch_set(const readset *R, const orc_asm_params *P, orc_mz ***uq_out, int **nuq_out)
+static void sketch_set(const readset *R, const orc_asm_params *P, int w, orc_mz ***uq_out, int **nuq_out)
 {
     int r;
     orc_mz **uq = (orc_mz **)malloc(sizeof(orc_mz *) * (size_t)R->n);
@@ -387,7 +387,7 @@ static void sketch_set(const readset *R, const orc_asm_params *P, orc_mz ***uq_o
     for (r = 0; r < R->n; r++) {
         int cap = R->len[r] + 8, n;
         uq[r] = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)cap);
-        n = orc_sketch(R->seq[r], R->len[r], P->w, P->k, P->hpc, uq[r], cap);
+        n = orc_sketch(R->seq[r], R->len[r], w, P->k, P->hpc, uq[r], cap);
         nuq[r] = orc_unique_sorted(uq[r], n);
     }
     *uq_out = uq; *nuq_out = nuq;
@@ -611,13 +611,13 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
 }
 
 /* one correction round: R -> corrected reads (new buffers); returns total windows examined */
-static void correction_round(readset *R, const orc_asm_params *P, int do_rc, orc_ovl **accepted, int *n_accepted)
+static void correction_round(readset *R, const orc_asm_params *P, int w, int do_rc, orc_ovl **accepted, int *n_accepted)
 {
     orc_mz **uq; int *nuq, n_ov, n_win, q;
     orc_ovl *ov; int32_t *cq, *ct; orc_win *W;
     char **nseq = (char **)malloc(sizeof(char *) * (size_t)R->n);
     int *nlen = (int *)malloc(sizeof(int) * (size_t)R->n);
-    sketch_set(R, P, &uq, &nuq);
+    sketch_set(R, P, w, &uq, &nuq);
     collect_overlaps(R, P, P->bw_ec, uq, nuq, &ov, &cq, &ct, &n_ov);
     W = align_overlaps(R, P, ov, n_ov, cq, ct, &n_win);
     if (P->diploid) { /* unphased read set: overlaps between the two haplotypes leave the consensus (is_match = 2 as in hifiasm) */
@@ -649,7 +649,7 @@ void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->diploid = 0;
-    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1;
+    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0;
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),
@@ -660,7 +660,7 @@ static int final_overlaps(const readset *R, const orc_asm_params *P, const orc_o
 {
     orc_mz **uq; int *nuq, n_ov, i, m = 0;
     orc_ovl *ov; int32_t *cq, *ct;
-    sketch_set(R, P, &uq, &nuq);
+    sketch_set(R, P, P->w_later > 0 ? P->w_later : P->w, &uq, &nuq);
     collect_overlaps(R, P, P->bw_final, uq, nuq, &ov, &cq, &ct, &n_ov);
     for (i = 0; i < n_ov; i++) {
         orc_ovl *o = &ov[i];
@@ -792,7 +792,7 @@ int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const o
     }
     for (i = 0; i < P->n_rounds; i++) {
         const int last = i + 1 == P->n_rounds;
-        correction_round(&R, P, !last, last ? &prev : NULL, last ? &n_prev : NULL);
+        correction_round(&R, P, (i > 0 && P->w_later > 0) ? P->w_later : P->w, !last, last ? &prev : NULL, last ? &n_prev : NULL);
     }
     if (corrected && corrected_off) {
         uint64_t u = 0;
