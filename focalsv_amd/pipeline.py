@@ -395,6 +395,19 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     lanes = len(ctxs)
     if static:
         batches = list(batches)
+    # A lane thread spends its time inside library calls (GIL released) and needs the GIL for microseconds between them, while the
+    # host-half and read-side threads run pure Python.  With CPython's default 5 ms switch interval every such hand-over can cost the
+    # lane up to 5 ms of GPU idle time -- three or four per batch; a short interval makes the Python threads yield promptly.
+    import sys
+    old_interval = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
+    try:
+        return _run_stream(ctxs, batches, on_result, static, stagger, host_workers, keep_results, lanes, **kw)
+    finally:
+        sys.setswitchinterval(old_interval)
+
+
+def _run_stream(ctxs, batches, on_result, static, stagger, host_workers, keep_results, lanes, **kw):
     results: Dict[int, CallResult] = {}
     errs: List[BaseException] = []
     source = enumerate(batches)
