@@ -102,33 +102,74 @@ __global__ __launch_bounds__(64) void k_chain_aln(const uint32_t *__restrict__ w
     // extract_contig_signature_CCS.py:251-327): the anchors inside the query interval of a chain are taken out -- they are a
     // contiguous run, the list is in query order -- and the rest goes through the same DP, up to ALN_MAX_REC chains.
     for (int rec = 0; rec < ALN_MAX_REC && n >= P.min_anchors; rec++) {
-        for (int i = 0; i < n; i++) {
+        // chain DP (look back 64 anchors, the best-scoring predecessor, the nearer one on ties; oracle/aln.c:orc_aln_chains).  A contig
+        // against its own reference window is co-linear except at its SVs, so 64 anchors are settled at once as in the assembler's
+        // k_chain: hypothesis "every anchor links to its predecessor" (the scores are a prefix sum), proof that no other predecessor
+        // beats it (cand(i, j) <= f[j] + k: only the j with f[j] + k > f[i] are evaluated), one sequential step where it fails.
+        // Round 1 walked the anchors one by one, a barrier and three LDS round trips each (4.3 ms for 50 kb contigs).
+        auto cand_of = [&](int qe, int te, int qj, int tj, int fj, bool &ok) -> int {
+            const int dq = qe - qj, dt = te - tj;
+            ok = false;
+            if (dq <= 0 || dt <= 0) return 0;
+            const int gap = dq > dt ? dq - dt : dt - dq;
+            if (gap > P.max_gap) return 0;
+            int sc = min(min(dq, dt), P.k);
+            if (gap) sc -= (gap >> 7) + (ilog2_u32((uint32_t)gap) >> 1) + 1;
+            ok = true;
+            return sc + fj;
+        };
+        auto step_seq = [&](int i) {     // the DP step of anchor i as the sequential loop does it; all lanes take part
             const uint64_t ki = s_key[i];
             const int qe = (int)(ki >> 32), te = (int)(uint32_t)ki;
             const int j = i - 1 - lane;
-            int cand = -1; // -1 = no legal predecessor (a legal candidate is >= k - 200 + k > -1 ... kept distinct by `ok`)
-            bool ok = false;
-            if (j >= 0) {
-                const uint64_t kj = s_key[j];
-                const int dq = qe - (int)(kj >> 32), dt = te - (int)(uint32_t)kj;
-                if (dq > 0 && dt > 0) {
-                    const int gap = dq > dt ? dq - dt : dt - dq;
-                    if (gap <= P.max_gap) {
-                        int sc = min(min(dq, dt), P.k);
-                        if (gap) sc -= (gap >> 7) + (ilog2_u32((uint32_t)gap) >> 1) + 1;
-                        cand = sc + s_f[j];
-                        ok = true;
-                    }
-                }
-            }
+            bool ok = false; int cand = 0;
+            if (j >= 0) { const uint64_t kj = s_key[j]; cand = cand_of(qe, te, (int)(kj >> 32), (int)(uint32_t)kj, s_f[j], ok); }
             // scores can drop below zero here (gap penalty), so bias before packing; lanes without a legal predecessor sit out
-            const bool legal = ok;
-            const int mine = legal ? ((cand + (1 << 20)) * 64 + (63 - lane)) : -1; // < 2^27
+            const int mine = ok ? ((cand + (1 << 20)) * 64 + (63 - lane)) : -1; // < 2^27
             const int bestp = wave_max_i32(mine);
             const int bests = bestp < 0 ? -(1 << 30) : (int)(bestp >> 6) - (1 << 20);
             if (bests > P.k) { if (mine == bestp) { s_f[i] = bests; s_aux[i] = (uint16_t)j; } }
             else if (lane == 0) { s_f[i] = P.k; s_aux[i] = 0xffff; }
             __syncthreads();
+        };
+        if (n > 0) step_seq(0);
+        for (int i0 = 1; i0 < n;) {
+            const int nb = min(64, n - i0), i = i0 + lane;
+            const bool in = lane < nb;
+            int qe = 0, te = 0, sc1 = 0; bool ok1 = false;
+            if (in) {
+                const uint64_t ki = s_key[i], kp = s_key[i - 1];
+                qe = (int)(ki >> 32); te = (int)(uint32_t)ki;
+                sc1 = cand_of(qe, te, (int)(kp >> 32), (int)(uint32_t)kp, 0, ok1);
+            }
+            int pre = ok1 ? sc1 : 0;
+            for (int off = 1; off < 64; off <<= 1) { const int o2 = __shfl_up(pre, off, 64); if (lane >= off) pre += o2; }
+            const int fi = s_f[i0 - 1] + pre;
+            bool bad = in && !(ok1 && fi > P.k);
+            __syncthreads();
+            if (in) s_f[i] = fi;
+            __syncthreads();
+            for (int d = 2; d <= 64; d++) {
+                const int j = i - d;
+                const bool live = in && !bad && j >= 0;
+                if (!__any(live)) break;
+                int fj = 0;
+                if (live) fj = s_f[j];
+                const bool need = live && fj + P.k > fi;
+                if (__any(need)) {
+                    if (need) {
+                        bool ok2; const uint64_t kj = s_key[j];
+                        const int c2 = cand_of(qe, te, (int)(kj >> 32), (int)(uint32_t)kj, fj, ok2);
+                        if (ok2 && c2 > fi) bad = true;
+                    }
+                }
+            }
+            const uint64_t badm = __ballot(bad);
+            const int good = badm ? (int)__ffsll((long long)badm) - 1 : nb;
+            if (lane < good) s_aux[i] = (uint16_t)(i - 1);
+            __syncthreads();
+            i0 += good;
+            if (good < nb) { step_seq(i0); i0++; }
         }
         long long bk = -1;
         for (int i = lane; i < n; i += 64) { long long v = (long long)s_f[i] * 16384 + (16383 - i); bk = v > bk ? v : bk; }
@@ -328,24 +369,30 @@ struct NwRows {
 
 // cell (i, j) of diagonal d = i + j (ksw_extz2's recurrence, ksw2_extz2_sse.c; boundary: a gap of length l before the
 // first cell costs min(q + e*l, q2 + e2*l))
+// BYROW: the rolling rows are indexed by the target row i instead of the query column j (k_nw_rows: events with a short target side)
+template <bool BYROW = false>
 __device__ __forceinline__ void nw_cell(const NwRows &R, int d, int i, int j, uint32_t tb, uint32_t qb, bool two, const fsv_aln_params &P,
                                         uint8_t *__restrict__ bt, int ql)
 {
+    const int xc = BYROW ? i : j;             // this cell's slot
+    const int xd = xc - 1;                    // the diagonal neighbour (i-1, j-1)
+    const int xe = BYROW ? i - 1 : j;         // E comes from (i-1, j)
+    const int xf = BYROW ? i : j - 1;         // F comes from (i, j-1)
     int32_t hdiag, a, b, a2 = NW_NEG, b2 = NW_NEG;
     if (i == 0 && j == 0) hdiag = 0;
     else if (i == 0) { int g1 = -(P.q + P.e * j), g2 = two ? -(P.q2 + P.e2 * j) : NW_NEG; hdiag = max(g1, g2); }
     else if (j == 0) { int g1 = -(P.q + P.e * i), g2 = two ? -(P.q2 + P.e2 * i) : NW_NEG; hdiag = max(g1, g2); }
-    else hdiag = R.H(d - 2)[j - 1];
+    else hdiag = R.H(d - 2)[xd];
     if (i == 0) {
         int g1 = -(P.q + P.e * (j + 1)), g2 = two ? -(P.q2 + P.e2 * (j + 1)) : NW_NEG;
         const int hup = max(g1, g2); // H(-1, j)
         a = hup - P.q - P.e; if (two) a2 = hup - P.q2 - P.e2;
-    } else { a = R.E(d - 1)[j]; if (two) a2 = R.E2(d - 1)[j]; }
+    } else { a = R.E(d - 1)[xe]; if (two) a2 = R.E2(d - 1)[xe]; }
     if (j == 0) {
         int g1 = -(P.q + P.e * (i + 1)), g2 = two ? -(P.q2 + P.e2 * (i + 1)) : NW_NEG;
         const int hleft = max(g1, g2); // H(i, -1)
         b = hleft - P.q - P.e; if (two) b2 = hleft - P.q2 - P.e2;
-    } else { b = R.F(d - 1)[j - 1]; if (two) b2 = R.F2(d - 1)[j - 1]; }
+    } else { b = R.F(d - 1)[xf]; if (two) b2 = R.F2(d - 1)[xf]; }
     int32_t h = hdiag + (tb == qb ? P.a : -P.b);
     uint8_t dd = 0;
     if (a > h) { h = a; dd = 1; }
@@ -353,14 +400,14 @@ __device__ __forceinline__ void nw_cell(const NwRows &R, int d, int i, int j, ui
     if (two && a2 > h) { h = a2; dd = 3; }
     if (two && b2 > h) { h = b2; dd = 4; }
     int32_t o = h - P.q;
-    if (a > o) { dd |= 0x08; R.E(d)[j] = a - P.e; } else R.E(d)[j] = o - P.e;
-    if (b > o) { dd |= 0x10; R.F(d)[j] = b - P.e; } else R.F(d)[j] = o - P.e;
+    if (a > o) { dd |= 0x08; R.E(d)[xc] = a - P.e; } else R.E(d)[xc] = o - P.e;
+    if (b > o) { dd |= 0x10; R.F(d)[xc] = b - P.e; } else R.F(d)[xc] = o - P.e;
     if (two) {
         o = h - P.q2;
-        if (a2 > o) { dd |= 0x20; R.E2(d)[j] = a2 - P.e2; } else R.E2(d)[j] = o - P.e2;
-        if (b2 > o) { dd |= 0x40; R.F2(d)[j] = b2 - P.e2; } else R.F2(d)[j] = o - P.e2;
+        if (a2 > o) { dd |= 0x20; R.E2(d)[xc] = a2 - P.e2; } else R.E2(d)[xc] = o - P.e2;
+        if (b2 > o) { dd |= 0x40; R.F2(d)[xc] = b2 - P.e2; } else R.F2(d)[xc] = o - P.e2;
     }
-    R.H(d)[j] = h;
+    R.H(d)[xc] = h;
     bt[(size_t)d * ql + j] = dd;
 }
 
@@ -468,6 +515,52 @@ __global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, c
     nw_backtrack(bt, ql, tl, cg_all + T.cg_off, cg_n + T.out_idx, s_bt, s_walk);
 }
 
+// The transposed case -- a long query against a short target (an insertion: ~50 reference bases of padding against the inserted
+// kilobases): thread t owns the target rows t, t+NT, ..., the rolling rows are indexed by row, the query bases come through the LDS
+// ring.  With the rows of such an event in ONE wavefront a diagonal costs a single-wave barrier; round 1 sent these events to
+// k_nw<3072, 1024>, where each of their ~2 000 diagonals paid a 16-wave barrier for a few dozen cells (7.3 ms per bench step).
+template <int RCAP, int NT>
+__global__ __launch_bounds__(NT) void k_nw_rows(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+                                                const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
+                                                const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
+                                                const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all,
+                                                uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
+{
+    constexpr int C = RCAP / NT;
+    constexpr int CH = 64;
+    constexpr int QB = 2 * RCAP;        // ring of query bases (power of two >= RCAP + CH)
+    __shared__ int32_t s_rows[11 * RCAP];
+    __shared__ uint8_t s_q[QB];
+    __shared__ uint8_t s_bt[NW_TD][NW_TC];
+    __shared__ int s_walk[8];
+    const NwTask T = tasks[blockIdx.x];
+    const uint32_t qw = word_off[pair_q[T.pair]], tw = word_off[pair_t[T.pair]];
+    const int lenq = read_len[pair_q[T.pair]], rev = hdr[T.pair].rev;
+    const int ql = T.ql, tl = T.tl, tid = threadIdx.x;
+    const bool two = P.q2 >= 0;
+    const NwRows R{s_rows, RCAP};
+    uint8_t *bt = bt_all + T.bt_off;
+    uint32_t tb[C];
+#pragma unroll
+    for (int m = 0; m < C; m++) { const int i = tid + m * NT; tb[m] = i < tl ? fsv_base_fwd(store, tw, T.ts + i) : 0u; }
+    for (int d = 0; d <= ql + tl - 2; d++) {
+        if (d % CH == 0) {
+            // columns d .. d+CH-1 enter the sweep during the next CH diagonals; columns below d-tl+1 have left it
+            for (int j = d + tid; j < min(d + CH, ql); j += NT) s_q[j & (QB - 1)] = (uint8_t)qbase(store, qw, lenq, rev, T.qs + j);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < C; m++) {
+            const int i = tid + m * NT, j = d - i;
+            if (i < tl && j >= 0 && j < ql) nw_cell<true>(R, d, i, j, tb[m], s_q[j & (QB - 1)], two, P, bt, ql);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) scores[T.out_idx] = R.H(ql + tl - 2)[tl - 1];
+    nw_backtrack(bt, ql, tl, cg_all + T.cg_off, cg_n + T.out_idx, s_bt, s_walk);
+}
+
 // Any query length: rolling rows in HBM, bases fetched per cell (events with queries above NW_LDS_Q bases: rare, slow path)
 __global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                                 const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
@@ -503,6 +596,9 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 struct AlnWs {
     DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, ev_packed, ev_count, tasks, bt, rows, cg, cg_n, scores, gaps, gap_shift, thin;
     fsv_aln_stats stats;
+    // the size classes of the event DP run side by side: a class is a handful of long-running blocks, never a full chip
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores, &gaps, &gap_shift, &thin}; }
 };
 
@@ -511,6 +607,8 @@ void aln_ws_free(fsv_ctx *ctx)
     AlnWs *w = (AlnWs *)ctx->aln_ws;
     if (!w) return;
     for (DevBuf *b : w->all()) if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < 3; i++) { if (w->side[i]) (void)hipStreamDestroy(w->side[i]); if (w->join[i]) (void)hipEventDestroy(w->join[i]); }
+    if (w->fork) (void)hipEventDestroy(w->fork);
     delete w;
     ctx->aln_ws = nullptr;
 }
@@ -611,10 +709,11 @@ int run_nw(fsv_ctx *ctx, AlnWs &W, const std::vector<NwTask> &tasks, uint64_t bt
     const size_t n = tasks.size();
     std::vector<uint32_t> order;
     order.reserve(n);
-    size_t cls_end[3];
-    for (int c = 0; c < 3; c++) {
+    // class 3: a short target side under a long query (insertions): the row-owning single-wave kernel
+    size_t cls_end[4];
+    for (int c = 0; c < 4; c++) {
         for (size_t i = 0; i < n; i++) {
-            const int cl = tasks[i].ql <= 256 ? 0 : tasks[i].ql <= NW_LDS_Q ? 1 : 2;
+            const int cl = tasks[i].ql <= 256 ? 0 : tasks[i].tl <= 256 ? 3 : tasks[i].ql <= NW_LDS_Q ? 1 : 2;
             if (cl == c) order.push_back((uint32_t)i);
         }
         cls_end[c] = order.size();
@@ -627,23 +726,44 @@ int run_nw(fsv_ctx *ctx, AlnWs &W, const std::vector<NwTask> &tasks, uint64_t bt
     TRY(ensure(ctx, W.cg, n * (size_t)ALN_CG_CAP * 4));
     TRY(ensure(ctx, W.cg_n, n * 4));
     TRY(ensure(ctx, W.scores, n * 4));
+    if (!W.fork) {
+        FSV_HIP(ctx, hipEventCreateWithFlags(&W.fork, hipEventDisableTiming));
+        for (int i = 0; i < 3; i++) {
+            FSV_HIP(ctx, hipStreamCreateWithFlags(&W.side[i], hipStreamNonBlocking));
+            FSV_HIP(ctx, hipEventCreateWithFlags(&W.join[i], hipEventDisableTiming));
+        }
+    }
+    // class c runs on its own stream between a fork and a join on the context's stream (class 0 stays on it)
+    FSV_HIP(ctx, hipEventRecord(W.fork, ctx->stream));
+    auto lane = [&](int c) -> hipStream_t { return c == 0 ? ctx->stream : W.side[c - 1]; };
+    bool used[4] = {false, false, false, false};
+    for (int c = 1; c < 4; c++)
+        if (cls_end[c] > cls_end[c - 1]) { used[c] = true; FSV_HIP(ctx, hipStreamWaitEvent(W.side[c - 1], W.fork, 0)); }
     if (cls_end[0])
-        hipLaunchKernelGGL((k_nw<256, 64>), dim3((uint32_t)cls_end[0]), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+        hipLaunchKernelGGL((k_nw<256, 64>), dim3((uint32_t)cls_end[0]), dim3(64), 0, lane(0), (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
                            (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (uint32_t *)W.cg.p, (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
-    if (cls_end[1] > cls_end[0])
-        hipLaunchKernelGGL((k_nw<NW_LDS_Q, 1024>), dim3((uint32_t)(cls_end[1] - cls_end[0])), dim3(1024), 0, ctx->stream, (const uint32_t *)W.store.p,
+    if (used[1])
+        hipLaunchKernelGGL((k_nw<NW_LDS_Q, 1024>), dim3((uint32_t)(cls_end[1] - cls_end[0])), dim3(1024), 0, lane(1), (const uint32_t *)W.store.p,
                            (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
                            (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + cls_end[0], (uint8_t *)W.bt.p, (uint32_t *)W.cg.p,
                            (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
-    if (cls_end[2] > cls_end[1])
-        hipLaunchKernelGGL(k_nw_any, dim3((uint32_t)(cls_end[2] - cls_end[1])), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p,
+    if (used[2])
+        hipLaunchKernelGGL(k_nw_any, dim3((uint32_t)(cls_end[2] - cls_end[1])), dim3(256), 0, lane(2), (const uint32_t *)W.store.p,
                            (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
                            (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + cls_end[1], (uint8_t *)W.bt.p, (int32_t *)W.rows.p, (uint32_t *)W.cg.p,
                            (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
+    if (used[3])
+        hipLaunchKernelGGL((k_nw_rows<256, 64>), dim3((uint32_t)(cls_end[3] - cls_end[2])), dim3(64), 0, lane(3), (const uint32_t *)W.store.p,
+                           (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
+                           (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + cls_end[2], (uint8_t *)W.bt.p, (uint32_t *)W.cg.p,
+                           (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
+    FSV_HIP(ctx, hipGetLastError());
+    for (int c = 1; c < 4; c++)
+        if (used[c]) { FSV_HIP(ctx, hipEventRecord(W.join[c - 1], W.side[c - 1])); FSV_HIP(ctx, hipStreamWaitEvent(ctx->stream, W.join[c - 1], 0)); }
     return FSV_OK;
 }
 
