@@ -27,7 +27,7 @@ assert WPATH_DTYPE.itemsize == 128
 
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final",
-                                         "min_contig_reads", "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later")]
+                                         "min_contig_reads", "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "partition")]
 
 
 class ReadSets(C.Structure):
@@ -39,7 +39,7 @@ SET_UNPHASED = 1
 # return / status codes of include/focalsv_hip.h
 OK, ENODEV, EINVAL, ENOMEM, EHIP, ECAP, EUNSUP = 0, -1, -2, -3, -4, -5, -6
 # set_status warning bits (FSV_W_*)
-W_MZ_TRUNC, W_ANCHOR_TRUNC, W_NO_LAYOUT, W_INS_EVENTS, W_WINDOW_KEPT, W_INTERNAL = 1, 2, 4, 8, 16, 32
+W_MZ_TRUNC, W_ANCHOR_TRUNC, W_NO_LAYOUT, W_INS_EVENTS, W_WINDOW_KEPT, W_INTERNAL, W_SITES = 1, 2, 4, 8, 16, 32, 64
 
 
 class Contigs(C.Structure):

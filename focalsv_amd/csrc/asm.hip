@@ -35,10 +35,10 @@ struct KTimes {
     void reset() { recs.clear(); used = 0; }
     ~KTimes() { for (auto e : pool) (void)hipEventDestroy(e); }
 };
-enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_COUNT,
+enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_PARTITION, KN_COUNT,
        ST_SKETCH = KN_COUNT, ST_CHAIN, ST_VERIFY, ST_PATH, ST_CONSENSUS, ST_FINAL };
 const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm", "k_rescue_accept", "k_path_fast", "k_path_dp", "k_consensus",
-                                        "k_repack", "k_exact", "k_stitch"};
+                                        "k_repack", "k_exact", "k_stitch", "k_partition"};
 
 // a stage: from construction to stop(), in stream order
 struct Span {
@@ -53,7 +53,7 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
        CT_MZ_LO = 10, CT_MZ_HI = 11, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, trans, read_flag, changed,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_vec, site_cursor, redo, site_lists, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -68,7 +68,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &trans, &read_flag, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_vec, &site_cursor, &redo, &site_lists, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -311,7 +311,7 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
     if (!p) return;
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
-    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0;
+    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0; p->partition = 1;
 }
 
 extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
@@ -323,6 +323,7 @@ extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
     p->win_rate_pm = 250; p->k_cap = FSV_K_WIDE; p->accept_err_pm = 300;   // two 10 % reads differ by ~20 %: k = 93 for a full window
     p->bw_rechain = 50;                         // corrected reads keep a 1-base indel every few kb
     p->w_later = 63;                            // after one round the reads are ~99 % accurate: sparser seeds keep a pair's anchors below 1 024
+    p->partition = 0;                           // coincident errors of 10 % reads would pass for alleles and split the set
     p->min_contig_reads = 2;                    // reads of 10-30 kb tile a 50 kb window with three or four uncontained reads: hifiasm's tip rule (4) would drop them
 }
 
@@ -465,13 +466,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     }
     TRY(ensure(ctx, W.warn, (size_t)B.n_reads * 4));
     FSV_HIP(ctx, hipMemsetAsync(W.warn.p, 0, (size_t)B.n_reads * 4, ctx->stream));
-    bool any_unphased = false;
-    if (sets->set_flags) {
-        std::vector<uint8_t> rf(B.n_reads, 0);
-        for (uint32_t s2 = 0; s2 < B.n_sets; s2++)
-            if (sets->set_flags[s2] & FSV_SET_UNPHASED) { any_unphased = true; for (uint32_t r = B.set_start[s2]; r < B.set_start[s2 + 1]; r++) rf[r] = 1; }
-        if (any_unphased) TRY(upload(ctx, W.read_flag, rf));
-    }
+    // set_flags (FSV_SET_UNPHASED) no longer changes anything here: the haplotype partition runs for every read of every set, as in hifiasm
 
     // minimizer slots stay where they are for the whole call (a read grows by a few bases at most when it is corrected): the
     // final pass can then keep the lists of reads the last round did not change
@@ -626,22 +621,50 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         TRY(ensure(ctx, W.changed, (size_t)B.n_reads * 4));
         FSV_HIP(ctx, hipMemsetAsync(W.changed.p, 0, (size_t)B.n_reads * 4, ctx->stream));
         C.changed = (uint32_t *)W.changed.p;
-        if (any_unphased && B.n_pairs) {
-            // unphased sets: mark the overlaps that carry the other allele at a heterozygous column, then take them out of
-            // the consensus (and, through is_match = 2, out of what the final pass accepts as verified)
-            TRY(ensure(ctx, W.trans, (size_t)B.n_pairs * 4));
-            FSV_HIP(ctx, hipMemsetAsync(W.trans.p, 0, (size_t)B.n_pairs * 4, ctx->stream));
-            hipLaunchKernelGGL(k_het, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, (const uint8_t *)W.read_flag.p, (uint32_t *)W.trans.p);
-            FSV_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_apply_trans, dim3(fsv_grid_for(B.n_pairs, 256)), dim3(256), 0, ctx->stream, (fsv_ovl *)W.ovl.p, (uint4 *)W.ovl_c.p,
-                               (const uint32_t *)W.trans.p, B.n_pairs);
-            FSV_HIP(ctx, hipGetLastError());
+        const bool partition = B.n_pairs && P.partition;
+        SiteArgs SA{};
+        SiteLists SL{};
+        if (partition) {
+            const size_t vec_cap = (size_t)B.n_pairs * 64 + (1u << 20);
+            TRY(ensure(ctx, W.site_cnt, (size_t)std::max(1u, n_gwin) * 4));
+            TRY(ensure(ctx, W.site_rec, (size_t)std::max(1u, n_gwin) * FSV_SITE_WIN_CAP * sizeof(uint2)));
+            TRY(ensure(ctx, W.site_vec, vec_cap));
+            TRY(ensure(ctx, W.site_cursor, 16));
+            TRY(ensure(ctx, W.redo, (size_t)B.n_reads * 4));
+            TRY(ensure(ctx, W.site_lists, (size_t)std::max(1u, n_gwin) * 8));
+            FSV_HIP(ctx, hipMemsetAsync(W.site_cursor.p, 0, 16, ctx->stream));
+            FSV_HIP(ctx, hipMemsetAsync(W.redo.p, 0, (size_t)B.n_reads * 4, ctx->stream));
+            SA.site_cnt = (uint32_t *)W.site_cnt.p; SA.site_rec = (uint2 *)W.site_rec.p; SA.vec = (int8_t *)W.site_vec.p;
+            SA.vec_cursor = (uint32_t *)W.site_cursor.p; SA.vec_cap = (uint32_t)std::min<size_t>(vec_cap, 0xfffffff0u);
+            SA.read_sites = (uint32_t *)W.redo.p;
+            SL.site_cnt = SA.site_cnt; SL.win_list = (uint32_t *)W.site_lists.p; SL.redo_list = SL.win_list + std::max(1u, n_gwin);
+            SL.win_n = (uint32_t *)W.site_cursor.p + 1;
         }
+        // consensus of every window; with the haplotype partition (K7) on, the windows that hold a candidate site are listed on the
+        // way, k_snp_sites / k_hap_partition take the overlaps with the other allele out (is_match 2 / 4: out of the consensus and,
+        // through that, out of what the final pass accepts as verified), and the reads that lost an overlap get their windows redone
         W.cons_rec.push_back(W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_gwin * (96 + 448)));
-        if (wide_bands) hipLaunchKernelGGL(k_consensus<FSV_EV_CAP_WIDE>, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
-        else hipLaunchKernelGGL(k_consensus<FSV_EV_CAP>, dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin);
+        if (wide_bands) {
+            if (partition) hipLaunchKernelGGL((k_consensus<FSV_EV_CAP_WIDE, 1>), dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, SL);
+            else hipLaunchKernelGGL((k_consensus<FSV_EV_CAP_WIDE, 0>), dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, SL);
+        } else {
+            if (partition) hipLaunchKernelGGL((k_consensus<FSV_EV_CAP, 1>), dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, SL);
+            else hipLaunchKernelGGL((k_consensus<FSV_EV_CAP, 0>), dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, SL);
+        }
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);
+        if (partition) {
+            const uint32_t grid_l = std::min<uint32_t>(std::max(1u, n_gwin), (uint32_t)ctx->n_cu * 16);
+            W.kt.begin(ctx, KN_PARTITION, (uint64_t)B.n_reads * 4);
+            hipLaunchKernelGGL(k_snp_sites, dim3(grid_l), dim3(64), 0, ctx->stream, C, SA, SL);
+            FSV_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_hap_partition, dim3(B.n_reads), dim3(64), 0, ctx->stream, C, SA, (fsv_ovl *)W.ovl.p, (uint4 *)W.ovl_c.p, SL);
+            FSV_HIP(ctx, hipGetLastError());
+            if (wide_bands) hipLaunchKernelGGL(k_consensus_redo<FSV_EV_CAP_WIDE>, dim3(grid_l), dim3(64), 0, ctx->stream, C, SL);
+            else hipLaunchKernelGGL(k_consensus_redo<FSV_EV_CAP>, dim3(grid_l), dim3(64), 0, ctx->stream, C, SL);
+            FSV_HIP(ctx, hipGetLastError());
+            W.kt.end(ctx);
+        }
         hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
                            (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p);
         FSV_HIP(ctx, hipGetLastError());
@@ -790,7 +813,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     for (uint32_t s = 0; s < B.n_sets && rc_out == FSV_OK; s++) {
         const uint32_t r0 = B.set_start[s], ns = B.set_start[s + 1] - r0;
         int32_t st = 0;
-        for (uint32_t r = r0; r < r0 + ns; r++) st |= (int32_t)(hwarn[r] & (FSV_W_MZ_TRUNC | FSV_W_ANCHOR_TRUNC | FSV_W_INS_EVENTS | FSV_W_WINDOW_KEPT | FSV_W_INTERNAL));
+        for (uint32_t r = r0; r < r0 + ns; r++) st |= (int32_t)(hwarn[r] & (FSV_W_MZ_TRUNC | FSV_W_ANCHOR_TRUNC | FSV_W_INS_EVENTS | FSV_W_WINDOW_KEPT | FSV_W_INTERNAL | FSV_W_SITES));
         if (ns == 0) { out->set_status[s] = st; continue; }
         if (lay[s].fallback) st |= FSV_W_NO_LAYOUT;
         for (auto &c : lay[s].contigs) {

@@ -1371,8 +1371,18 @@ __global__ void k_gwin_tab(const uint32_t *__restrict__ gwin_read, const uint32_
 }
 
 // EVC: insertion events a window can hold (HiFi at 30x: ~8 -> FSV_EV_CAP; ONT-profile reads: hundreds -> FSV_EV_CAP_WIDE)
-template <int EVC>
-__global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
+// MODE 0: every window.  MODE 1: every window, and a window with a column that split_sub_list would keep as a site of the
+// haplotype partition is marked (site_cnt[gw] = FSV_SITE_MARK) -- the consensus written here is then provisional: k_snp_sites and
+// k_hap_partition run next, and the windows of a read that lost overlaps to the partition are redone.  MODE 2: that redo.
+#define FSV_SITE_MARK 0xffffffffu
+struct SiteLists {
+    uint32_t *site_cnt;        // per grid window: FSV_SITE_MARK after k_consensus<., 1>, the number of kept sites after k_snp_sites
+    uint32_t *win_list;        // marked windows, [0] of win_n
+    uint32_t *redo_list;       // windows of the reads that lost an overlap to the partition
+    uint32_t *win_n;           // {marked windows, redo windows}
+};
+template <int EVC, int MODE>
+__device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32_t gw, const SiteLists &L)
 {
     // Per-column votes of one 375-bp grid window.  A match op votes for the backbone's own base, so a lane (= one
     // overlap) only contributes (a) its coverage interval, through a difference array, and (b) its deviations --
@@ -1388,8 +1398,6 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     __shared__ uint32_t s_xraw[28];                // raw store words covering x[gs-16 .. gs+glen+16)
     __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
-    const uint32_t gw = blockIdx.x;
-    if (gw >= n_gwin) return;
     const uint4 gt = A.gwin_tab[gw];
     const uint32_t r = gt.x, pbase = gt.y, n_ovl = gt.z;
     const int g = (int)gt.w;
@@ -1501,11 +1509,27 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
     const bool verbatim = s_cover < 3u || s_anydev == 0u;
     if (s_evn > (uint32_t)EVC && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
     int arrived = before;
-    bool differs = false;
+    bool differs = false, site = false;
     for (int c = c0; c < c1; c++) {
         arrived += s_cov[c];
         const uint32_t own = XB(gs + c);
         uint8_t nb = 0;
+        if (MODE == 1 && !verbatim) {
+            // split_sub_list (Correct.cpp:5804) on the same tallies, as in k_snp_sites
+            int oa[4], occ1 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) { oa[b] = (int)CNT_GET(c, (uint32_t)b); occ1 += oa[b]; }
+            if (occ1 > 1) {
+                const int occ2 = (int)CNT_GET(c, 4u), occ0 = arrived - occ1 - occ2;
+                int mx = occ2, mi = -1;
+#pragma unroll
+                for (int b = 0; b < 4; b++) if (oa[b] > mx) { mx = oa[b]; mi = b; }
+                bool ok = occ0 != 0 && mi >= 0 && mx > 1;
+#pragma unroll
+                for (int b = 0; b < 4; b++) if (oa[b] == mx && b != mi) ok = false;
+                if (ok && (double)(occ0 + 1 + mx) / (double)(arrived + 1) >= 0.95 && (double)mx / (double)(arrived + 1 - (occ0 + 1)) >= 0.70) site = true;
+            }
+        }
         if (verbatim) { s_out[c][1] = (uint8_t)own; nb = 1; }
         else {
             const int p = gs + c;
@@ -1546,6 +1570,13 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
         if (nb != 1 || s_out[c][1] != (uint8_t)own) differs = true;
     }
     if (differs && A.changed) A.changed[r] = 1u;
+    if (MODE == 1) {
+        const bool any_site = __ballot(site) != 0ull;
+        if (lane == 0) {
+            L.site_cnt[gw] = any_site ? FSV_SITE_MARK : 0u;
+            if (any_site) L.win_list[atomicAdd(&L.win_n[0], 1u)] = gw;
+        }
+    }
     __syncthreads();
     uint32_t mine = 0;
     for (int c = c0; c < c1; c++) mine += s_out[c][0];
@@ -1565,43 +1596,78 @@ __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin)
 #undef CNT_GET
 }
 
-// ------------------------------------------------------------------------------------------------ k_het / k_apply_trans
-// Unphased read sets (FSV_SET_UNPHASED): a much reduced partition_overlaps_advance (Correct.cpp:7127-7206).  Same tally as
-// k_consensus over one grid window; a column is heterozygous when at least FSV_HET_MIN overlapping reads agree with the
-// backbone and at least FSV_HET_MIN agree on one other base; an overlap whose path shows that other base there comes from the
-// other haplotype.  It is marked (trans[pair slot]) and k_apply_trans takes it out of the consensus (is_match = 2, as hifiasm
-// labels such overlaps), so each haplotype's reads are corrected by their own kind and assemble into their own contig.
-#define FSV_HET_MIN 3
-__global__ __launch_bounds__(64) void k_het(ConsArgs A, uint32_t n_gwin, const uint8_t *__restrict__ read_flag, uint32_t *__restrict__ trans)
+template <int EVC, int MODE>
+__global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin, SiteLists L)
 {
-    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][3];  // 16 bits each: A C | G T votes that differ from the backbone | deleted, -
+    if (blockIdx.x < n_gwin) consensus_window<EVC, MODE>(A, blockIdx.x, L);
+}
+
+// the redo: a fixed grid walks the list k_hap_partition left
+template <int EVC>
+__global__ __launch_bounds__(64) void k_consensus_redo(ConsArgs A, SiteLists L)
+{
+    const uint32_t n = L.win_n[1];
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        consensus_window<EVC, 0>(A, L.redo_list[i], L);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_snp_sites / k_hap_partition
+// partition_overlaps_advance (Correct.cpp:7127-7206), for every read of every set as hifiasm runs it (it has no notion of a phased
+// input: in a phased set the "heterozygous" columns are coincident read errors, and the few overlaps set aside by them are
+// what makes the last corrected reads equal hifiasm's).  Two kernels:
+//   k_snp_sites     one wavefront per 375-bp grid window: columns where at least two overlaps show a mismatch are candidate
+//                   sites (cluster_advance :5585, markSNP_detail :4998); split_sub_list :5804 keeps a site when one alternative
+//                   base dominates; every overlap covering a kept site leaves 0 (backbone's base), 1 (that base) or 2 (else) in
+//                   the site's vector (InsertSNPVector, Correct.h:630).  Window cigars only: calculate_boundary_cigars :2310
+//                   is not restated.
+//   k_hap_partition one wavefront per read: generate_haplotypes_DP :6677 -- sites beside another site dropped, overlaps that are
+//                   informative / not / informative again set aside (is_match 4), longest chains of mutually compatible sites
+//                   enumerated (Preorder_Merge_Advance_Repeat :6233), a chain with support for both alleles
+//                   (if_snp_vector_useful :6356) makes the overlaps with the other allele trans (is_match 2).
+// oracle/asm.c:partition_read is the same algorithm, statement by statement.
+#define FSV_SITE_WIN_CAP 16        // kept sites per grid window
+#define FSV_SITE_READ_CAP 256      // kept sites per read
+#define FSV_K7_GROUP_CAP 100000    // chains enumerated per read (the enumeration is exponential in ties)
+struct SiteArgs {
+    uint32_t *site_cnt;            // per grid window
+    uint2 *site_rec;               // per grid window x FSV_SITE_WIN_CAP: {position in the read | homopolymer << 31, byte offset of the vector}
+    int8_t *vec;                   // vector pool: one byte per overlap of the read, -1 = does not cover the site
+    uint32_t *vec_cursor;          // bytes handed out
+    uint32_t vec_cap;
+    uint32_t *read_sites;          // per read: some window of it kept a site
+};
+
+__device__ __forceinline__ void snp_sites_window(const ConsArgs &A, const uint32_t gw, const SiteArgs &S)
+{
+    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][3];  // 16 bits each: A C | G T mismatch votes | x base without partner, -
     __shared__ int32_t s_cov[FSV_WINDOW + 2];
     __shared__ uint32_t s_path[64][27];
-    __shared__ uint8_t s_het[FSV_WINDOW + 1];      // 0, or 1 + the other allele of a heterozygous column
-    __shared__ uint32_t s_cover, s_any;
+    __shared__ uint8_t s_alt[FSV_WINDOW + 1];      // 0, or 1 + the dominating other base of a kept site
+    __shared__ uint8_t s_sidx[FSV_WINDOW + 1];     // kept site -> its index in the window
+    __shared__ uint32_t s_cover, s_nsite, s_vbase;
     __shared__ uint32_t s_xraw[28];
     __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
-    const uint32_t gw = blockIdx.x;
-    if (gw >= n_gwin) return;
     const uint4 gt = A.gwin_tab[gw];
     const uint32_t r = gt.x, pbase = gt.y, n_ovl = gt.z;
-    if (!read_flag[r]) return;
     const int g = (int)gt.w;
     const int xlen = A.read_len[r];
     const int gs = g * FSV_WINDOW, glen = min(FSV_WINDOW, xlen - gs);
     const uint32_t xw = A.word_off[r];
     const int xw0 = (gs >> 4) - 1;
+    if (lane == 0) S.site_cnt[gw] = 0;
     if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((xlen + 15) >> 4)) ? A.store[xw + wi] : 0u; }
     for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
-    for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_het[i] = 0;
-    if (lane == 0) { s_cover = 0; s_any = 0; }
+    for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_alt[i] = 0;
+    if (lane == 0) { s_cover = 0; s_nsite = 0; }
     __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
 #define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
 #define CNT_GET(c, b) ((s_cnt[(c)][(b) >> 1] >> (((b) & 1u) << 4)) & 0xffffu)
-#define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
+    const uint32_t vstride = (n_ovl + 3u) & ~3u;
     for (int pass = 0; pass < 2; pass++) {
         for (uint32_t oi = lane; oi < n_ovl; oi += 64) {
             const uint4 oc = A.ovl_c[pbase + oi];
@@ -1622,22 +1688,35 @@ __global__ __launch_bounds__(64) void k_het(ConsArgs A, uint32_t n_gwin, const u
 #pragma unroll
                 for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
                 const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
-                bool other = false;
-                for (int p = 0; p < plen;) {
-                    const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1);
-                    if (rest == 0u) { p = ((p >> 4) + 1) << 4; continue; }
-                    const uint32_t op = rest & 3u;
-                    const int xp = xs + p - n2;
-                    if (op == 2u) { n2++; p++; continue; }
-                    if (op == 3u) { if (pass == 0) CNT_ADD(xp, 4u); n3++; }
-                    else if (op == 1u) {
-                        const uint32_t yb = fsv_base_at(A.store, y_word, y_len, y_rev, ry_start + p - n3);
-                        if (pass == 0) CNT_ADD(xp, yb);
-                        else if (s_het[xp] == yb + 1u) other = true;
+                if (pass == 0) {
+                    for (int p = 0; p < plen;) {
+                        const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1);
+                        if (rest == 0u) { p = ((p >> 4) + 1) << 4; continue; }
+                        const uint32_t op = rest & 3u;
+                        const int xp = xs + p - n2;
+                        if (op == 2u) { n2++; p++; continue; }
+                        if (op == 3u) { CNT_ADD(xp, 4u); n3++; }
+                        else if (op == 1u) CNT_ADD(xp, fsv_base_at(A.store, y_word, y_len, y_rev, ry_start + p - n3));
+                        p++;
                     }
-                    p++;
+                } else {
+                    // every column: the kept sites want the matching overlaps too
+                    for (int p = 0; p < plen; p++) {
+                        const uint32_t op = (s_path[lane][p >> 4] >> ((p & 15) << 1)) & 3u;
+                        const int xp = xs + p - n2;
+                        if (op == 2u) { n2++; continue; }
+                        const uint32_t alt = s_alt[xp];
+                        if (alt) {
+                            int8_t v = 0;
+                            if (op == 3u) v = 2;
+                            else if (op == 1u) v = fsv_base_at(A.store, y_word, y_len, y_rev, ry_start + p - n3) + 1u == alt ? 1 : 2;
+                            S.vec[s_vbase + (uint32_t)s_sidx[xp] * vstride + oi] = v;
+                        }
+                        if (op == 3u) n3++;
+                    }
                 }
-                if (pass == 1 && other) trans[pbase + oi] = 1u;
+            } else if (pass == 1) {
+                for (int c = xs; c < xs + plen; c++) if (s_alt[c]) S.vec[s_vbase + (uint32_t)s_sidx[c] * vstride + oi] = 0;
             }
             if (pass == 0) {
                 const int xcols = plen - n2;   // clean paths: n2 = 0
@@ -1646,43 +1725,251 @@ __global__ __launch_bounds__(64) void k_het(ConsArgs A, uint32_t n_gwin, const u
             }
         }
         __syncthreads();
-        if (pass == 1 || s_cover < 3u) break;
+        if (pass == 1 || s_cover == 0u) break;
         // arrived[c] = prefix sum of the difference array; each lane owns the contiguous columns [c0, c1)
         const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
         int run = 0;
         for (int c = c0; c < c1; c++) run += s_cov[c];
         s_scan[lane] = (uint32_t)run;
         __syncthreads();
-        int arrived = 0;
+        int arrived = 0, mine = 0;
         for (int i = 0; i < lane; i++) arrived += (int)s_scan[i];
-        bool any = false;
         for (int c = c0; c < c1; c++) {
             arrived += s_cov[c];
-            const uint32_t own = XB(gs + c);
-            int dev = (int)CNT_GET(c, 4u), alt = -1, altc = -1;
+            // split_sub_list: occ_0 overlaps with the backbone's base, occ_1 with another base, occ_2 without a partner for it
+            int oa[4], occ1 = 0, mx, mi = -1;
+            const int occ2 = (int)CNT_GET(c, 4u);
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int v = (int)CNT_GET(c, (uint32_t)b);
-                dev += v;
-                if ((uint32_t)b != own && v > altc) { altc = v; alt = b; }
-            }
-            if (altc >= FSV_HET_MIN && arrived - dev >= FSV_HET_MIN) { s_het[c] = (uint8_t)(alt + 1); any = true; }
+            for (int b = 0; b < 4; b++) { oa[b] = (int)CNT_GET(c, (uint32_t)b); occ1 += oa[b]; }
+            if (occ1 <= 1) continue;               // hap->flag > snp_threshold: at least two mismatches
+            const int occ0 = arrived - occ1 - occ2, total = arrived;
+            mx = occ2;
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (oa[b] > mx) { mx = oa[b]; mi = b; }
+            if (occ0 == 0 || mi < 0 || mx <= 1) continue;
+            bool tie = false;
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (oa[b] == mx && b != mi) tie = true;
+            if (tie) continue;
+            if ((double)(occ0 + 1 + mx) / (double)(total + 1) < 0.95) continue;
+            if ((double)mx / (double)(total + 1 - (occ0 + 1)) < 0.70) continue;
+            s_alt[c] = (uint8_t)(mi + 1);
+            mine++;
         }
-        if (any) s_any = 1u;
+        s_scan[lane] = (uint32_t)mine;
         __syncthreads();
-        if (!s_any) break;
+        int first = 0, all = 0;
+        for (int i = 0; i < 64; i++) { if (i < lane) first += (int)s_scan[i]; all += (int)s_scan[i]; }
+        if (all == 0) break;
+        if (all > FSV_SITE_WIN_CAP) { if (lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_SITES); break; }
+        if (lane == 0) {
+            const uint32_t off = atomicAdd(S.vec_cursor, (uint32_t)all * vstride);
+            s_vbase = off;
+            s_nsite = off + (uint32_t)all * vstride <= S.vec_cap ? (uint32_t)all : 0u;
+            if (!s_nsite) atomicOr(&A.warn[r], (uint32_t)FSV_W_SITES);
+        }
+        __syncthreads();
+        if (!s_nsite) break;
+        for (uint32_t i = lane; i < (uint32_t)all * vstride; i += 64) S.vec[s_vbase + i] = -1;
+        for (int c = c0, k = first; c < c1; c++) {
+            if (!s_alt[c]) continue;
+            s_sidx[c] = (uint8_t)k;
+            const int p = gs + c;
+            const uint32_t own = XB(p);
+            const bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < xlen && XB(p + 1) == own);
+            S.site_rec[(size_t)gw * FSV_SITE_WIN_CAP + k] = make_uint2((uint32_t)p | (homo ? 0x80000000u : 0u), s_vbase + (uint32_t)k * vstride);
+            k++;
+        }
+        if (lane == 0) { S.site_cnt[gw] = (uint32_t)all; S.read_sites[r] = 1u; }
+        __threadfence_block();
+        __syncthreads();
     }
 #undef XB
 #undef CNT_ADD
 #undef CNT_GET
-#undef OP
 }
 
-__global__ void k_apply_trans(fsv_ovl *__restrict__ ovl, uint4 *__restrict__ ovl_c, const uint32_t *__restrict__ trans, uint32_t n_pairs)
+// the windows k_consensus<., 1> marked (a fixed grid walks the list)
+__global__ __launch_bounds__(64) void k_snp_sites(ConsArgs A, SiteArgs S, SiteLists L)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs || !trans[p]) return;
-    if (ovl[p].valid && ovl[p].is_match == 1) { ovl[p].is_match = 2; ovl_c[p].z &= 0x7fffffffu; }
+    const uint32_t n = L.win_n[0];
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        snp_sites_window(A, L.win_list[i], S);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_hap_partition(ConsArgs A, SiteArgs S, fsv_ovl *__restrict__ ovl, uint4 *__restrict__ ovl_c, SiteLists L)
+{
+    __shared__ int32_t s_pos[FSV_SITE_READ_CAP];
+    __shared__ uint32_t s_voff[FSV_SITE_READ_CAP];
+    __shared__ uint16_t s_max[FSV_SITE_READ_CAP], s_order[FSV_SITE_READ_CAP];
+    __shared__ uint32_t s_bt[FSV_SITE_READ_CAP][FSV_SITE_READ_CAP / 32];   // predecessors on a longest chain, as a bit set
+    __shared__ uint16_t s_buf[FSV_SITE_READ_CAP], s_cur[FSV_SITE_READ_CAP]; // the chain being walked; per depth, the next predecessor to try
+    __shared__ uint8_t s_visit[FSV_SITE_READ_CAP], s_keep[FSV_SITE_READ_CAP];
+    __shared__ uint32_t s_n;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t s_redo;
+    const uint32_t r = blockIdx.x;
+    if (r >= A.n_reads || !S.read_sites[r]) return;
+    const uint32_t g0 = A.gwin_off[r], g1 = A.gwin_off[r + 1];
+    if (g0 == g1) return;
+    if (lane == 0) s_redo = 0;
+    const uint4 gt = A.gwin_tab[g0];
+    const uint32_t pbase = gt.y, n_ovl = gt.z;
+    // the read's kept sites in position order
+    if (lane == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t gb = g0; gb < g1; gb += 64) {
+        const uint32_t gw = gb + lane;
+        const uint32_t c = gw < g1 ? S.site_cnt[gw] : 0u;
+        uint32_t incl = c;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+        const uint32_t base = s_n + incl - c;
+        for (uint32_t k = 0; k < c; k++)
+            if (base + k < FSV_SITE_READ_CAP) { const uint2 rec = S.site_rec[(size_t)gw * FSV_SITE_WIN_CAP + k]; s_pos[base + k] = (int32_t)rec.x; s_voff[base + k] = rec.y; }
+        __syncthreads();
+        if (lane == 63) s_n = base + c;
+        __syncthreads();
+    }
+    int nS = (int)s_n;
+    if (nS == 0) return;
+    if (nS > FSV_SITE_READ_CAP) { if (lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_SITES); return; }
+    // a site directly beside another one is dropped
+    if (nS > 1) {
+        for (int j = lane; j < nS; j += 64) {
+            const int p = s_pos[j] & 0x7fffffff;
+            const bool left = j > 0 && p == (s_pos[j - 1] & 0x7fffffff) + 1, right = j + 1 < nS && p + 1 == (s_pos[j + 1] & 0x7fffffff);
+            s_keep[j] = !(left || right);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int m = 0;
+            for (int j = 0; j < nS; j++) if (s_keep[j]) { s_pos[m] = s_pos[j]; s_voff[m] = s_voff[j]; m++; }
+            s_n = (uint32_t)m;
+        }
+        __syncthreads();
+        nS = (int)s_n;
+        if (nS == 0) return;
+    }
+    // informative, not informative, informative again: the overlap is set aside
+    for (uint32_t i = lane; i < n_ovl; i += 64) {
+        if (!(ovl_c[pbase + i].z >> 31)) continue;
+        int st = -1;
+        for (int j = 0; j < nS; j++) {
+            const int8_t v = S.vec[s_voff[j] + i];
+            const bool inf = v == 0 || v == 1;
+            if (st == -1) { if (inf) st = 0; }
+            else if (st == 0) { if (!inf) st = 2; }
+            else if (inf) { st = 3; break; }
+        }
+        if (st == 3) {
+            for (int j = 0; j < nS; j++) S.vec[s_voff[j] + i] = 2;
+            ovl[pbase + i].is_match = 4;
+            ovl_c[pbase + i].z &= 0x7fffffffu;
+            s_redo = 1u;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // longest chains of mutually compatible sites
+    for (int i = 0; i < nS; i++) {
+        if (lane < FSV_SITE_READ_CAP / 32) s_bt[i][lane] = 0;
+        int best = 1;
+        for (int j = 0; j < i; j++) {
+            bool bad = false;
+            for (uint32_t o = lane; o < n_ovl; o += 64) {
+                const int8_t a = S.vec[s_voff[i] + o], b = S.vec[s_voff[j] + o];
+                if (a != b && (a == 0 || a == 1) && (b == 0 || b == 1)) bad = true;
+            }
+            if (__ballot(bad)) continue;
+            const int cand = (int)s_max[j] + 1;
+            if (cand > best) {
+                best = cand;
+                if (lane < FSV_SITE_READ_CAP / 32) s_bt[i][lane] = 0;
+            }
+            if (cand == best && lane == 0) s_bt[i][j >> 5] |= 1u << (j & 31);
+            __syncthreads();
+        }
+        if (lane == 0) { s_max[i] = (uint16_t)best; s_visit[i] = 0; }
+        __syncthreads();
+    }
+    // longest first, ties in site order (a stable sort, as glibc's qsort is for arrays this small)
+    for (int i = lane; i < nS; i += 64) {
+        int rank = 0;
+        for (int j = 0; j < nS; j++) rank += (s_max[j] > s_max[i]) || (s_max[j] == s_max[i] && j < i);
+        s_order[rank] = (uint16_t)i;
+    }
+    __syncthreads();
+    uint32_t n_groups = 0;
+    for (int oi = 0; oi < nS; oi++) {
+        const int root = s_order[oi];
+        if (s_visit[root]) continue;          // uniform: s_visit is only written between barriers
+        // depth-first over the predecessor sets, ascending site index (Preorder_Merge_Advance_Repeat)
+        int depth = 0;
+        if (lane == 0) { s_buf[0] = (uint16_t)root; s_cur[0] = 0; s_visit[root] = 1; }
+        __syncthreads();
+        while (depth >= 0) {
+            const int id = s_buf[depth];
+            bool leaf = true;
+            for (int w = 0; w < FSV_SITE_READ_CAP / 32; w++) if (s_bt[id][w]) leaf = false;
+            if (leaf) {
+                if (n_groups <= FSV_K7_GROUP_CAP) {
+                    // process_repeat_snps for the chain s_buf[0 .. depth]: first informative entry of every overlap
+                    const int plen = depth + 1;
+                    int occ0 = 0, occ1 = 0;
+                    for (uint32_t ob = 0; ob < n_ovl; ob += 64) {
+                        const uint32_t o = ob + lane;
+                        int8_t rv = -1;
+                        if (o < n_ovl) for (int k = 0; k < plen && rv == -1; k++) { const int8_t v = S.vec[s_voff[s_buf[k]] + o]; if (v == 0 || v == 1) rv = v; }
+                        occ0 += __popcll(__ballot(rv == 0));
+                        occ1 += __popcll(__ballot(rv == 1));
+                    }
+                    bool useful = false;
+                    if (occ0 && occ1) {
+                        const double low = (double)(occ0 + occ1) * 0.3;
+                        if ((double)occ1 >= low && (double)occ0 >= low) useful = true;
+                        else if (occ1 >= 5 && occ0 >= 5) useful = true;
+                        else if (occ1 >= 3 && occ0 >= 3 && plen >= 2) {
+                            int far = 0;
+                            for (int k = 0; k < plen; k++) {
+                                const int cur = s_pos[s_buf[k]] & 0x7fffffff;
+                                bool nearby = false;
+                                if (k > 0 && (s_pos[s_buf[k - 1]] & 0x7fffffff) - cur < 10) nearby = true;
+                                if (k + 1 < plen && cur - (s_pos[s_buf[k + 1]] & 0x7fffffff) < 10) nearby = true;
+                                if (!nearby) far++;
+                            }
+                            useful = far > 0;
+                        }
+                    }
+                    if (useful)
+                        for (uint32_t o = lane; o < n_ovl; o += 64) {
+                            int8_t rv = -1;
+                            for (int k = 0; k < plen && rv == -1; k++) { const int8_t v = S.vec[s_voff[s_buf[k]] + o]; if (v == 0 || v == 1) rv = v; }
+                            if (rv == 1 && (ovl_c[pbase + o].z >> 31)) { ovl[pbase + o].is_match = 2; ovl_c[pbase + o].z &= 0x7fffffffu; s_redo = 1u; }
+                        }
+                    n_groups++;
+                }
+                depth--;
+                continue;
+            }
+            // next predecessor of id at or after s_cur[depth]
+            int nxt = -1;
+            for (int j = s_cur[depth]; j < id; j++) if (s_bt[id][j >> 5] >> (j & 31) & 1u) { nxt = j; break; }
+            __syncthreads();
+            if (nxt < 0 || n_groups > FSV_K7_GROUP_CAP) { depth--; continue; }
+            if (lane == 0) { s_cur[depth] = (uint16_t)(nxt + 1); s_buf[depth + 1] = (uint16_t)nxt; s_cur[depth + 1] = 0; s_visit[nxt] = 1; }
+            __syncthreads();
+            depth++;
+        }
+        __syncthreads();
+    }
+    // a read that lost an overlap: its windows get their consensus again
+    if (s_redo) {
+        uint32_t base = lane == 0 ? atomicAdd(&L.win_n[1], g1 - g0) : 0u;
+        base = __shfl(base, 0);
+        for (uint32_t i = lane; i < g1 - g0; i += 64) L.redo_list[base + i] = g0 + i;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_newlen / k_repack

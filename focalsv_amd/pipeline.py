@@ -24,7 +24,8 @@ from .readsets import PackedBatch, pack_sets
 log = logging.getLogger("focalsv_amd")
 
 _SET_WARNINGS = {1: "minimizers truncated", 2: "anchors truncated", 4: "no layout (no contig, as hifiasm)", 8: "consensus insertion events dropped",
-                 16: "a corrected window kept uncorrected", 32: "internal minimizer slot overflow"}
+                 16: "a corrected window kept uncorrected", 32: "internal minimizer slot overflow",
+                 64: "haplotype partition skipped for a window / read with too many candidate sites"}
 
 
 def describe_set_status(st: int) -> str:

@@ -160,6 +160,8 @@ typedef struct fsv_asm_params {
     int32_t accept_err_pm;    /* an overlap is used when its error rate is at most this / 1000: 30 (Correct.cpp:725) */
     int32_t bw_rechain;       /* indel budget per mille when the final pass re-chains a pair without an exact overlap: 1 (max_ov_diff_final 0.001) */
     int32_t w_later;          /* minimizer window from the second correction round on; 0 = w throughout (hifiasm) */
+    int32_t partition;        /* 1: haplotype partition of every read's overlaps before the consensus, as hifiasm (partition_overlaps_advance,
+                               * Correct.cpp:7127); 0: off (the ONT profile: at 10 % error coincident errors pass for alleles) */
 } fsv_asm_params;
 void fsv_asm_default_params(fsv_asm_params *p);
 /* ONT-profile reads (BASELINE configs[4]: ~10 % error): k = 15, w = 15 without homopolymer compression (a 30 kb read then has ~3 750 minimizers: below the 4 096 a list holds), chain indel budget 0.15 / 0.05,
@@ -212,6 +214,8 @@ typedef struct fsv_contigs {
 #define FSV_W_INS_EVENTS   8  /* a consensus window saw more inserted-base events than its buffer holds; the extra votes were dropped */
 #define FSV_W_WINDOW_KEPT 16  /* a corrected window would have outgrown its slot; the read keeps that window uncorrected */
 #define FSV_W_INTERNAL    32  /* a minimizer slot overflowed (cannot happen: one minimizer per base at most) */
+#define FSV_W_SITES       64  /* haplotype partition: more than 16 candidate sites in a window or 256 in a read (or the site pool ran out);
+                                 * that window's sites / that read's partition were skipped */
 
 /* capacity needed for fsv_contigs.seq / contig count for these read sets */
 int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap);

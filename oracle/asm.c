@@ -475,11 +475,7 @@ static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ov
 }
 
 /* consensus of read q given all accepted overlaps; returns new length, writes into out (cap >= 2*len+64) */
-/* trans != NULL: no output; instead the overlaps that carry the other allele at a heterozygous column of q are marked
- * (the haplotype partition of an unphased read set, a much reduced partition_overlaps_advance, Correct.cpp:7127-7206): a column
- * is heterozygous when at least ORC_HET_MIN overlapping reads agree with q and at least ORC_HET_MIN agree on one other base. */
-#define ORC_HET_MIN 3
-static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, const orc_win *W, char *out, uint8_t *trans)
+static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, const orc_win *W, char *out)
 {
     const char *x = R->seq[q];
     int xlen = R->len[q], nwin = (xlen + ORC_WINDOW - 1) / ORC_WINDOW, g, i, outn = 0;
@@ -544,36 +540,6 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
                 xp++; p++;
             }
         }
-        if (trans) {
-            uint8_t het[ORC_WINDOW + 1];
-            int any = 0;
-            if (cover < 3) continue;
-            for (c = 0; c < glen; c++) {
-                int own = base2(x[gs + c]), b, alt = -1;
-                for (b = 0; b < 4; b++) if (b != own && (alt < 0 || cnt[c][b] > cnt[c][alt])) alt = b;
-                het[c] = (cnt[c][alt] >= ORC_HET_MIN && cnt[c][own] >= ORC_HET_MIN) ? (uint8_t)(alt + 1) : 0;
-                any |= het[c];
-            }
-            if (!any) continue;
-            for (i = o0; i < o1; i++) { /* the same walk again: who shows the other allele at a heterozygous column */
-                const orc_ovl *o = &ov[i];
-                const orc_win *w;
-                const char *y = R->seq[o->t];
-                int ylen = R->len[o->t], j = g - o->x_s / ORC_WINDOW, xp, yp, p;
-                if (o->is_match != 1 || j < 0 || j >= o->n_win) continue;
-                w = &W[o->first_win + j];
-                if (w->err <= 0) continue;
-                xp = w->x_start - gs; yp = w->ry_start;
-                for (p = 0; p < w->path_len; p++) {
-                    int op = w->path[p];
-                    if (op == 2) { yp++; continue; }
-                    if (op == 1 && het[xp] && base2(ybase(y, ylen, o->rev, yp)) + 1 == het[xp]) trans[i] = 1;
-                    if (op != 3) yp++;
-                    xp++;
-                }
-            }
-            continue;
-        }
         if (cover < 3) { /* MIN_COVERAGE_THRESHOLD: copy verbatim */
             memcpy(out + outn, x + gs, (size_t)glen); outn += glen;
             continue;
@@ -610,6 +576,214 @@ static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, co
     return outn;
 }
 
+/* ---------------------------------------------------------------- S7a: haplotype partition of the overlaps of read q
+ * partition_overlaps_advance (Correct.cpp:7127-7206) restated: (1) per grid window, columns where at least two overlaps show a
+ * mismatch are candidate sites and every overlap covering one leaves an evidence (same base / other base / x base without
+ * partner) -- cluster_advance :5585-5738, markSNP_detail :4998, addSNPtohaplotype_details :5247 (window cigars only: the
+ * re-aligned junction cigars of calculate_boundary_cigars :2310 are not restated); (2) split_sub_list :5804-5910 keeps a site
+ * when one alternative base dominates; (3) generate_haplotypes_DP :6677-6913: sites next to another site are dropped, an overlap
+ * that is informative, then not, then informative again is set aside (is_match 4), the longest chains of mutually compatible
+ * site vectors are enumerated (Preorder_Merge_Advance_Repeat :6233) and a chain whose two alleles both have support
+ * (if_snp_vector_useful :6356) turns the overlaps carrying the other allele into trans overlaps (is_match 2,
+ * try_to_remove_reads :6467).  Runs for every read of every set, as hifiasm does -- it has no notion of a phased input. */
+#define ORC_SITE_WIN_CAP 16
+#define ORC_SITE_READ_CAP 256
+typedef struct { int site, occ0, occ1, occ2, homo; int8_t *vec; } snp_site;
+
+static int vec_conflict(const int8_t *a, const int8_t *b, int n)
+{
+    int i;
+    for (i = 0; i < n; i++) if (a[i] != b[i] && (a[i] == 0 || a[i] == 1) && (b[i] == 0 || b[i] == 1)) return 1;
+    return 0;
+}
+
+typedef struct { snp_site *S; int nS, n; int *maxv, *bt_len, **bt; int *buf; orc_ovl *ov; int *visit; int n_groups; } k7_ctx;
+
+static void k7_group(k7_ctx *C, int plen)
+{
+    /* process_repeat_snps :6508 for one chain of sites (buf[0..plen), later sites first) */
+    int8_t *r = (int8_t *)malloc((size_t)C->n + 1);
+    int i, j, occ0 = 0, occ1 = 0, useful = 0;
+    memset(r, -1, (size_t)C->n + 1);
+    for (j = 0; j < plen; j++) {
+        const int8_t *v = C->S[C->buf[j]].vec;
+        for (i = 0; i < C->n; i++)
+            if (r[i] == -1) { if (v[i] == 0) { occ0++; r[i] = 0; } else if (v[i] == 1) { occ1++; r[i] = 1; } }
+    }
+    if (occ0 && occ1) {
+        double low = (occ0 + occ1) * 0.3;
+        if (occ1 >= low && occ0 >= low) useful = 1;
+        else if (occ1 >= 5 && occ0 >= 5) useful = 1;
+        else if (occ1 >= 3 && occ0 >= 3 && plen >= 2) { /* count_nearby_snps (Correct.h:309): a site 10 or more bases from its chain neighbours */
+            int far = 0;
+            for (j = 0; j < plen; j++) {
+                int cur = C->S[C->buf[j]].site, nearby = 0;
+                if (j > 0 && C->S[C->buf[j - 1]].site - cur < 10) nearby = 1;
+                if (j + 1 < plen && cur - C->S[C->buf[j + 1]].site < 10) nearby = 1;
+                if (!nearby) far++;
+            }
+            if (far > 0) useful = 1;
+        }
+    }
+    if (useful) for (i = 0; i < C->n; i++) if (r[i] == 1 && C->ov[i].is_match == 1) C->ov[i].is_match = 2;
+    free(r);
+    C->n_groups++;
+}
+
+static void k7_preorder(k7_ctx *C, int id, int plen)
+{
+    int j;
+    C->visit[id] = 1;
+    C->buf[plen++] = id;
+    if (C->n_groups > 100000) return; /* the enumeration is exponential in ties; hifiasm has no bound, real data stays far below this */
+    if (C->bt_len[id] == 0) { k7_group(C, plen); return; }
+    for (j = 0; j < C->bt_len[id]; j++) k7_preorder(C, C->bt[id][j], plen);
+}
+
+static void partition_read(const readset *R, int q, orc_ovl *ov, int n_ov, const orc_win *W)
+{
+    const char *x = R->seq[q];
+    int xlen = R->len[q], nwin = (xlen + ORC_WINDOW - 1) / ORC_WINDOW, g, i, j, o0 = 0, o1, n, nS = 0, capS = 0;
+    snp_site *S = NULL;
+    uint8_t flag[ORC_WINDOW + 1];
+    while (o0 < n_ov && (int)ov[o0].q != q) o0++;
+    o1 = o0;
+    while (o1 < n_ov && (int)ov[o1].q == q) o1++;
+    n = o1 - o0;
+    if (n == 0) return;
+    for (g = 0; g < nwin; g++) {
+        int gs = g * ORC_WINDOW, glen = (gs + ORC_WINDOW <= xlen ? ORC_WINDOW : xlen - gs), c, any = 0, nS_win = nS;
+        memset(flag, 0, sizeof flag);
+        for (i = o0; i < o1; i++) { /* markSNP_detail: mismatch columns */
+            const orc_ovl *o = &ov[i];
+            const orc_win *w;
+            int jw = g - o->x_s / ORC_WINDOW, xp, p;
+            if (o->is_match != 1 || jw < 0 || jw >= o->n_win) continue;
+            w = &W[o->first_win + jw];
+            if (w->err <= 0) continue;
+            xp = w->x_start - gs;
+            for (p = 0; p < w->path_len; p++) {
+                int op = w->path[p];
+                if (op == 2) continue;
+                if (op == 1 && flag[xp] < 127) { flag[xp]++; any = 1; }
+                xp++;
+            }
+        }
+        if (!any) continue;
+        for (c = 0; c < glen; c++) {
+            int occ0 = 0, occ1 = 0, occ2 = 0, oa[4] = {0, 0, 0, 0}, mx, mi, b, total;
+            int8_t *ev;
+            if (flag[c] <= 1) continue;
+            ev = (int8_t *)malloc((size_t)n);     /* -1 none, 0 same, 1..4 other base + 1, 5 gap */
+            memset(ev, -1, (size_t)n);
+            for (i = o0; i < o1; i++) { /* addSNPtohaplotype_details at column c */
+                const orc_ovl *o = &ov[i];
+                const orc_win *w;
+                const char *y = R->seq[o->t];
+                int ylen = R->len[o->t], jw = g - o->x_s / ORC_WINDOW, xp, yp, p;
+                if (o->is_match != 1 || jw < 0 || jw >= o->n_win) continue;
+                w = &W[o->first_win + jw];
+                if (w->err < 0) continue;
+                xp = w->x_start - gs; yp = w->ry_start;
+                if (c < xp || c >= xp + w->x_len) continue;
+                if (w->err == 0) { ev[i - o0] = 0; occ0++; continue; }
+                for (p = 0; p < w->path_len; p++) {
+                    int op = w->path[p];
+                    if (op == 2) { yp++; continue; }
+                    if (xp == c) {
+                        if (op == 0) { ev[i - o0] = 0; occ0++; }
+                        else if (op == 1) { b = base2(ybase(y, ylen, o->rev, yp)); ev[i - o0] = (int8_t)(1 + b); oa[b]++; occ1++; }
+                        else { ev[i - o0] = 5; occ2++; }
+                        break;
+                    }
+                    if (op != 3) yp++;
+                    xp++;
+                }
+            }
+            /* split_sub_list */
+            mx = occ2; mi = -1;
+            for (b = 0; b < 4; b++) if (oa[b] > mx) { mx = oa[b]; mi = b; }
+            total = occ0 + occ1 + occ2;
+            if (occ0 == 0 || occ1 == 0 || mi < 0 || mx <= 1) { free(ev); continue; }
+            for (b = 0; b < 4; b++) if (oa[b] == mx && b != mi) mi = -2;
+            if (mi < 0) { free(ev); continue; }
+            if ((double)(occ0 + 1 + mx) / (double)(total + 1) < 0.95) { free(ev); continue; }
+            if ((double)mx / (double)(total + 1 - (occ0 + 1)) < 0.70) { free(ev); continue; }
+            if (nS == capS) { capS = capS ? capS * 2 : 16; S = (snp_site *)realloc(S, sizeof(snp_site) * (size_t)capS); }
+            S[nS].site = gs + c; S[nS].occ0 = S[nS].occ1 = S[nS].occ2 = 0; S[nS].homo = is_homopolymer_site(x, xlen, gs + c);
+            for (i = 0; i < n; i++) { /* InsertSNPVector */
+                if (ev[i] == 0) S[nS].occ0++;
+                else if (ev[i] == 1 + mi) { ev[i] = 1; S[nS].occ1++; }
+                else if (ev[i] > 0) { ev[i] = 2; S[nS].occ2++; }
+            }
+            S[nS].vec = ev;
+            nS++;
+        }
+        /* bounds of the HIP path (FSV_SITE_WIN_CAP, FSV_SITE_READ_CAP; hifiasm has none): a window with more than 16 kept sites
+         * contributes none, a read with more than 256 is not partitioned */
+        if (nS - nS_win > ORC_SITE_WIN_CAP) { while (nS > nS_win) free(S[--nS].vec); }
+    }
+    if (nS > ORC_SITE_READ_CAP) { for (j = 0; j < nS; j++) free(S[j].vec); free(S); return; }
+    if (nS == 0) { free(S); return; }
+    /* generate_haplotypes_DP: a site directly beside another one is dropped */
+    if (nS > 1) {
+        int m = 0;
+        uint8_t *keep = (uint8_t *)calloc((size_t)nS, 1);
+        for (j = 0; j < nS; j++) {
+            int left = j > 0 && S[j].site == S[j - 1].site + 1, right = j + 1 < nS && S[j].site + 1 == S[j + 1].site;
+            keep[j] = !(left || right);
+        }
+        for (j = 0; j < nS; j++) { if (keep[j]) S[m++] = S[j]; else free(S[j].vec); }
+        free(keep);
+        nS = m;
+    }
+    for (i = 0; i < n; i++) { /* informative, not informative, informative again: set aside */
+        int st = -1;
+        if (ov[o0 + i].is_match != 1) continue;
+        for (j = 0; j < nS; j++) {
+            int inf = S[j].vec[i] == 0 || S[j].vec[i] == 1;
+            if (st == -1) { if (inf) st = 0; }
+            else if (st == 0) { if (!inf) st = 2; }
+            else if (st == 2) { if (inf) { st = 3; break; } }
+        }
+        if (st == 3) {
+            for (j = 0; j < nS; j++) {
+                if (S[j].vec[i] == 0) { S[j].occ0--; S[j].occ2++; }
+                else if (S[j].vec[i] == 1) { S[j].occ1--; S[j].occ2++; }
+                else if (S[j].vec[i] != 2) S[j].occ2++;
+                S[j].vec[i] = 2;
+            }
+            ov[o0 + i].is_match = 4;
+        }
+    }
+    if (nS > 0) {
+        k7_ctx C;
+        int *order = (int *)malloc(sizeof(int) * (size_t)nS);
+        C.S = S; C.nS = nS; C.n = n; C.ov = ov + o0; C.n_groups = 0;
+        C.maxv = (int *)malloc(sizeof(int) * (size_t)nS); C.bt_len = (int *)calloc((size_t)nS, sizeof(int));
+        C.bt = (int **)malloc(sizeof(int *) * (size_t)nS); C.buf = (int *)malloc(sizeof(int) * (size_t)nS + 8);
+        C.visit = (int *)calloc((size_t)nS, sizeof(int));
+        for (i = 0; i < nS; i++) {
+            int eq = 0;
+            C.maxv[i] = 1;
+            C.bt[i] = (int *)malloc(sizeof(int) * (size_t)(i + 1));
+            for (j = 0; j < i; j++) {
+                if (vec_conflict(S[i].vec, S[j].vec, n)) continue;
+                if (C.maxv[i] < C.maxv[j] + 1) { C.maxv[i] = C.maxv[j] + 1; C.bt[i][0] = j; eq = 1; }
+                else if (C.maxv[i] == C.maxv[j] + 1) C.bt[i][eq++] = j;
+            }
+            C.bt_len[i] = eq;
+        }
+        for (i = 0; i < nS; i++) order[i] = i; /* by chain length, longest first (stable, as glibc's qsort is for arrays this small) */
+        for (i = 1; i < nS; i++) { int v = order[i]; for (j = i; j > 0 && C.maxv[order[j - 1]] < C.maxv[v]; j--) order[j] = order[j - 1]; order[j] = v; }
+        for (i = 0; i < nS; i++) if (!C.visit[order[i]]) k7_preorder(&C, order[i], 0);
+        for (i = 0; i < nS; i++) free(C.bt[i]);
+        free(C.bt); free(C.maxv); free(C.bt_len); free(C.buf); free(C.visit); free(order);
+    }
+    for (j = 0; j < nS; j++) free(S[j].vec);
+    free(S);
+}
+
 /* one correction round: R -> corrected reads (new buffers); returns total windows examined */
 static void correction_round(readset *R, const orc_asm_params *P, int w, int do_rc, orc_ovl **accepted, int *n_accepted)
 {
@@ -620,16 +794,10 @@ static void correction_round(readset *R, const orc_asm_params *P, int w, int do_
     sketch_set(R, P, w, &uq, &nuq);
     collect_overlaps(R, P, P->bw_ec, uq, nuq, &ov, &cq, &ct, &n_ov);
     W = align_overlaps(R, P, ov, n_ov, cq, ct, &n_win);
-    if (P->diploid) { /* unphased read set: overlaps between the two haplotypes leave the consensus (is_match = 2 as in hifiasm) */
-        uint8_t *trans = (uint8_t *)calloc((size_t)n_ov + 1, 1);
-        int i;
-        for (q = 0; q < R->n; q++) correct_read(R, q, ov, n_ov, W, NULL, trans);
-        for (i = 0; i < n_ov; i++) if (trans[i] && ov[i].is_match == 1) ov[i].is_match = 2;
-        free(trans);
-    }
+    if (P->partition) for (q = 0; q < R->n; q++) partition_read(R, q, ov, n_ov, W); /* every read of every set, phased or not, as hifiasm */
     for (q = 0; q < R->n; q++) {
         nseq[q] = (char *)malloc((size_t)R->len[q] * 2 + 64 + (size_t)ORC_WINDOW * 16);
-        nlen[q] = correct_read(R, q, ov, n_ov, W, nseq[q], NULL);
+        nlen[q] = correct_read(R, q, ov, n_ov, W, nseq[q]);
         if (do_rc) revcomp_inplace(nseq[q], nlen[q]);
     }
     for (q = 0; q < R->n; q++) { free(R->seq[q]); R->seq[q] = nseq[q]; R->len[q] = nlen[q]; }
@@ -648,7 +816,7 @@ typedef struct { int to, to_rev, ovl; } arc_t; /* best successor of an oriented 
 void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
-    P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->diploid = 0;
+    P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->partition = 1;
     P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0;
 }
 

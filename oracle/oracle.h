@@ -29,7 +29,7 @@ typedef struct {
                                  homopolymer run yields an HPC k-mer whose end is off by the truncated bases, which a non-zero
                                  budget lets into the chain and shifts the exact-overlap interval by one) */
     int32_t min_contig_reads; /* chains of fewer reads are dropped (asg_cut_tip with max_short_tip = 3, Overlaps.cpp:4666): 4 */
-    int32_t diploid;          /* 1: unphased read set -- overlaps that carry the other allele at a heterozygous column are kept out of the consensus */
+    int32_t partition;        /* 1: haplotype partition of every read's overlaps before the consensus, as hifiasm does for every read set (default); 0: off (ONT profile) */
     /* error model (hifiasm: fixed for HiFi reads; raised for the ONT profile of BASELINE configs[4], where the reference has Flye) */
     int32_t win_rate_pm;      /* window threshold = x_len x this / 1000: 40 (max_ov_diff_ec 0.04 -> k = 15 for a full window) */
     int32_t k_cap;            /* largest threshold the rescue pass doubles to: 31 (THRESHOLD_MAX_SIZE, Hash_Table.h:9-22) */

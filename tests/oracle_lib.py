@@ -88,7 +88,7 @@ def sketch(seq: str, w=51, k=51, hpc=1):
 
 
 class AsmParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "diploid",
+    _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "partition",
                                          "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later")]
 
 
@@ -103,6 +103,7 @@ def ont_params():
     p = default_params()
     p.k, p.w, p.hpc, p.bw_ec, p.bw_final = 15, 15, 0, 150, 50
     p.win_rate_pm, p.k_cap, p.accept_err_pm, p.bw_rechain, p.min_contig_reads, p.w_later = 250, 95, 300, 50, 2, 63
+    p.partition = 0
     return p
 
 
