@@ -474,105 +474,218 @@ static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ov
     return W;
 }
 
-/* consensus of read q given all accepted overlaps; returns new length, writes into out (cap >= 2*len+64) */
-static int correct_read(const readset *R, int q, const orc_ovl *ov, int n_ov, const orc_win *W, char *out)
+/* One alignment of a partner read against a stretch of a backbone: the votes it casts (addmatchedSeqToGraph, POA.cpp:309). */
+typedef struct { const char *y; int ylen, rev, ry_start, xs, path_len, pend0; const uint8_t *path; uint32_t pend_key; } vote_aln;
+
+typedef struct { int32_t (*cnt)[6]; int32_t *instot; ins_list ins; } vote_ws;
+
+/* Consensus of the backbone xf[gs, gs+glen) given the alignments (get_seq_from_Graph, Correct.cpp:4010-4129, as a per-column
+ * vote); homopolymer tests look at xf[0, xf_len).  Writes the consensus to out, and for every backbone column where its own
+ * output base (kept or replaced) sits in out, or -1 when the column was deleted (col_idx may be NULL).  Returns the length. */
+static int vote_consensus(const char *xf, int xf_len, int gs, int glen, const vote_aln *A, int nA, vote_ws *V, char *out, int *col_idx)
+{
+    int i, c, outn = 0;
+    memset(V->cnt, 0, sizeof(int32_t[6]) * (ORC_WINDOW + 1));
+    V->ins.n = 0;
+    memset(V->instot, 0, sizeof(int32_t) * (ORC_WINDOW + 1));
+    for (i = 0; i < nA; i++) {
+        const vote_aln *a = &A[i];
+        int xp = a->xs, yp = a->ry_start, p, pend = a->pend0;
+        if (pend && (a->pend_key >> 24)) ins_vote(&V->ins, 0, a->pend_key);
+        for (p = 0; p < a->path_len; ) {
+            int op = a->path[p];
+            if (op == 2) { /* run of y-only bases in front of column xp */
+                int L = 0;
+                while (p + L < a->path_len && a->path[p + L] == 2) L++;
+                if (xp < glen) {
+                    pend = 1;
+                    if (L <= INS_MAXLEN) {
+                        uint32_t key = (uint32_t)L << 24; int b;
+                        for (b = 0; b < L; b++) key |= (uint32_t)base2(ybase(a->y, a->ylen, a->rev, yp + b)) << (2 * b);
+                        ins_vote(&V->ins, xp, key);
+                    }
+                }
+                yp += L; p += L;
+                continue;
+            }
+            V->cnt[xp][5]++;               /* reads arriving at this column */
+            if (pend) { V->instot[xp]++; pend = 0; } /* ... of which after an insertion */
+            if (op == 3) V->cnt[xp][4]++;  /* x base without partner: deletion vote */
+            else { V->cnt[xp][base2(ybase(a->y, a->ylen, a->rev, yp))]++; yp++; }
+            xp++; p++;
+        }
+    }
+    for (c = 0; c < glen; c++) {
+        int homo = is_homopolymer_site(xf, xf_len, gs + c), b, bestb, bestc, total;
+        /* (1) what sits between column c-1 and c: nothing, or an inserted string */
+        {
+            int none = V->cnt[c][5] - V->instot[c] + 1; /* + the read itself */
+            uint32_t key = 0;
+            int bc = V->instot[c] ? ins_winner(&V->ins, c, &key) : 0;
+            total = V->cnt[c][5] + 1;
+            if (bc > none && wins(bc, total, homo)) {
+                int L = (int)(key >> 24);
+                for (b = 0; b < L; b++) out[outn++] = "ACGT"[(key >> (2 * b)) & 3];
+            }
+        }
+        /* (2) the column itself: A/C/G/T or deleted */
+        {
+            int own = base2(xf[gs + c]);
+            int v[5];
+            for (b = 0; b < 5; b++) v[b] = V->cnt[c][b];
+            v[own]++; /* backbone's own base starts with weight 1 (POA.cpp:269-307) */
+            total = v[0] + v[1] + v[2] + v[3] + v[4];
+            bestb = own; bestc = v[own];
+            for (b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
+            if (bestb != own && !wins(bestc, total, homo)) bestb = own;
+            if (col_idx) col_idx[c] = bestb < 4 ? outn : -1;
+            if (bestb < 4) out[outn++] = "ACGT"[bestb];
+        }
+    }
+    return outn;
+}
+
+#define ORC_BOUNDARY_HALF 187   /* WINDOW_BOUNDARY / 2 (Hash_Table.h:10) */
+#define ORC_BOUNDARY_SIDE 25    /* WINDOW_UNCORRECT_SINGLE_SIDE_BOUNDARY (Hash_Table.h:12) */
+
+/* consensus of read q given all accepted overlaps; returns new length, writes into out (cap >= 2*len+64).
+ * generate_consensus (Correct.cpp:4731-4808): first the grid windows one by one (window_consensus :4132); then, when
+ * P->second_round, every junction between two grid windows again (process_boundary :4453-4728): the 375 bases of the FIRST-round
+ * result centred on the junction are the backbone, every overlap that covers the start of the later window is re-aligned to
+ * it (threshold doubled once on failure), and the inner 325 bases are replaced by the consensus of those alignments
+ * (merge_cigars :4267: from the first to the last kept column inside [25, len - 25)). */
+static int correct_read(const readset *R, const orc_asm_params *P, int q, const orc_ovl *ov, int n_ov, const orc_win *W, char *out)
 {
     const char *x = R->seq[q];
     int xlen = R->len[q], nwin = (xlen + ORC_WINDOW - 1) / ORC_WINDOW, g, i, outn = 0;
-    int32_t (*cnt)[6] = (int32_t (*)[6])malloc(sizeof(int32_t[6]) * (ORC_WINDOW + 1));
-    ins_list ins = {0, 0, 0};
-    int32_t *instot = (int32_t *)malloc(sizeof(int32_t) * (ORC_WINDOW + 1));
+    vote_ws V;
+    vote_aln *A;
+    int *lb = (int *)malloc(sizeof(int) * (size_t)(nwin + 1));      /* corrected length after every window */
+    uint8_t *covered = (uint8_t *)calloc((size_t)nwin + 1, 1);     /* window went through window_consensus */
     /* overlaps of q are contiguous in ov[] (generated q-major) */
     int o0 = 0, o1;
     while (o0 < n_ov && (int)ov[o0].q != q) o0++;
     o1 = o0;
     while (o1 < n_ov && (int)ov[o1].q == q) o1++;
+    V.cnt = (int32_t (*)[6])malloc(sizeof(int32_t[6]) * (ORC_WINDOW + 1));
+    V.instot = (int32_t *)malloc(sizeof(int32_t) * (ORC_WINDOW + 1));
+    V.ins.e = NULL; V.ins.n = V.ins.cap = 0;
+    A = (vote_aln *)malloc(sizeof(vote_aln) * (size_t)(o1 - o0 + 1));
 
     for (g = 0; g < nwin; g++) {
-        int gs = g * ORC_WINDOW, glen = (gs + ORC_WINDOW <= xlen ? ORC_WINDOW : xlen - gs), cover = 0, c;
-        memset(cnt, 0, sizeof(int32_t[6]) * (ORC_WINDOW + 1));
-        ins.n = 0;
-        memset(instot, 0, sizeof(int32_t) * (ORC_WINDOW + 1));
+        int gs = g * ORC_WINDOW, glen = (gs + ORC_WINDOW <= xlen ? ORC_WINDOW : xlen - gs), cover = 0, nA = 0;
         for (i = o0; i < o1; i++) {
             const orc_ovl *o = &ov[i];
             const orc_win *w;
-            const char *y = R->seq[o->t];
-            int ylen = R->len[o->t], j = g - o->x_s / ORC_WINDOW, xp, yp, p, pend;
+            int j = g - o->x_s / ORC_WINDOW;
+            vote_aln *a;
             if (o->is_match != 1 || j < 0 || j >= o->n_win) continue;
             w = &W[o->first_win + j];
             if (w->err < 0) continue;
             cover++;
-            xp = w->x_start - gs; yp = w->ry_start;
+            a = &A[nA++];
+            a->y = R->seq[o->t]; a->ylen = R->len[o->t]; a->rev = o->rev; a->ry_start = w->ry_start; a->xs = w->x_start - gs;
+            a->path = w->path; a->path_len = w->path_len; a->pend0 = 0; a->pend_key = 0;
             /* junction with the previous window of the same overlap: y bases skipped by both end-free
              * alignments are an insertion in front of this window's first column */
-            pend = 0;
-            if (j > 0 && W[o->first_win + j - 1].err >= 0) {
+            if (!P->second_round && j > 0 && W[o->first_win + j - 1].err >= 0) {
                 int gap = w->ry_start - W[o->first_win + j - 1].ry_end - 1;
-                if (gap > 0 && xp == 0) {
-                    pend = 1;
+                if (gap > 0 && a->xs == 0) {
+                    a->pend0 = 1;
                     if (gap <= INS_MAXLEN) {
                         uint32_t key = (uint32_t)gap << 24; int b;
-                        for (b = 0; b < gap; b++) key |= (uint32_t)base2(ybase(y, ylen, o->rev, w->ry_start - gap + b)) << (2 * b);
-                        ins_vote(&ins, 0, key);
+                        for (b = 0; b < gap; b++) key |= (uint32_t)base2(ybase(a->y, a->ylen, o->rev, w->ry_start - gap + b)) << (2 * b);
+                        a->pend_key = key;
                     }
                 }
-            }
-            for (p = 0; p < w->path_len; ) {
-                int op = w->path[p];
-                if (op == 2) { /* run of y-only bases in front of column xp */
-                    int L = 0;
-                    while (p + L < w->path_len && w->path[p + L] == 2) L++;
-                    if (xp < glen) {
-                        pend = 1;
-                        if (L <= INS_MAXLEN) {
-                            uint32_t key = (uint32_t)L << 24; int b;
-                            for (b = 0; b < L; b++) key |= (uint32_t)base2(ybase(y, ylen, o->rev, yp + b)) << (2 * b);
-                            ins_vote(&ins, xp, key);
-                        }
-                    }
-                    yp += L; p += L;
-                    continue;
-                }
-                cnt[xp][5]++;               /* reads arriving at this column */
-                if (pend) { instot[xp]++; pend = 0; } /* ... of which after an insertion */
-                if (op == 3) cnt[xp][4]++;  /* x base without partner: deletion vote */
-                else { cnt[xp][base2(ybase(y, ylen, o->rev, yp))]++; yp++; }
-                xp++; p++;
             }
         }
         if (cover < 3) { /* MIN_COVERAGE_THRESHOLD: copy verbatim */
             memcpy(out + outn, x + gs, (size_t)glen); outn += glen;
-            continue;
+        } else {
+            outn += vote_consensus(x, xlen, gs, glen, A, nA, &V, out + outn, NULL);
+            covered[g] = 1;
         }
-        for (c = 0; c < glen; c++) {
-            int homo = is_homopolymer_site(x, xlen, gs + c), b, bestb, bestc, total;
-            /* (1) what sits between column c-1 and c: nothing, or an inserted string */
-            {
-                int none = cnt[c][5] - instot[c] + 1; /* + the read itself */
-                uint32_t key = 0;
-                int bc = instot[c] ? ins_winner(&ins, c, &key) : 0;
-                total = cnt[c][5] + 1;
-                if (bc > none && wins(bc, total, homo)) {
-                    int L = (int)(key >> 24);
-                    for (b = 0; b < L; b++) out[outn++] = "ACGT"[(key >> (2 * b)) & 3];
-                }
-            }
-            /* (2) the column itself: A/C/G/T or deleted */
-            {
-                int own = base2(x[gs + c]);
-                int v[5];
-                for (b = 0; b < 5; b++) v[b] = cnt[c][b];
-                v[own]++; /* backbone's own base starts with weight 1 (POA.cpp:269-307) */
-                total = v[0] + v[1] + v[2] + v[3] + v[4];
-                bestb = own; bestc = v[own];
-                for (b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
-                if (bestb != own && !wins(bestc, total, homo)) bestb = own;
-                if (bestb < 4) out[outn++] = "ACGT"[bestb];
-            }
-        }
+        lb[g] = outn;
     }
-    free(cnt); free(ins.e); free(instot);
-    (void)i;
+    if (P->second_round && nwin > 1) {
+        /* replacements in first-round coordinates, ascending and disjoint */
+        int nrep = 0, *rs = (int *)malloc(sizeof(int) * (size_t)nwin * 3), total_extra = 0;
+        char **rstr = (char **)malloc(sizeof(char *) * (size_t)nwin);
+        orc_win *tw = (orc_win *)malloc(sizeof(orc_win) * (size_t)(o1 - o0 + 1));
+        char ybuf[ORC_WINDOW + 2 * ORC_K_WIDE + 8];
+        static __thread uint64_t cols[5 * 4 * (ORC_WINDOW + 4)];
+        uint8_t tmp[2 * ORC_WINDOW + 4 * ORC_K_WIDE + 16];
+        int rl[2 * ORC_WINDOW + 64];
+        uint8_t ro[2 * ORC_WINDOW + 64];
+        int col_idx[ORC_WINDOW + 1];
+        char cons[2 * ORC_WINDOW + 64 + ORC_WINDOW * 16];
+        for (g = 1; g < nwin; g++) {
+            int gs = g * ORC_WINDOW, LB = lb[g - 1], len_now = lb[g], cws, cwe, blen, nA = 0, terr = 0, k0, sb, eb, c, xs_ = -1, xe_ = -1, cn;
+            if (!covered[g] || LB == 0) continue;
+            cws = LB - ORC_BOUNDARY_HALF; cwe = LB + ORC_BOUNDARY_HALF - 1;
+            if (cws < 0) cws = 0;
+            if (cwe >= len_now) cwe = len_now - 1;
+            blen = cwe - cws + 1;
+            k0 = orc_thr_for_len_p(P, blen);
+            for (i = o0; i < o1; i++) {
+                const orc_ovl *o = &ov[i];
+                const orc_win *w;
+                orc_win *t = &tw[nA];
+                const char *y = R->seq[o->t];
+                int ylen = R->len[o->t], j = g - o->x_s / ORC_WINDOW;
+                vote_aln *a;
+                if (o->is_match != 1 || j < 0 || j >= o->n_win) continue;
+                w = &W[o->first_win + j];
+                if (w->err < 0 || w->x_start != gs) continue;
+                memset(t, 0, sizeof(*t));
+                t->x_start = cws; t->x_len = (int16_t)blen; t->k = (uint8_t)k0; t->y_start = w->ry_start - ORC_BOUNDARY_HALF;
+                if (t->y_start < 0) continue;
+                if (!window_verify(out, y, ylen, o->rev, t, ybuf, P->k_cap) || t->err < 0) {
+                    int k2 = k0 * 2;
+                    if (k2 == 0 && blen >= 4) k2 = 1;
+                    if (blen >= 300 && k2 < P->k_cap) k2 = P->k_cap;
+                    if (k2 > P->k_cap) k2 = P->k_cap;
+                    t->k = (uint8_t)k2; t->y_start = w->ry_start - ORC_BOUNDARY_HALF;
+                    if (!window_verify(out, y, ylen, o->rev, t, ybuf, P->k_cap) || t->err < 0) continue;
+                }
+                window_path(out, y, ylen, o->rev, t, ybuf, cols, tmp, rl, ro);
+                if (t->err < 0) continue;
+                terr += t->err;
+                a = &A[nA++];
+                a->y = y; a->ylen = ylen; a->rev = o->rev; a->ry_start = t->ry_start; a->xs = 0; a->path = t->path; a->path_len = t->path_len;
+                a->pend0 = 0; a->pend_key = 0;
+            }
+            if (nA < 3 || terr == 0) continue;
+            sb = ORC_BOUNDARY_SIDE; eb = blen - 1 - ORC_BOUNDARY_SIDE;
+            if (eb <= sb) continue;
+            cn = vote_consensus(out, len_now, cws, blen, A, nA, &V, cons, col_idx);
+            if (cn == blen && !memcmp(cons, out + cws, (size_t)blen)) continue;   /* the new cigar is one run of matches */
+            for (c = sb; c < blen && xs_ < 0; c++) if (col_idx[c] >= 0) xs_ = c;
+            for (c = eb; c < blen && xe_ < 0; c++) if (col_idx[c] >= 0) xe_ = c;
+            if (xs_ < 0 || xe_ < 0) continue;               /* a gap at the end of the stretch: "very likely miscorrection" */
+            rs[3 * nrep] = cws + xs_; rs[3 * nrep + 1] = cws + xe_; rs[3 * nrep + 2] = col_idx[xe_] - col_idx[xs_] + 1;
+            rstr[nrep] = (char *)malloc((size_t)rs[3 * nrep + 2] + 1);
+            memcpy(rstr[nrep], cons + col_idx[xs_], (size_t)rs[3 * nrep + 2]);
+            total_extra += rs[3 * nrep + 2];
+            nrep++;
+        }
+        if (nrep) {
+            char *fin = (char *)malloc((size_t)outn + (size_t)total_extra + 16);
+            int pos = 0, fn = 0, r;
+            for (r = 0; r < nrep; r++) {
+                memcpy(fin + fn, out + pos, (size_t)(rs[3 * r] - pos)); fn += rs[3 * r] - pos;
+                memcpy(fin + fn, rstr[r], (size_t)rs[3 * r + 2]); fn += rs[3 * r + 2];
+                pos = rs[3 * r + 1] + 1;
+                free(rstr[r]);
+            }
+            memcpy(fin + fn, out + pos, (size_t)(outn - pos)); fn += outn - pos;
+            memcpy(out, fin, (size_t)fn); outn = fn;
+            free(fin);
+        }
+        free(rs); free(rstr); free(tw);
+    }
+    free(V.cnt); free(V.ins.e); free(V.instot); free(A); free(lb); free(covered);
     return outn;
 }
 
@@ -797,7 +910,7 @@ static void correction_round(readset *R, const orc_asm_params *P, int w, int do_
     if (P->partition) for (q = 0; q < R->n; q++) partition_read(R, q, ov, n_ov, W); /* every read of every set, phased or not, as hifiasm */
     for (q = 0; q < R->n; q++) {
         nseq[q] = (char *)malloc((size_t)R->len[q] * 2 + 64 + (size_t)ORC_WINDOW * 16);
-        nlen[q] = correct_read(R, q, ov, n_ov, W, nseq[q]);
+        nlen[q] = correct_read(R, P, q, ov, n_ov, W, nseq[q]);
         if (do_rc) revcomp_inplace(nseq[q], nlen[q]);
     }
     for (q = 0; q < R->n; q++) { free(R->seq[q]); R->seq[q] = nseq[q]; R->len[q] = nlen[q]; }
@@ -817,7 +930,7 @@ void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->partition = 1;
-    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0;
+    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 0;
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),

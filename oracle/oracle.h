@@ -36,6 +36,7 @@ typedef struct {
     int32_t accept_err_pm;    /* an overlap is used when its error rate is at most this / 1000: 30 (Correct.cpp:725) */
     int32_t bw_rechain;       /* indel budget per mille when the final pass re-chains a pair without an exact overlap: 1 (max_ov_diff_final 0.001) */
     int32_t w_later;          /* minimizer window from the second correction round on (0 = w throughout, as hifiasm) */
+    int32_t second_round;     /* 1: the junctions between grid windows get a second consensus (process_boundary, Correct.cpp:4453) */
 } orc_asm_params;
 
 typedef struct {

@@ -144,3 +144,54 @@ def test_ont_profile_read_set_assembles_and_carries_its_svs():
     assert len(ev) == len(want)
     for (k, p, n), (wk, wp, wn) in zip(sorted(ev, key=lambda e: e[1]), sorted(want, key=lambda e: e[1])):
         assert k == wk and abs(p - wp) <= 5 and abs(n - wn) <= max(1, wn // 50), (ev, want)
+
+
+# ---- round by round (tools/make_golden_rounds.py) --------------------------------------------------------------------------
+def _round_sets(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
+    return json.load(open(os.path.join(golden_dir, "hifiasm_rounds.json")))["sets"]
+
+
+# After the FIRST round one or two reads of these sets still differ from hifiasm's (after the second round all 88 sets are
+# identical): where all overlaps insert two bases whose second equals the next backbone base, hifiasm's insertion consensus
+# (build_DAGCon, Correct.cpp:3219-3950) emits one base and this column vote both; the rest untraced.  Listed so that a fix shows.
+KNOWN_ROUND1_DEVIATIONS = {4, 9, 16, 18, 27, 30, 33, 46, 63, 74, 77, 82, 83, 86, 87}
+
+
+def _round_ids():
+    # every third set by default (the whole list with FSV_FULL_GOLDEN=1)
+    n = len(_round_sets())
+    return list(range(n)) if os.environ.get("FSV_FULL_GOLDEN") else [i for i in range(n) if i % 3 == 0 or i in (16, 19)]
+
+
+@pytest.mark.parametrize("idx", _round_ids())
+def test_every_round_equals_hifiasm_with_the_second_junction_pass(golden_dir, idx):
+    """hifiasm's generate_consensus is two passes: the grid windows, then every junction between two windows again on the result
+    of the first (process_boundary, Correct.cpp:4453-4728).  With that second pass (orc_asm_params.second_round = 1) and the
+    haplotype partition the restatement's reads equal `hifiasm -r 2` md5 for md5 on all 88 sets and `hifiasm -r 1` on 73 of them
+    (KNOWN_ROUND1_DEVIATIONS) -- round by round, not only at the end.
+    The HIP path and the oracle's default (second_round = 0) replace the second pass by a vote on the bases both end-free window
+    alignments skip at a junction: same reads after three rounds on the golden sets (one read end in 2 796 apart), but not after
+    the first round"""
+    g = _round_sets(golden_dir)[idx]
+    if g["kind"] == "repeat":
+        reads = synth.make_repeat_region(g["index"]).reads[0]
+    else:
+        reads = synth.make_region(g["region"], width=g["width"], depth_per_hap=g["depth"]).reads[g["hap"] - 1]
+    assert hashlib.md5(b"\n".join(reads)).hexdigest() == g["reads_md5"], "synthetic generator drifted"
+    for rounds in (1, 2):
+        p = O.default_params()
+        p.n_rounds, p.second_round = rounds, 1
+        _, corrected = O.assemble(reads, p)
+        same = hashlib.md5(b"\n".join(canon(c) for c in corrected)).hexdigest() == g["round_md5"][rounds - 1]
+        assert same != (rounds == 1 and idx in KNOWN_ROUND1_DEVIATIONS), (idx, rounds)
+
+
+def test_second_junction_pass_closes_the_last_read_end_deviation(golden_dir):
+    """repeat set 15, read 13: the one corrected read of the 2 796 that differs from hifiasm's in the default mode is identical
+    with the second pass on"""
+    g = _repeat_sets(golden_dir)[15]
+    r = synth.make_repeat_region(15)
+    p = O.default_params()
+    p.second_round = 1
+    _, corrected = O.assemble(r.reads[0], p)
+    assert [hashlib.md5(c).hexdigest()[:12] for c in corrected] == g["corrected_read_md5"]
