@@ -53,7 +53,7 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
        CT_MZ_LO = 10, CT_MZ_HI = 11, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_vec, site_cursor, redo, site_lists, changed,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_vec, site_cursor, redo, site_lists, read_dirty, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -68,7 +68,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_vec, &site_cursor, &redo, &site_lists, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -621,6 +621,14 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         TRY(ensure(ctx, W.changed, (size_t)B.n_reads * 4));
         FSV_HIP(ctx, hipMemsetAsync(W.changed.p, 0, (size_t)B.n_reads * 4, ctx->stream));
         C.changed = (uint32_t *)W.changed.p;
+        C.read_dirty = nullptr;
+        if (B.n_pairs) {
+            TRY(ensure(ctx, W.read_dirty, (size_t)B.n_reads * 4));
+            hipLaunchKernelGGL(k_read_dirty, dim3(B.n_reads), dim3(64), 0, ctx->stream, (const uint4 *)W.ovl_c.p, (const fsv_wpath *)W.paths.p,
+                               (const uint32_t *)W.read_set.p, (const uint32_t *)W.set_start.p, (const uint32_t *)W.pair_base.p, B.n_reads, (uint32_t *)W.read_dirty.p);
+            FSV_HIP(ctx, hipGetLastError());
+            C.read_dirty = (const uint32_t *)W.read_dirty.p;
+        }
         const bool partition = B.n_pairs && P.partition;
         SiteArgs SA{};
         SiteLists SL{};

@@ -1352,12 +1352,45 @@ struct ConsArgs {
     uint32_t *warn;
     uint32_t *changed;           // per read: set when the consensus of some window differs from the read (nullptr: not tracked)
     uint32_t n_reads;
+    const uint32_t *read_dirty;  // per read: some accepted overlap deviates from it somewhere (k_read_dirty); nullptr: not known
 };
 
 __device__ __forceinline__ bool vote_wins(int cnt, int total, bool homo)
 {
     if (cnt * 5 >= total * 3) return true;
     return homo && cnt * 1000 >= total * 515;
+}
+
+// One wavefront per read, one lane per overlap: does some accepted overlap deviate from the read anywhere -- a window at distance
+// > 0, or y bases skipped between two consecutive windows (what k_consensus votes as a junction insertion)?  A read no overlap
+// deviates from keeps every window as it is; from the second round on that is most reads, and their windows skip the tally.
+__global__ __launch_bounds__(64) void k_read_dirty(const uint4 *__restrict__ ovl_c, const fsv_wpath *__restrict__ paths, const uint32_t *__restrict__ read_set,
+                                                   const uint32_t *__restrict__ set_start, const uint32_t *__restrict__ pair_base, uint32_t n_reads,
+                                                   uint32_t *__restrict__ read_dirty)
+{
+    const uint32_t r = blockIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t s = read_set[r], r0 = set_start[s], ns = set_start[s + 1] - r0;
+    const uint32_t pbase = pair_base[s] + (r - r0) * (ns - 1), n_ovl = ns - 1;
+    bool dirty = false;
+    for (uint32_t oi = threadIdx.x; oi < n_ovl; oi += 64) {
+        const uint4 oc = ovl_c[pbase + oi];
+        if (!(oc.z >> 31)) continue;
+        const int n_win = (int)(oc.z & 0x7fffffffu);
+        int prev_end = 0; bool prev_ok = false;
+        for (int j = 0; j < n_win && !dirty; j++) {
+            const uint4 h0 = *reinterpret_cast<const uint4 *>(paths + (oc.y + (uint32_t)j));
+            const bool ok = (h0.w & 0xffu) == 1u;
+            if (ok) {
+                if ((int16_t)(h0.z >> 16) != 0) dirty = true;
+                if (prev_ok && (int)h0.x - prev_end - 1 > 0) dirty = true;
+                prev_end = (int)h0.y;
+            }
+            prev_ok = ok;
+        }
+    }
+    const bool any = __ballot(dirty) != 0ull;
+    if (threadIdx.x == 0) read_dirty[r] = any ? 1u : 0u;
 }
 
 // per grid window, once per round: everything k_consensus would otherwise look up through three levels of tables
@@ -1406,6 +1439,15 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     const uint32_t xw = A.word_off[r];
     const int xw0 = (gs >> 4) - 1; // first staged word (may be -1 at the read start: reads as 0, never used)
     if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((xlen + 15) >> 4)) ? A.store[xw + wi] : 0u; }
+    if (A.read_dirty && !A.read_dirty[r]) {
+        // every accepted overlap of this read matches it base for base (from the second round on: most reads): all votes are for
+        // the backbone, whatever the coverage
+        __syncthreads();
+        uint8_t *dst0 = A.cwin + (size_t)gw * FSV_CW_STRIDE;
+        for (int c = lane; c < glen; c += 64) dst0[c] = (uint8_t)((s_xraw[((gs + c) >> 4) - xw0] >> (((gs + c) & 15) << 1)) & 3u);
+        if (lane == 0) { A.cwin_len[gw] = (uint16_t)glen; if (MODE == 1) L.site_cnt[gw] = 0u; }
+        return;
+    }
     for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_evhead[i] = 0xffffu;
