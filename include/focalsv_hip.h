@@ -192,10 +192,11 @@ typedef struct fsv_readsets {
     const int32_t  *read_len;   /* host: n_reads lengths in bases */
     const uint32_t *set_start;  /* host: n_sets+1 read indices; set s owns reads [set_start[s], set_start[s+1]) */
     uint32_t n_reads, n_sets;
-    const uint8_t  *set_flags;  /* host: n_sets flags, or NULL; FSV_SET_UNPHASED marks a set that mixes both haplotypes' reads */
+    const uint8_t  *set_flags;  /* host: n_sets flags, or NULL; informational since round 2 (see FSV_SET_UNPHASED) */
 } fsv_readsets;
-#define FSV_SET_UNPHASED 1      /* unphased.fa (run_assembly.py:17-21): overlaps that carry the other allele at a heterozygous
-                                 * column stay out of the consensus, so each haplotype comes out as its own contig */
+#define FSV_SET_UNPHASED 1      /* unphased.fa (run_assembly.py:17-21).  The haplotype partition that keeps the other allele's overlaps out
+                                 * of a read's consensus (partition_overlaps_advance, Correct.cpp:7127) runs for EVERY set, as in hifiasm,
+                                 * so the flag no longer changes the result; callers may keep passing it */
 
 typedef struct fsv_contigs {
     char     *seq;         /* host, capacity seq_cap: ASCII contig bases back to back */
