@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(64) void k_consensus_redo(ConsArgs A, SiteLists L)
 // oracle/asm.c:partition_read is the same algorithm, statement by statement.
 #define FSV_SITE_WIN_CAP 16        // kept sites per grid window
 #define FSV_SITE_READ_CAP 256      // kept sites per read
-#define FSV_K7_GROUP_CAP 100000    // chains enumerated per read (the enumeration is exponential in ties)
+#define FSV_K7_GROUP_CAP 10000     // chains enumerated per read (the enumeration is exponential in ties; hifiasm has no bound)
 struct SiteArgs {
     uint32_t *site_cnt;            // per grid window
     uint2 *site_rec;               // per grid window x FSV_SITE_WIN_CAP: {position in the read | homopolymer << 31, byte offset of the vector}

@@ -748,7 +748,7 @@ static void k7_preorder(k7_ctx *C, int id, int plen)
     int j;
     C->visit[id] = 1;
     C->buf[plen++] = id;
-    if (C->n_groups > 100000) return; /* the enumeration is exponential in ties; hifiasm has no bound, real data stays far below this */
+    if (C->n_groups > 10000) return; /* FSV_K7_GROUP_CAP: the enumeration is exponential in ties; hifiasm has no bound, real data stays far below this */
     if (C->bt_len[id] == 0) { k7_group(C, plen); return; }
     for (j = 0; j < C->bt_len[id]; j++) k7_preorder(C, C->bt[id][j], plen);
 }

@@ -109,6 +109,40 @@ def test_all_golden_sets_equal_hifiasm(ctx, golden_dir):
             assert got == exp, (g["region"], g["hap"])
 
 
+def test_partition_on_mixed_sets_of_many_shapes_matches_oracle(ctx):
+    """the haplotype partition (k_snp_sites / k_hap_partition / the consensus redo) against oracle/asm.c:partition_read on read
+    sets it has real work on: both haplotypes mixed at 8x-25x per haplotype, three window widths, tandem-repeat regions, an
+    uneven mix (a third of one haplotype's reads), and three haplotype-like read groups in one set; corrected reads and contigs
+    bit for bit, after one round and after three"""
+    import random
+    sets = []
+    for i, (width, depth) in enumerate(((26000, 8.0), (26000, 15.0), (50000, 25.0), (50000, 12.0), (100000, 10.0), (14000, 20.0))):
+        r = synth.make_region(700 + i, width=width, depth_per_hap=depth)
+        sets.append(r.reads[0] + r.reads[1])
+    for i in (7, 15, 23):       # i % 8 == 7: a tandem-repeat block
+        r = synth.make_region(i)
+        sets.append(r.reads[0] + r.reads[1])
+    r = synth.make_region(41)
+    rng = random.Random(3)
+    sets.append(r.reads[0] + [x for x in r.reads[1] if rng.random() < 0.33])
+    r2 = synth.make_region(41, depth_per_hap=10.0)
+    sets.append(r.reads[0][:40] + r.reads[1][:40] + r2.reads[1])
+    for rounds in (1, 3):
+        p = ctx.default_asm_params()
+        p.n_rounds = rounds
+        contigs, cset, status, reads, b = gpu_assemble(ctx, sets, p)
+        po = O.default_params()
+        po.n_rounds = rounds
+        k = 0
+        for si, s in enumerate(sets):
+            oc, ocorr = O.assemble(s, po)
+            for j in range(len(s)):
+                assert reads[k + j] == ocorr[j], (rounds, si, j, len(reads[k + j]), len(ocorr[j]))
+            k += len(s)
+            mine = [c for c, cs in zip(contigs, cset) if cs == si]
+            assert mine == oc, (rounds, si, [len(c) for c in mine], [len(c) for c in oc])
+
+
 def test_degenerate_sets(ctx):
     r = synth.make_region(5)
     sets = [[], r.reads[0][:1], r.reads[0][:2], [b"ACGT" * 30, b"ACGT" * 30]]
