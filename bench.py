@@ -232,6 +232,9 @@ def main():
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
     ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
     ap.add_argument("--cpu-sample", type=int, default=8, help="regions the CPU baseline runs (0 = skip)")
+    ap.add_argument("--second-round", type=int, choices=(0, 1), default=None,
+                    help="fsv_asm_params.second_round: 1 = hifiasm's second consensus pass over the window junctions on the GPU, 0 = the junction-insertion "
+                         "vote that stands in for it; default: the library's default")
     ap.add_argument("--profile", choices=["hifi", "ont"], default="hifi",
                     help="read profile of the synthetic256 workload: hifi = BASELINE.json configs[1] (the metric's configuration); ont = configs[4] "
                          "(10 %% error, reads of 10-30 kb, fsv_asm_ont_params: wide-band K5 / K6)")
@@ -285,6 +288,10 @@ def main():
     lanes = max(1, min(args.lanes, n))
     ctxs = [_lib.Context(local) for _ in range(lanes)]
     kw = {"asm_params": ctxs[0].ont_asm_params()} if args.profile == "ont" else {}
+    if args.second_round is not None:
+        ap_ = kw.get("asm_params") or ctxs[0].default_asm_params()
+        ap_.second_round = args.second_round
+        kw["asm_params"] = ap_
     # "steps": every lane takes whole steps and only runs their GPU half; the host half (Python SV logic) of a batch runs on its own
     # thread.  This also holds for a single lane (one stream, one batch on the GPU at a time).
     by_steps = args.lane_mode == "steps"

@@ -50,10 +50,10 @@ struct Span {
 // per-round block of device counters (one 64-byte slot per correction round + one for the final pass, zeroed once per batch and
 // read back with the round's one synchronisation or at the end): u32 indices
 enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4, CT_COLS_HI = 5, CT_DP_WIDE = 6, CT_DP_SB = 7, CT_DP_GEN = 8, CT_DP_XW = 9,
-       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_SLOT = 16 };
+       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_vec, site_cursor, redo, site_lists, read_dirty, changed,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -68,7 +68,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -311,7 +311,7 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
     if (!p) return;
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
-    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0; p->partition = 1;
+    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0; p->partition = 1; p->second_round = 1;
 }
 
 extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
@@ -324,6 +324,7 @@ extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
     p->bw_rechain = 50;                         // corrected reads keep a 1-base indel every few kb
     p->w_later = 63;                            // after one round the reads are ~99 % accurate: sparser seeds keep a pair's anchors below 1 024
     p->partition = 0;                           // coincident errors of 10 % reads would pass for alleles and split the set
+    p->second_round = 0;                        // the junction vote: what the ONT outcome was validated with (and a third less work)
     p->min_contig_reads = 2;                    // reads of 10-30 kb tile a 50 kb window with three or four uncontained reads: hifiasm's tip rule (4) would drop them
 }
 
@@ -419,6 +420,148 @@ extern "C" int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out)
 }
 
 // one chunk of read sets through the whole assembly (what fsv_assemble_batch was before it learnt to split a batch)
+// K6 for a task list: the fast paths, then the DP kernels on what is left (the lists and their counters live in the counter row ct).
+// Used for the window tasks of a round and, with second_round, for the junction tasks of its second consensus pass.
+static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_wtask *tasks, const fsv_wres *res, fsv_wpath *paths, uint32_t task_cap,
+                      const uint32_t *n_tasks_dev, uint32_t *ct, int round, bool wide_bands, const fsv_asm_params &P, bool first_pass)
+{
+    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_FAST, 0); if (first_pass) W.fast_rec.push_back(rec_); }
+    hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
+                       tasks, res, task_cap, paths,
+                       (uint32_t *)W.dp_list.p, ct + CT_DP, (uint32_t *)W.dp_wide.p, ct + CT_DP_WIDE, false, n_tasks_dev,
+                       (uint32_t *)W.dp_xwide.p, ct + CT_DP_XW);
+    FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
+    // single-indel windows are settled without the DP (k_path_indel1); what is left goes to the sub-band kernel
+    // (distance <= FSV_SB_MAXERR) or to the general one
+    hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, tasks,
+                       res, (const uint32_t *)W.dp_list.p, 0u, paths, (uint32_t *)W.dp_list2.p, ct + CT_DP_SB,
+                       (const uint32_t *)(ct + CT_DP), (uint32_t *)W.dp_list3.p, ct + CT_DP_GEN);
+    FSV_HIP(ctx, hipGetLastError());
+    // persistent grids: as many blocks as the device holds at once, each striding through its list, so the column scratch
+    // is a fixed few hundred MB whatever the number of windows
+    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_DP, 0); if (first_pass) W.dp_rec.push_back(rec_); }
+    {
+        int per_cu = 0;
+        FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_sb<false>, 64, 0));
+        const uint32_t grid = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, per_cu) * (uint32_t)ctx->n_cu);
+        TRY(ensure(ctx, W.cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
+        if (getenv("FSV_K6_STAMPS")) {   // diagnostic: where a k_path_sb wave spends its cycles (never in a measured run)
+            DevBuf &sb = W.tmp;
+            TRY(ensure(ctx, sb, 64));
+            FSV_HIP(ctx, hipMemsetAsync(sb.p, 0, 64, ctx->stream));
+            hipLaunchKernelGGL(k_path_sb<true>, dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
+                               (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)sb.p);
+            unsigned long long h[4] = {0, 0, 0, 0};
+            FSV_HIP(ctx, hipMemcpyAsync(h, sb.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            fprintf(stderr, "[fsv] k_path_sb round %d: %llu waves, cycles per wave: forward %.0f, walk %.0f, finish %.0f (grid %u)\n", round, h[3],
+                    h[3] ? (double)h[0] / h[3] : 0.0, h[3] ? (double)h[1] / h[3] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0, grid);
+        } else
+        hipLaunchKernelGGL(k_path_sb<false>, dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
+                           (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
+        FSV_HIP(ctx, hipGetLastError());
+        // the general kernel's lists are short (rescue windows, distances above 7): two blocks per CU are plenty
+        const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 2u * (uint32_t)ctx->n_cu), stride = gridg * 64;
+        TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * sizeof(uint64_t)));
+        hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(gridg), dim3(64), 0, ctx->stream, store, tasks,
+                           (const uint32_t *)W.dp_list3.p, 0u, 0u, paths, (uint32_t *)W.cols.p, stride, (const uint32_t *)(ct + CT_DP_GEN));
+        FSV_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(gridg), dim3(64), 0, ctx->stream, store, tasks,
+                           (const uint32_t *)W.dp_wide.p, 0u, 0u, paths, (uint64_t *)W.cols.p, stride, (const uint32_t *)(ct + CT_DP_WIDE));
+        FSV_HIP(ctx, hipGetLastError());
+        if (wide_bands) {
+            // bands above 63 rows: every gapped window of an ONT-profile batch; 1.15 MB of column scratch per persistent block
+            int pc = 0;
+            FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_path_wide, 64, 0));
+            const uint32_t gridw = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, std::min(pc, 12)) * (uint32_t)ctx->n_cu);
+            TRY(ensure(ctx, W.cols_wide, (size_t)gridw * FSV_WINDOW * 2 * FSV_WL * 64 * 4));
+            hipLaunchKernelGGL(k_path_wide, dim3(gridw), dim3(64), 0, ctx->stream, store, tasks, res,
+                               (const uint32_t *)W.dp_xwide.p, (const uint32_t *)(ct + CT_DP_XW), paths, (uint32_t *)W.cols_wide.p, P.k_cap);
+            FSV_HIP(ctx, hipGetLastError());
+        }
+    }
+    W.kt.end(ctx);
+    return FSV_OK;
+}
+
+// The second consensus pass of a round (process_boundary, Correct.cpp:4453): see asm_kernels.h "second consensus pass".
+// Runs between the windows' consensus (cwin / cwin_len final for the first pass) and k_newlen; leaves cwin / cwin_len patched.
+static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, const uint32_t *store, const fsv_asm_params &P, const ConsArgs &C,
+                       uint32_t n_gwin, uint32_t task_cap, const uint32_t *n_tasks_dev, uint32_t *ct2, int round, bool wide_bands)
+{
+    // where window g starts in the first pass's result, and that result as a 2-bit store behind a copy of the round's reads
+    TRY(ensure(ctx, W.lb, (size_t)std::max(1u, n_gwin) * 4));
+    hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
+                       (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p, (uint32_t *)W.lb.p);
+    FSV_HIP(ctx, hipGetLastError());
+    const uint32_t a_words = G.word_off[B.n_reads];
+    std::vector<uint32_t> brel(B.n_reads + 1, 0);
+    for (uint32_t r = 0; r < B.n_reads; r++) {
+        const uint64_t nx = (uint64_t)brel[r] + (uint64_t)(G.gwin_off[r + 1] - G.gwin_off[r]) * (FSV_CW_STRIDE / 16) + 2;
+        if (nx + a_words >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "second consensus pass: store larger than 2^32 words; split the batch");
+        brel[r + 1] = (uint32_t)nx;
+    }
+    const uint32_t b_words = brel[B.n_reads];
+    TRY(ensure(ctx, W.sr_store, ((size_t)a_words + b_words + 16) * 4));
+    FSV_HIP(ctx, hipMemcpyAsync(W.sr_store.p, store, (size_t)a_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    TRY(upload(ctx, W.brel_off, brel));
+    uint32_t *store2 = (uint32_t *)W.sr_store.p;
+    hipLaunchKernelGGL(k_repack, dim3(fsv_grid_for(b_words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p, (const uint16_t *)W.cwin_len.p,
+                       (const uint8_t *)W.cwin.p, (const uint32_t *)W.brel_off.p, (const int32_t *)W.new_len.p, B.n_reads, b_words, 0, store2 + a_words,
+                       (const uint32_t *)W.read_dirty.p);
+    FSV_HIP(ctx, hipGetLastError());
+    FSV_HIP(ctx, hipMemsetAsync(store2 + a_words + b_words, 0, 32, ctx->stream));
+    // junction tasks
+    TRY(ensure(ctx, W.tasks2, (size_t)task_cap * sizeof(fsv_wtask)));
+    TRY(ensure(ctx, W.res2, (size_t)task_cap * sizeof(fsv_wres)));
+    TRY(ensure(ctx, W.paths2, (size_t)task_cap * sizeof(fsv_wpath)));
+    TRY(ensure(ctx, W.idx2, (size_t)task_cap * 4));
+    TRY(ensure(ctx, W.tasks3, (size_t)task_cap * sizeof(fsv_wtask)));
+    TRY(ensure(ctx, W.res3, (size_t)task_cap * sizeof(fsv_wres)));
+    TRY(ensure(ctx, W.src3, (size_t)task_cap * 4));
+    TRY(ensure(ctx, W.bnd_flag, (size_t)(n_gwin + 2) * 4));
+    TRY(ensure(ctx, W.bnd_list, (size_t)(n_gwin + 2) * 4));
+    TRY(ensure(ctx, W.bnd_patch, (size_t)(n_gwin + 2) * sizeof(BndPatch)));
+    TRY(ensure(ctx, W.bnd_bytes, (size_t)(n_gwin + 2) * FSV_CW_STRIDE));
+    FSV_HIP(ctx, hipMemsetAsync(W.bnd_flag.p, 0, (size_t)(n_gwin + 2) * 4, ctx->stream));
+    BndArgs A;
+    A.tasks = (const fsv_wtask *)W.tasks.p; A.paths = (const fsv_wpath *)W.paths.p; A.n_tasks = n_tasks_dev;
+    A.ovl_c = (const uint4 *)W.ovl_c.p; A.pair_base = (const uint32_t *)W.pair_base.p; A.set_start = (const uint32_t *)W.set_start.p; A.n_sets = B.n_sets;
+    A.gwin_off = (const uint32_t *)W.gwin_off.p; A.lb = (const uint32_t *)W.lb.p; A.cwin_len = (const uint16_t *)W.cwin_len.p;
+    A.cov3 = (const uint8_t *)W.cov3.p; A.read_dirty = (const uint32_t *)W.read_dirty.p;
+    A.brel_off = (const uint32_t *)W.brel_off.p; A.b_base = a_words; A.thr_tab = (const uint8_t *)W.thr_tab.p;
+    A.tasks2 = (fsv_wtask *)W.tasks2.p; A.idx2 = (int32_t *)W.idx2.p; A.n_tasks2 = ct2 + CT_TASKS;
+    A.bnd_flag = (uint32_t *)W.bnd_flag.p; A.bnd_list = (uint32_t *)W.bnd_list.p; A.n_bnd = ct2 + CT_B_LIST;
+    hipLaunchKernelGGL(k_bnd_tasks, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, A);
+    FSV_HIP(ctx, hipGetLastError());
+    // K5, once more with the doubled threshold for the tasks without an alignment, K6
+    TRY(fsv_bpm_windows_dev_n(ctx, store2, (const fsv_wtask *)W.tasks2.p, task_cap, ct2 + CT_TASKS, (fsv_wres *)W.res2.p, P.k_cap));
+    hipLaunchKernelGGL(k_bnd_retry, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, (fsv_wtask *)W.tasks2.p, (const fsv_wres *)W.res2.p,
+                       (const uint32_t *)(ct2 + CT_TASKS), (fsv_wtask *)W.tasks3.p, (uint32_t *)W.src3.p, ct2 + CT_B_RETRY, P.k_cap);
+    FSV_HIP(ctx, hipGetLastError());
+    TRY(fsv_bpm_windows_dev_n(ctx, store2, (const fsv_wtask *)W.tasks3.p, task_cap, ct2 + CT_B_RETRY, (fsv_wres *)W.res3.p, P.k_cap));
+    hipLaunchKernelGGL(k_bnd_scatter, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, (fsv_wres *)W.res2.p, (const fsv_wres *)W.res3.p,
+                       (const uint32_t *)W.src3.p, (const uint32_t *)(ct2 + CT_B_RETRY));
+    FSV_HIP(ctx, hipGetLastError());
+    TRY(path_stage(ctx, W, store2, (const fsv_wtask *)W.tasks2.p, (const fsv_wres *)W.res2.p, (fsv_wpath *)W.paths2.p, task_cap, (const uint32_t *)(ct2 + CT_TASKS), ct2,
+                   round, wide_bands, P, false));
+    // the junctions' consensus, handed to the windows as patches
+    const uint32_t grid_l = std::min<uint32_t>(std::max(1u, n_gwin), (uint32_t)ctx->n_cu * 16);
+    W.kt.begin(ctx, KN_CONSENSUS, 0);
+    if (wide_bands) hipLaunchKernelGGL(k_bnd_consensus<FSV_EV_CAP_WIDE>, dim3(grid_l), dim3(64), 0, ctx->stream, C, A, (const fsv_wpath *)W.paths2.p, (const uint32_t *)store2,
+                                       (BndPatch *)W.bnd_patch.p, (uint8_t *)W.bnd_bytes.p);
+    else hipLaunchKernelGGL(k_bnd_consensus<FSV_EV_CAP>, dim3(grid_l), dim3(64), 0, ctx->stream, C, A, (const fsv_wpath *)W.paths2.p, (const uint32_t *)store2,
+                            (BndPatch *)W.bnd_patch.p, (uint8_t *)W.bnd_bytes.p);
+    FSV_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_bnd_apply, dim3(std::max(1u, n_gwin)), dim3(64), 0, ctx->stream, (const uint32_t *)W.gwin_read.p, (const uint32_t *)W.gwin_off.p,
+                       (const BndPatch *)W.bnd_patch.p, (const uint8_t *)W.bnd_bytes.p, (const uint32_t *)W.bnd_flag.p, n_gwin, (uint8_t *)W.cwin.p,
+                       (uint16_t *)W.cwin_len.p, (uint32_t *)W.changed.p, (uint32_t *)W.warn.p);
+    FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
+    return FSV_OK;
+}
+
 static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params &P, fsv_contigs *out)
 {
     AsmWs &W = *ws_get(ctx);
@@ -491,8 +634,9 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     const bool wide_bands = P.k_cap > FSV_K_MAX;   // the error model allows thresholds above hifiasm's 31: wide-band K5 / K6 / rescue
     bool short_reads = true;     // every read below 65 536 bases: k_chain's compact LDS layout
     for (uint32_t r = 0; r < B.n_reads; r++) { reads_in_bytes += (uint64_t)(len[r] + 3) / 4; if (len[r] >= 65536) short_reads = false; }
-    TRY(ensure(ctx, W.counters, (size_t)(P.n_rounds + 1) * CT_SLOT * 4));
-    FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, (size_t)(P.n_rounds + 1) * CT_SLOT * 4, ctx->stream));
+    // rows 0 .. n_rounds: the rounds and the final pass; rows n_rounds + 1 ..: the second consensus pass of every round
+    TRY(ensure(ctx, W.counters, (size_t)(2 * P.n_rounds + 2) * CT_SLOT * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, (size_t)(2 * P.n_rounds + 2) * CT_SLOT * 4, ctx->stream));
     TRY(ensure(ctx, W.set_cols, (size_t)B.n_reads * 4));       // K5 columns per set, summed over the rounds (statistics)
     FSV_HIP(ctx, hipMemsetAsync(W.set_cols.p, 0, (size_t)B.n_reads * 4, ctx->stream));
 
@@ -541,63 +685,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             W.kt.end(ctx);
             tv.stop();
             Span tp(ctx, W.kt, ST_PATH);
-            W.fast_rec.push_back(W.kt.begin(ctx, KN_PATH_FAST, 0));
-            hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
-                               (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, task_cap, (fsv_wpath *)W.paths.p,
-                               (uint32_t *)W.dp_list.p, ct + CT_DP, (uint32_t *)W.dp_wide.p, ct + CT_DP_WIDE, false, (const uint32_t *)(ct + CT_TASKS),
-                               (uint32_t *)W.dp_xwide.p, ct + CT_DP_XW);
-            FSV_HIP(ctx, hipGetLastError());
-            W.kt.end(ctx);
-            // single-indel windows are settled without the DP (k_path_indel1); what is left goes to the sub-band kernel
-            // (distance <= FSV_SB_MAXERR) or to the general one
-            hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                               (const fsv_wres *)W.res.p, (const uint32_t *)W.dp_list.p, 0u, (fsv_wpath *)W.paths.p, (uint32_t *)W.dp_list2.p, ct + CT_DP_SB,
-                               (const uint32_t *)(ct + CT_DP), (uint32_t *)W.dp_list3.p, ct + CT_DP_GEN);
-            FSV_HIP(ctx, hipGetLastError());
-            // persistent grids: as many blocks as the device holds at once, each striding through its list, so the column scratch
-            // is a fixed few hundred MB whatever the number of windows
-            W.dp_rec.push_back(W.kt.begin(ctx, KN_PATH_DP, 0));
-            {
-                int per_cu = 0;
-                FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_sb<false>, 64, 0));
-                const uint32_t grid = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, per_cu) * (uint32_t)ctx->n_cu);
-                TRY(ensure(ctx, W.cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
-                if (getenv("FSV_K6_STAMPS")) {   // diagnostic: where a k_path_sb wave spends its cycles (never in a measured run)
-                    DevBuf &sb = W.tmp;
-                    TRY(ensure(ctx, sb, 64));
-                    FSV_HIP(ctx, hipMemsetAsync(sb.p, 0, 64, ctx->stream));
-                    hipLaunchKernelGGL(k_path_sb<true>, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p,
-                                       (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)W.paths.p, (uint4 *)W.cols_sb.p, (unsigned long long *)sb.p);
-                    unsigned long long h[4] = {0, 0, 0, 0};
-                    FSV_HIP(ctx, hipMemcpyAsync(h, sb.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-                    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    fprintf(stderr, "[fsv] k_path_sb round %d: %llu waves, cycles per wave: forward %.0f, walk %.0f, finish %.0f (grid %u)\n", round, h[3],
-                            h[3] ? (double)h[0] / h[3] : 0.0, h[3] ? (double)h[1] / h[3] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0, grid);
-                } else
-                hipLaunchKernelGGL(k_path_sb<false>, dim3(grid), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p,
-                                   (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)W.paths.p, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
-                FSV_HIP(ctx, hipGetLastError());
-                // the general kernel's lists are short (rescue windows, distances above 7): two blocks per CU are plenty
-                const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 2u * (uint32_t)ctx->n_cu), stride = gridg * 64;
-                TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * sizeof(uint64_t)));
-                hipLaunchKernelGGL(k_path_dp<uint32_t>, dim3(gridg), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                                   (const uint32_t *)W.dp_list3.p, 0u, 0u, (fsv_wpath *)W.paths.p, (uint32_t *)W.cols.p, stride, (const uint32_t *)(ct + CT_DP_GEN));
-                FSV_HIP(ctx, hipGetLastError());
-                hipLaunchKernelGGL(k_path_dp<uint64_t>, dim3(gridg), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p,
-                                   (const uint32_t *)W.dp_wide.p, 0u, 0u, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p, stride, (const uint32_t *)(ct + CT_DP_WIDE));
-                FSV_HIP(ctx, hipGetLastError());
-                if (wide_bands) {
-                    // bands above 63 rows: every gapped window of an ONT-profile batch; 1.15 MB of column scratch per persistent block
-                    int pc = 0;
-                    FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_path_wide, 64, 0));
-                    const uint32_t gridw = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, std::min(pc, 12)) * (uint32_t)ctx->n_cu);
-                    TRY(ensure(ctx, W.cols_wide, (size_t)gridw * FSV_WINDOW * 2 * FSV_WL * 64 * 4));
-                    hipLaunchKernelGGL(k_path_wide, dim3(gridw), dim3(64), 0, ctx->stream, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p,
-                                       (const uint32_t *)W.dp_xwide.p, (const uint32_t *)(ct + CT_DP_XW), (fsv_wpath *)W.paths.p, (uint32_t *)W.cols_wide.p, P.k_cap);
-                    FSV_HIP(ctx, hipGetLastError());
-                }
-            }
-            W.kt.end(ctx);
+            TRY(path_stage(ctx, W, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, (fsv_wpath *)W.paths.p, task_cap, (const uint32_t *)(ct + CT_TASKS), ct, round, wide_bands, P, true));
             tp.stop();
         }
         // consensus -> corrected windows -> new read store
@@ -622,6 +710,9 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         FSV_HIP(ctx, hipMemsetAsync(W.changed.p, 0, (size_t)B.n_reads * 4, ctx->stream));
         C.changed = (uint32_t *)W.changed.p;
         C.read_dirty = nullptr;
+        C.junction_vote = P.second_round ? 0 : 1;
+        C.cov3 = nullptr;
+        if (P.second_round && B.n_pairs) { TRY(ensure(ctx, W.cov3, (size_t)std::max(1u, n_gwin))); C.cov3 = (uint8_t *)W.cov3.p; }
         if (B.n_pairs) {
             TRY(ensure(ctx, W.read_dirty, (size_t)B.n_reads * 4));
             hipLaunchKernelGGL(k_read_dirty, dim3(B.n_reads), dim3(64), 0, ctx->stream, (const uint4 *)W.ovl_c.p, (const fsv_wpath *)W.paths.p,
@@ -673,8 +764,10 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             FSV_HIP(ctx, hipGetLastError());
             W.kt.end(ctx);
         }
+        if (P.second_round && B.n_pairs)
+            TRY(second_pass(ctx, W, B, G, store, P, C, n_gwin, task_cap, (const uint32_t *)(ct + CT_TASKS), ct_of(P.n_rounds + 1 + round), round, wide_bands));
         hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
-                           (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p);
+                           (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p, (uint32_t *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
         // the round's one synchronisation: new read lengths (+ this round's counters)
         std::vector<int32_t> nlen(B.n_reads);

@@ -1353,6 +1353,8 @@ struct ConsArgs {
     uint32_t *changed;           // per read: set when the consensus of some window differs from the read (nullptr: not tracked)
     uint32_t n_reads;
     const uint32_t *read_dirty;  // per read: some accepted overlap deviates from it somewhere (k_read_dirty); nullptr: not known
+    uint8_t *cov3;               // per grid window: at least three overlaps voted (the window went through window_consensus); nullptr: not kept
+    int junction_vote;           // 1: bases skipped between two windows of an overlap are voted as an insertion (the stand-in for the second pass)
 };
 
 __device__ __forceinline__ bool vote_wins(int cnt, int total, bool homo)
@@ -1481,7 +1483,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
 #define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))
         const int xs = max(gs, o_x_s) - gs;
         bool pend = false;
-        if (j > 0) {
+        if (j > 0 && A.junction_vote) {
             const uint4 hp = *reinterpret_cast<const uint4 *>(A.paths + ti - 1);
             if ((hp.w & 0xffu) == 1u) {
                 const int gap = ry_start - (int)hp.y - 1;
@@ -1549,6 +1551,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
     // fewer than three overlaps: the reference leaves the window alone; no deviation anywhere: every vote is for the backbone
     const bool verbatim = s_cover < 3u || s_anydev == 0u;
+    if (A.cov3 && lane == 0) A.cov3[gw] = s_cover >= 3u ? 1 : 0;
     if (s_evn > (uint32_t)EVC && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
     int arrived = before;
     bool differs = false, site = false;
@@ -2015,12 +2018,13 @@ __global__ __launch_bounds__(64) void k_hap_partition(ConsArgs A, SiteArgs S, fs
 }
 
 // ------------------------------------------------------------------------------------------------ k_newlen / k_repack
-__global__ void k_newlen(const uint32_t *__restrict__ gwin_off, const uint16_t *__restrict__ cwin_len, uint32_t n_reads, int32_t *__restrict__ new_len)
+__global__ void k_newlen(const uint32_t *__restrict__ gwin_off, const uint16_t *__restrict__ cwin_len, uint32_t n_reads, int32_t *__restrict__ new_len,
+                         uint32_t *__restrict__ lb = nullptr)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     int32_t L = 0;
-    for (uint32_t g = gwin_off[r]; g < gwin_off[r + 1]; g++) L += cwin_len[g];
+    for (uint32_t g = gwin_off[r]; g < gwin_off[r + 1]; g++) { if (lb) lb[g] = (uint32_t)L; L += cwin_len[g]; }   // lb: where window g starts in the corrected read
     new_len[r] = L;
 }
 
@@ -2028,13 +2032,14 @@ __global__ void k_newlen(const uint32_t *__restrict__ gwin_off, const uint16_t *
 __global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwin_off, const uint16_t *__restrict__ cwin_len,
                                                 const uint8_t *__restrict__ cwin, const uint32_t *__restrict__ new_word_off,
                                                 const int32_t *__restrict__ new_len, uint32_t n_reads, uint32_t total_words, int rc,
-                                                uint32_t *__restrict__ out)
+                                                uint32_t *__restrict__ out, const uint32_t *__restrict__ only = nullptr)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= total_words) return;
     uint32_t lo = 0, hi = n_reads;
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (new_word_off[mid] <= w) lo = mid; else hi = mid; }
     const uint32_t r = lo;
+    if (only && !only[r]) return;      // the second pass only looks at reads some overlap deviates from
     const int len = new_len[r];
     const int b0 = (int)(w - new_word_off[r]) * 16;
     uint32_t v = 0;
@@ -2058,6 +2063,306 @@ __global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwi
         }
     }
     out[w] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ second consensus pass
+// process_boundary (Correct.cpp:4453-4728) + merge_cigars (:4267): after the grid windows, every junction between two windows of a
+// read once more.  Backbone = the 375 bases of the FIRST pass's result centred on the junction (read from a 2-bit copy of that
+// result placed behind the round's read store, so K5 / K6 run on it as on any window task); every overlap that covers the start
+// of the later window is re-aligned to it, threshold doubled once on failure; the inner bases (25 off either end) are replaced
+// by the consensus of those alignments, from the first to the last column that keeps a base.  The replacement is handed to the
+// two windows it touches as patches (k_bnd_apply) so that k_newlen / k_repack work on the windows as before.
+// oracle/asm.c:correct_read (second_round) is the same, statement for statement.
+#define FSV_BND_HALF 187
+#define FSV_BND_SIDE 25
+struct BndArgs {
+    const fsv_wtask *tasks; const fsv_wpath *paths; const uint32_t *n_tasks;     // the round's window tasks and their paths
+    const uint4 *ovl_c; const uint32_t *pair_base, *set_start; uint32_t n_sets;
+    const uint32_t *gwin_off, *lb; const uint16_t *cwin_len; const uint8_t *cov3; const uint32_t *read_dirty;
+    const uint32_t *brel_off; uint32_t b_base;      // first-pass result of read r in the second-pass store: word b_base + brel_off[r]
+    const uint8_t *thr_tab;
+    fsv_wtask *tasks2; int32_t *idx2; uint32_t *n_tasks2;      // junction tasks; idx2[window task] = its junction task or -1
+    uint32_t *bnd_flag, *bnd_list, *n_bnd;                    // junctions with at least one task
+};
+
+__global__ __launch_bounds__(256) void k_bnd_tasks(BndArgs A)
+{
+    const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= *A.n_tasks) return;
+    A.idx2[ti] = -1;
+    const fsv_wtask t = A.tasks[ti];
+    if (t.x_start % FSV_WINDOW != 0 || t.x_start == 0) return;    // only an overlap that covers the window's first base takes part
+    const uint32_t p = t.ovl;
+    uint32_t lo = 0, hi = A.n_sets;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.pair_base[mid] <= p) lo = mid; else hi = mid; }
+    const uint32_t r0 = A.set_start[lo], ns = A.set_start[lo + 1] - r0;
+    const uint32_t r = r0 + (p - A.pair_base[lo]) / (ns - 1);
+    if (!A.read_dirty[r]) return;     // every overlap matches the read base for base: every junction alignment has distance 0
+    const uint32_t gw = A.gwin_off[r] + (uint32_t)(t.x_start / FSV_WINDOW);
+    if (!A.cov3[gw]) return;
+    const int LB = (int)A.lb[gw];
+    if (LB == 0) return;
+    if (!(A.ovl_c[p].z >> 31)) return;
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(A.paths + ti);
+    if ((h0.w & 0xffu) != 1u) return;
+    const int len_now = LB + (int)A.cwin_len[gw];
+    const int cws = max(0, LB - FSV_BND_HALF), cwe = min(len_now - 1, LB + FSV_BND_HALF - 1), blen = cwe - cws + 1;
+    const int y_start = (int)h0.x - FSV_BND_HALF;
+    if (y_start < 0 || blen < 1) return;
+    const uint32_t slot = atomicAdd(A.n_tasks2, 1u);
+    fsv_wtask w;
+    w.x_word = A.b_base + A.brel_off[r]; w.y_word = t.y_word; w.x_start = cws; w.y_start = y_start; w.y_len = t.y_len;
+    w.x_len = (uint16_t)blen; w.k = A.thr_tab[blen]; w.y_rev = t.y_rev; w.ovl = p; w.win = ti;
+    A.tasks2[slot] = w;
+    A.idx2[ti] = (int32_t)slot;
+    if (atomicExch(&A.bnd_flag[gw], 1u) == 0u) A.bnd_list[atomicAdd(A.n_bnd, 1u)] = gw;
+}
+
+// junction tasks K5 found no alignment for get the doubled threshold (Correct.cpp:4585-4626) and go round once more
+__global__ __launch_bounds__(256) void k_bnd_retry(fsv_wtask *__restrict__ tasks2, const fsv_wres *__restrict__ res2, const uint32_t *__restrict__ n_tasks2,
+                                                   fsv_wtask *__restrict__ tasks3, uint32_t *__restrict__ src3, uint32_t *__restrict__ n3, int k_cap)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_tasks2 || res2[i].err >= 0) return;
+    fsv_wtask t = tasks2[i];
+    t.k = (uint8_t)double_thr(t.k, t.x_len, k_cap);
+    tasks2[i].k = t.k;
+    const uint32_t j = atomicAdd(n3, 1u);
+    tasks3[j] = t; src3[j] = i;
+}
+
+__global__ __launch_bounds__(256) void k_bnd_scatter(fsv_wres *__restrict__ res2, const fsv_wres *__restrict__ res3, const uint32_t *__restrict__ src3,
+                                                     const uint32_t *__restrict__ n3)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < *n3) res2[src3[j]] = res3[j];
+}
+
+// what a junction hands to the two windows it touches: in window gw-1 the bases [ts, ts + told) become tnew bytes, in window
+// gw the bases [hs, hs + hold) become hnew bytes (the tail bytes first in the junction's byte slot)
+struct BndPatch { uint16_t ts, told, tnew, hs, hold, hnew, valid, pad; };
+
+template <int EVC>
+__global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, const fsv_wpath *__restrict__ paths2, const uint32_t *__restrict__ store2,
+                                                      BndPatch *__restrict__ patch, uint8_t *__restrict__ patch_bytes)
+{
+    __shared__ uint32_t s_cnt[FSV_WINDOW + 1][3];
+    __shared__ int32_t s_cov[FSV_WINDOW + 2];
+    __shared__ uint32_t s_path[64][27];
+    __shared__ uint16_t s_evnext[EVC];
+    __shared__ uint32_t s_evkey[EVC];
+    __shared__ uint32_t s_evhead[FSV_WINDOW + 1];
+    __shared__ uint16_t s_off[FSV_WINDOW + 2];      // where a column's output starts in the consensus
+    __shared__ uint8_t s_own[FSV_WINDOW + 1];       // the column keeps a base (its own or another one)
+    __shared__ uint32_t s_evn, s_cover, s_terr;
+    __shared__ uint32_t s_xraw[28];
+    __shared__ uint32_t s_scan[64];
+    const int lane = threadIdx.x;
+    const uint32_t n_list = *B.n_bnd;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        __syncthreads();
+        const uint32_t gw = B.bnd_list[li];
+        const uint4 gt = A.gwin_tab[gw];
+        const uint32_t r = gt.x, pbase = gt.y, n_ovl = gt.z;
+        const int g = (int)gt.w;
+        const int gs = g * FSV_WINDOW;
+        const int LB = (int)B.lb[gw], len_now = LB + (int)B.cwin_len[gw];
+        const int cws = max(0, LB - FSV_BND_HALF), cwe = min(len_now - 1, LB + FSV_BND_HALF - 1), blen = cwe - cws + 1;
+        const uint32_t xw = B.b_base + B.brel_off[r];
+        const int xw0 = (cws >> 4) - 1;
+        if (lane == 0) patch[gw].valid = 0;
+        if (lane < 28) { const int wi = xw0 + lane; s_xraw[lane] = (wi >= 0 && wi <= ((len_now + 15) >> 4)) ? store2[xw + wi] : 0u; }
+        for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
+        for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
+        for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_evhead[i] = 0xffffu;
+        if (lane == 0) { s_evn = 0; s_cover = 0; s_terr = 0; }
+        __syncthreads();
+#define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
+#define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
+#define CNT_GET(c, b) ((s_cnt[(c)][(b) >> 1] >> (((b) & 1u) << 4)) & 0xffffu)
+        for (uint32_t oi = lane; oi < n_ovl; oi += 64) {
+            const uint4 oc = A.ovl_c[pbase + oi];
+            const int o_x_s = (int)oc.x, o_n_win = (int)(oc.z & 0x7fffffffu);
+            const int j = g - o_x_s / FSV_WINDOW;
+            if (!(oc.z >> 31) || j < 0 || j >= o_n_win || o_x_s > gs) continue;
+            const int32_t slot = B.idx2[oc.y + (uint32_t)j];
+            if (slot < 0) continue;
+            const fsv_wpath *P = paths2 + slot;
+            const uint4 h0 = *reinterpret_cast<const uint4 *>(P);
+            if ((h0.w & 0xffu) != 1u) continue;
+            const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16);
+            const int perr = (int)(int16_t)(h0.z >> 16);
+            atomicAdd(&s_cover, 1u);
+            const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
+            int n2 = 0, n3 = 0;
+            if (perr != 0) {
+                atomicAdd(&s_terr, (uint32_t)perr);
+                const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
+#pragma unroll
+                for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
+                const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
+#define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))
+#define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
+                bool pend = false;
+                for (int p = 0; p < plen;) {
+                    const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1);
+                    if (rest == 0u && !pend) { p = ((p >> 4) + 1) << 4; continue; }
+                    const uint32_t op = rest & 3u;
+                    const int xp = p - n2;
+                    if (op == 2u) {
+                        int L = 1;
+                        while (p + L < plen && OP(p + L) == 2u) L++;
+                        if (xp < blen) {
+                            pend = true;
+                            if (L <= FSV_INS_MAXLEN) {
+                                uint32_t key = (uint32_t)L << 24;
+                                const int yp = ry_start + p - n3;
+                                for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
+                                uint32_t e = atomicAdd(&s_evn, 1u);
+                                if (e < (uint32_t)EVC) { s_evkey[e] = key; s_evnext[e] = (uint16_t)atomicExch(&s_evhead[xp], e); }
+                            }
+                        }
+                        n2 += L; p += L;
+                        continue;
+                    }
+                    if (pend) { CNT_ADD(xp, 5u); pend = false; }
+                    if (op == 3u) { CNT_ADD(xp, 4u); n3++; }
+                    else if (op == 1u) CNT_ADD(xp, YB(ry_start + p - n3));
+                    p++;
+                }
+#undef OP
+#undef YB
+            }
+            atomicAdd(&s_cov[0], 1);
+            atomicAdd(&s_cov[plen - n2], -1);
+        }
+        __syncthreads();
+        if (s_cover < 3u || s_terr == 0u) continue;       // MIN_COVERAGE_THRESHOLD; "if there are no error, we do not need correction"
+        if (s_evn > (uint32_t)EVC && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
+        const int per = (blen + 63) / 64, c0 = min(blen, lane * per), c1 = min(blen, c0 + per);
+        int run = 0;
+        for (int c = c0; c < c1; c++) run += s_cov[c];
+        s_scan[lane] = (uint32_t)run;
+        __syncthreads();
+        int arrived = 0;
+        for (int i = 0; i < lane; i++) arrived += (int)s_scan[i];
+        __syncthreads();
+        uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]);
+        bool differs = false;
+        int mine = 0;
+        for (int c = c0; c < c1; c++) {
+            arrived += s_cov[c];
+            const int p = cws + c;
+            const uint32_t own = XB(p);
+            uint8_t nb = 0;
+            const bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < len_now && XB(p + 1) == own);
+            const int instot = (int)CNT_GET(c, 5u);
+            if (instot) {
+                int bc = 0; uint32_t bk = 0;
+                for (uint32_t i = s_evhead[c]; i != 0xffffu; i = s_evnext[i]) {
+                    const uint32_t key = s_evkey[i];
+                    int cn = 0;
+                    for (uint32_t j2 = s_evhead[c]; j2 != 0xffffu; j2 = s_evnext[j2]) cn += (s_evkey[j2] == key);
+                    if (cn > bc || (cn == bc && key < bk)) { bc = cn; bk = key; }
+                }
+                const int none = arrived - instot + 1, total = arrived + 1;
+                if (bc > none && vote_wins(bc, total, homo)) {
+                    const int L = (int)(bk >> 24);
+                    for (int b = 0; b < L; b++) s_out[c][1 + nb++] = (uint8_t)((bk >> (2 * b)) & 3u);
+                }
+            }
+            int v[5], dev = 0;
+#pragma unroll
+            for (int b = 0; b < 5; b++) { v[b] = (int)CNT_GET(c, (uint32_t)b); dev += v[b]; }
+#pragma unroll
+            for (int b = 0; b < 4; b++) if ((int)own == b) v[b] += arrived - dev + 1;
+            const int total = arrived + 1;
+            int bestb = (int)own, bestc = 0;
+#pragma unroll
+            for (int b = 0; b < 5; b++) if ((int)own == b) bestc = v[b];
+#pragma unroll
+            for (int b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
+            if (bestb != (int)own && !vote_wins(bestc, total, homo)) bestb = (int)own;
+            s_own[c] = bestb < 4;
+            if (bestb < 4) s_out[c][1 + nb++] = (uint8_t)bestb;
+            s_out[c][0] = nb;
+            mine += nb;
+            if (nb != 1 || s_out[c][1] != (uint8_t)own) differs = true;
+        }
+        s_scan[lane] = (uint32_t)mine;
+        __syncthreads();
+        if (__ballot(differs) == 0ull) continue;          // the new cigar is one run of matches
+        int off = 0;
+        for (int i = 0; i < lane; i++) off += (int)s_scan[i];
+        for (int c = c0; c < c1; c++) { s_off[c] = (uint16_t)off; off += s_out[c][0]; }
+        // the first and the last column to replace: the first kept column at or after 25 / at or after blen - 1 - 25
+        const int sb = FSV_BND_SIDE, eb = blen - 1 - FSV_BND_SIDE;
+        int fs = 0x7fffffff, fe = 0x7fffffff;
+        for (int c = c0; c < c1; c++) { if (s_own[c] && c >= sb && c < fs) fs = c; if (s_own[c] && c >= eb && c < fe) fe = c; }
+        for (int d = 32; d >= 1; d >>= 1) { fs = min(fs, __shfl_xor(fs, d)); fe = min(fe, __shfl_xor(fe, d)); }
+        __syncthreads();
+        if (eb <= sb || fs == 0x7fffffff || fe == 0x7fffffff) continue;   // "if there are some gap at the end of x, it very likely miscorrection"
+        const int o0 = (int)s_off[fs] + s_out[fs][0] - 1, o1 = (int)s_off[fe] + s_out[fe][0] - 1;   // the two kept bases in the consensus
+        const int R0 = cws + fs, R1 = cws + fe, sc = LB - cws;    // first-pass coordinates of the stretch; sc: the later window's first column
+        const int o_split = sc <= fs ? o0 : (sc > fe ? o1 + 1 : (int)s_off[sc]);
+        const int lb_prev = (int)B.lb[gw - 1];
+        BndPatch bp;
+        bp.valid = 1; bp.pad = 0;
+        bp.ts = (uint16_t)max(0, R0 - lb_prev); bp.told = (uint16_t)max(0, min(R1, LB - 1) - R0 + 1); bp.tnew = (uint16_t)(o_split - o0);
+        bp.hs = (uint16_t)(max(R0, LB) - LB); bp.hold = (uint16_t)max(0, R1 - max(R0, LB) + 1); bp.hnew = (uint16_t)(o1 + 1 - o_split);
+        if (R0 < lb_prev || o1 + 1 - o0 > FSV_CW_STRIDE) {     // the stretch would reach a third window / outgrow its slot: left as the first pass had it
+            if (lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_WINDOW_KEPT);
+            continue;
+        }
+        uint8_t *dst = patch_bytes + (size_t)gw * FSV_CW_STRIDE;
+        for (int c = c0; c < c1; c++)
+            for (int b = 0; b < s_out[c][0]; b++) { const int pos = (int)s_off[c] + b; if (pos >= o0 && pos <= o1) dst[pos - o0] = s_out[c][1 + b]; }
+        if (lane == 0) patch[gw] = bp;
+#undef XB
+#undef CNT_ADD
+#undef CNT_GET
+    }
+}
+
+// one wavefront per grid window: the window with the patches of its two junctions applied, in place
+__global__ __launch_bounds__(64) void k_bnd_apply(const uint32_t *__restrict__ gwin_read, const uint32_t *__restrict__ gwin_off, const BndPatch *__restrict__ patch,
+                                                  const uint8_t *__restrict__ patch_bytes, const uint32_t *__restrict__ bnd_flag, uint32_t n_gwin,
+                                                  uint8_t *__restrict__ cwin, uint16_t *__restrict__ cwin_len, uint32_t *__restrict__ changed, uint32_t *__restrict__ warn)
+{
+    __shared__ uint8_t s_old[FSV_CW_STRIDE];
+    const uint32_t gw = blockIdx.x;
+    if (gw >= n_gwin) return;
+    const uint32_t r = gwin_read[gw];
+    const bool has_h = gw > gwin_off[r] && bnd_flag[gw] && patch[gw].valid;
+    const bool has_t = gw + 1 < gwin_off[r + 1] && bnd_flag[gw + 1] && patch[gw + 1].valid;
+    if (!has_h && !has_t) return;
+    const int lane = threadIdx.x;
+    const int len = cwin_len[gw];
+    uint8_t *w = cwin + (size_t)gw * FSV_CW_STRIDE;
+    for (int i = lane; i < len; i += 64) s_old[i] = w[i];
+    __syncthreads();
+    int hs = 0, hold = 0, hnew = 0, ts = len, told = 0, tnew = 0;
+    const uint8_t *hb = nullptr, *tb = nullptr;
+    if (has_h) { const BndPatch p = patch[gw]; hs = p.hs; hold = p.hold; hnew = p.hnew; hb = patch_bytes + (size_t)gw * FSV_CW_STRIDE + p.tnew; }
+    if (has_t) { const BndPatch p = patch[gw + 1]; ts = p.ts; told = p.told; tnew = p.tnew; tb = patch_bytes + (size_t)(gw + 1) * FSV_CW_STRIDE; }
+    if (told == 0 && tnew == 0) ts = len;
+    const int new_len = len - hold + hnew - told + tnew;
+    if (hs + hold > ts || ts + told > len || new_len > FSV_CW_STRIDE || new_len < 0) {   // cannot happen with windows of ~375 bases: keep the first pass
+        if (lane == 0) atomicOr(&warn[r], (uint32_t)FSV_W_WINDOW_KEPT);
+        return;
+    }
+    // [0, hs) | head patch | [hs + hold, ts) | tail patch | [ts + told, len)
+    const int a1 = hs, a2 = a1 + hnew, a3 = a2 + (ts - hs - hold), a4 = a3 + tnew;
+    for (int i = lane; i < new_len; i += 64) {
+        uint8_t v;
+        if (i < a1) v = s_old[i];
+        else if (i < a2) v = hb[i - a1];
+        else if (i < a3) v = s_old[hs + hold + (i - a2)];
+        else if (i < a4) v = tb[i - a3];
+        else v = s_old[ts + told + (i - a4)];
+        w[i] = v;
+    }
+    if (lane == 0) { cwin_len[gw] = (uint16_t)new_len; changed[r] = 1u; }
 }
 
 // ------------------------------------------------------------------------------------------------ k_exact

@@ -162,6 +162,9 @@ typedef struct fsv_asm_params {
     int32_t w_later;          /* minimizer window from the second correction round on; 0 = w throughout (hifiasm) */
     int32_t partition;        /* 1: haplotype partition of every read's overlaps before the consensus, as hifiasm (partition_overlaps_advance,
                                * Correct.cpp:7127); 0: off (the ONT profile: at 10 % error coincident errors pass for alleles) */
+    int32_t second_round;     /* 1 (default): hifiasm's second consensus pass over the window junctions (process_boundary, Correct.cpp:4453): K5 + K6 +
+                               * consensus once more per junction.  0: a vote on the bases both window alignments skip at a junction stands in for
+                               * it -- a quarter faster, same reads after three rounds on all but one of 7 800 golden reads (ONT profile: 0) */
 } fsv_asm_params;
 void fsv_asm_default_params(fsv_asm_params *p);
 /* ONT-profile reads (BASELINE configs[4]: ~10 % error): k = 15, w = 15 without homopolymer compression (a 30 kb read then has ~3 750 minimizers: below the 4 096 a list holds), chain indel budget 0.15 / 0.05,

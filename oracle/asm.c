@@ -930,7 +930,7 @@ void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->partition = 1;
-    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 0;
+    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1;
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),

@@ -54,6 +54,28 @@ def test_rounds_match_oracle(ctx, rounds):
         assert mine == oc, (rounds, si, [len(c) for c in mine], [len(c) for c in oc])
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 3])
+def test_second_consensus_pass_matches_oracle(ctx, rounds):
+    """fsv_asm_params.second_round: hifiasm's second pass over the window junctions (process_boundary) on the GPU against
+    oracle/asm.c's, which is pinned to `hifiasm -r 1 / -r 2`: corrected reads and contigs bit for bit on phased sets of three
+    coverages, a mixed set, a repeat-rich set and a tandem-repeat region"""
+    regs = [synth.make_region(3), synth.make_region(600, width=26000, depth_per_hap=8.0), synth.make_region(7)]
+    sets = [regs[0].reads[0], regs[0].reads[1], regs[1].reads[0], regs[0].reads[0] + regs[0].reads[1], synth.make_repeat_region(15).reads[0], regs[2].reads[1]]
+    p = ctx.default_asm_params()
+    p.n_rounds, p.second_round = rounds, 1
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets, p)
+    po = O.default_params()
+    po.n_rounds, po.second_round = rounds, 1
+    k = 0
+    for si, s in enumerate(sets):
+        oc, ocorr = O.assemble(s, po)
+        bad = [j for j in range(len(s)) if reads[k + j] != ocorr[j]]
+        assert not bad, (rounds, si, bad[:8], [(len(reads[k + j]), len(ocorr[j])) for j in bad[:8]])
+        k += len(s)
+        mine = [c for c, cs in zip(contigs, cset) if cs == si]
+        assert mine == oc, (rounds, si, [len(c) for c in mine], [len(c) for c in oc])
+
+
 def test_batch_of_regions_matches_oracle_and_haplotypes(ctx):
     regions = [synth.make_region(i) for i in (0, 7, 22, 38)]
     sets = [rd for r in regions for rd in r.reads]

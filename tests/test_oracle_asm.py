@@ -94,7 +94,7 @@ def _repeat_sets(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
 
 # (set, read): our corrected read is one base shorter / longer at one END than hifiasm's; both are exact substrings of the planted
 # haplotype (the same read-end class as KNOWN_READ_END_DEVIATIONS)
-REPEAT_READ_END_DEVIATIONS = {(15, 13)}
+REPEAT_READ_END_DEVIATIONS = set()
 # sets where hifiasm-0.14 itself collapses one copy of a long exact repeat (its contig is shorter than the planted haplotype);
 # this restatement returns the haplotype
 REPEAT_HIFIASM_COLLAPSES = {12}
