@@ -35,10 +35,10 @@ struct KTimes {
     void reset() { recs.clear(); used = 0; }
     ~KTimes() { for (auto e : pool) (void)hipEventDestroy(e); }
 };
-enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_PARTITION, KN_COUNT,
+enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_PARTITION, KN_BND, KN_COUNT,
        ST_SKETCH = KN_COUNT, ST_CHAIN, ST_VERIFY, ST_PATH, ST_CONSENSUS, ST_FINAL };
 const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm", "k_rescue_accept", "k_path_fast", "k_path_dp", "k_consensus",
-                                        "k_repack", "k_exact", "k_stitch", "k_partition"};
+                                        "k_repack", "k_exact", "k_stitch", "k_partition", "k_bnd"};
 
 // a stage: from construction to stop(), in stream order
 struct Span {
@@ -492,6 +492,7 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
 {
     // where window g starts in the first pass's result, and that result as a 2-bit store behind a copy of the round's reads
     TRY(ensure(ctx, W.lb, (size_t)std::max(1u, n_gwin) * 4));
+    W.kt.begin(ctx, KN_BND, 0);
     hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
                        (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p, (uint32_t *)W.lb.p);
     FSV_HIP(ctx, hipGetLastError());
@@ -535,6 +536,8 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
     A.bnd_flag = (uint32_t *)W.bnd_flag.p; A.bnd_list = (uint32_t *)W.bnd_list.p; A.n_bnd = ct2 + CT_B_LIST;
     hipLaunchKernelGGL(k_bnd_tasks, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
+    W.kt.begin(ctx, KN_BPM, 0);
     // K5, once more with the doubled threshold for the tasks without an alignment, K6
     TRY(fsv_bpm_windows_dev_n(ctx, store2, (const fsv_wtask *)W.tasks2.p, task_cap, ct2 + CT_TASKS, (fsv_wres *)W.res2.p, P.k_cap));
     hipLaunchKernelGGL(k_bnd_retry, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, (fsv_wtask *)W.tasks2.p, (const fsv_wres *)W.res2.p,
@@ -544,11 +547,12 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
     hipLaunchKernelGGL(k_bnd_scatter, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, (fsv_wres *)W.res2.p, (const fsv_wres *)W.res3.p,
                        (const uint32_t *)W.src3.p, (const uint32_t *)(ct2 + CT_B_RETRY));
     FSV_HIP(ctx, hipGetLastError());
+    W.kt.end(ctx);
     TRY(path_stage(ctx, W, store2, (const fsv_wtask *)W.tasks2.p, (const fsv_wres *)W.res2.p, (fsv_wpath *)W.paths2.p, task_cap, (const uint32_t *)(ct2 + CT_TASKS), ct2,
                    round, wide_bands, P, false));
     // the junctions' consensus, handed to the windows as patches
     const uint32_t grid_l = std::min<uint32_t>(std::max(1u, n_gwin), (uint32_t)ctx->n_cu * 16);
-    W.kt.begin(ctx, KN_CONSENSUS, 0);
+    W.kt.begin(ctx, KN_BND, 0);
     if (wide_bands) hipLaunchKernelGGL(k_bnd_consensus<FSV_EV_CAP_WIDE>, dim3(grid_l), dim3(64), 0, ctx->stream, C, A, (const fsv_wpath *)W.paths2.p, (const uint32_t *)store2,
                                        (BndPatch *)W.bnd_patch.p, (uint8_t *)W.bnd_bytes.p);
     else hipLaunchKernelGGL(k_bnd_consensus<FSV_EV_CAP>, dim3(grid_l), dim3(64), 0, ctx->stream, C, A, (const fsv_wpath *)W.paths2.p, (const uint32_t *)store2,
@@ -1023,7 +1027,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     if (sets->set_start[0] != 0 || sets->set_start[sets->n_sets] != sets->n_reads) return fsv_fail(ctx, FSV_EINVAL, "set_start must span [0, n_reads]");
     for (uint32_t s = 0; s < sets->n_sets; s++) if (sets->set_start[s + 1] < sets->set_start[s]) return fsv_fail(ctx, FSV_EINVAL, "set_start not monotone");
     // Read sets are independent, so a batch that is too large for one pass -- 32-bit pair / task / offset indices, or a workspace
-    // beyond the budget (FSV_ASM_BUDGET_GB, default 40 % of the device's memory: ~200 B per window task, ~200 B per read pair,
+    // beyond the budget (FSV_ASM_BUDGET_GB, default 40 % of the device's memory: ~200 B per window task (400 with the second consensus pass), ~200 B per read pair,
     // ~48 B per base) -- is cut into runs of consecutive sets that go through one after the other; the caller sees one call.
     // (Round 1 returned FSV_EUNSUP and left the splitting to the caller.)
     const char *env = getenv("FSV_ASM_BUDGET_GB");
@@ -1036,7 +1040,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
             set_cost(sets, s, t1, p1, b1);
             if (t1 >= (1ull << 31) || p1 >= (1ull << 31) || b1 + b1 / 4 >= (1ull << 32)) return fsv_fail(ctx, FSV_EUNSUP, "a single read set exceeds the 2^31 window-task / pair bound");
             const bool over = tk + t1 >= (1ull << 31) || pr + p1 >= (1ull << 31) || (bs + b1) + (bs + b1) / 4 >= (1ull << 32) ||     /* minimizer slots: one per base + slack, 32-bit offsets */
-                              (double)(tk + t1) * 200.0 + (double)(pr + p1) * 200.0 + (double)(bs + b1) * 48.0 > budget;
+                              (double)(tk + t1) * (P.second_round ? 400.0 : 200.0) + (double)(pr + p1) * 200.0 + (double)(bs + b1) * (P.second_round ? 52.0 : 48.0) > budget;   /* second pass: the junction tasks' records, the patch slots */
             if (over && s > cut.back()) { cut.push_back(s); tk = pr = bs = 0; }
             tk += t1; pr += p1; bs += b1;
         }
