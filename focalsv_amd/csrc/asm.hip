@@ -533,7 +533,7 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
     A.cov3 = (const uint8_t *)W.cov3.p; A.read_dirty = (const uint32_t *)W.read_dirty.p;
     A.brel_off = (const uint32_t *)W.brel_off.p; A.b_base = a_words; A.thr_tab = (const uint8_t *)W.thr_tab.p;
     A.tasks2 = (fsv_wtask *)W.tasks2.p; A.idx2 = (int32_t *)W.idx2.p; A.n_tasks2 = ct2 + CT_TASKS;
-    A.bnd_flag = (uint32_t *)W.bnd_flag.p; A.bnd_list = (uint32_t *)W.bnd_list.p; A.n_bnd = ct2 + CT_B_LIST;
+    A.bnd_flag = (uint32_t *)W.bnd_flag.p; A.bnd_list = (uint32_t *)W.bnd_list.p; A.n_bnd = ct2 + CT_B_LIST; A.store2 = store2;
     hipLaunchKernelGGL(k_bnd_tasks, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);

@@ -2082,7 +2082,8 @@ struct BndArgs {
     const uint32_t *brel_off; uint32_t b_base;      // first-pass result of read r in the second-pass store: word b_base + brel_off[r]
     const uint8_t *thr_tab;
     fsv_wtask *tasks2; int32_t *idx2; uint32_t *n_tasks2;      // junction tasks; idx2[window task] = its junction task or -1
-    uint32_t *bnd_flag, *bnd_list, *n_bnd;                    // junctions with at least one task
+    uint32_t *bnd_flag, *bnd_list, *n_bnd;                    // per junction: bit 0 = has a task (and is in the list), the rest = alignments that match base for base
+    const uint32_t *store2;                                   // the second-pass store: the round's reads, then the first pass's result
 };
 
 __global__ __launch_bounds__(256) void k_bnd_tasks(BndArgs A)
@@ -2109,13 +2110,28 @@ __global__ __launch_bounds__(256) void k_bnd_tasks(BndArgs A)
     const int cws = max(0, LB - FSV_BND_HALF), cwe = min(len_now - 1, LB + FSV_BND_HALF - 1), blen = cwe - cws + 1;
     const int y_start = (int)h0.x - FSV_BND_HALF;
     if (y_start < 0 || blen < 1) return;
+    // about half of the partner reads match the first pass's result base for base on the predicted diagonal (K5 would report distance 0
+    // ending on that diagonal, K6 an all-match path): such an alignment only counts towards the junction's coverage
+    const uint32_t xw2 = A.b_base + A.brel_off[r];
+    if (y_start + blen <= t.y_len) {
+        bool same = true;
+        for (int b = 0; b < blen && same; b += 16) {
+            const uint32_t xb = fetch16_x(A.store2, xw2, cws + b);
+            const Bases16 yb = fetch16(A.store2, t.y_word, t.y_len, t.y_rev, y_start + b);
+            uint32_t d = xb ^ yb.bits;
+            const int lim = min(16, blen - b);
+            if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+            same = d == 0u;
+        }
+        if (same) { A.idx2[ti] = -2; atomicAdd(&A.bnd_flag[gw], 2u); return; }
+    }
     const uint32_t slot = atomicAdd(A.n_tasks2, 1u);
     fsv_wtask w;
-    w.x_word = A.b_base + A.brel_off[r]; w.y_word = t.y_word; w.x_start = cws; w.y_start = y_start; w.y_len = t.y_len;
+    w.x_word = xw2; w.y_word = t.y_word; w.x_start = cws; w.y_start = y_start; w.y_len = t.y_len;
     w.x_len = (uint16_t)blen; w.k = A.thr_tab[blen]; w.y_rev = t.y_rev; w.ovl = p; w.win = ti;
     A.tasks2[slot] = w;
     A.idx2[ti] = (int32_t)slot;
-    if (atomicExch(&A.bnd_flag[gw], 1u) == 0u) A.bnd_list[atomicAdd(A.n_bnd, 1u)] = gw;
+    if (!(atomicOr(&A.bnd_flag[gw], 1u) & 1u)) A.bnd_list[atomicAdd(A.n_bnd, 1u)] = gw;
 }
 
 // junction tasks K5 found no alignment for get the doubled threshold (Correct.cpp:4585-4626) and go round once more
@@ -2186,6 +2202,7 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
             const int j = g - o_x_s / FSV_WINDOW;
             if (!(oc.z >> 31) || j < 0 || j >= o_n_win || o_x_s > gs) continue;
             const int32_t slot = B.idx2[oc.y + (uint32_t)j];
+            if (slot == -2) { atomicAdd(&s_cover, 1u); atomicAdd(&s_cov[0], 1); atomicAdd(&s_cov[blen], -1); continue; }   // matches base for base
             if (slot < 0) continue;
             const fsv_wpath *P = paths2 + slot;
             const uint4 h0 = *reinterpret_cast<const uint4 *>(P);
@@ -2333,8 +2350,8 @@ __global__ __launch_bounds__(64) void k_bnd_apply(const uint32_t *__restrict__ g
     const uint32_t gw = blockIdx.x;
     if (gw >= n_gwin) return;
     const uint32_t r = gwin_read[gw];
-    const bool has_h = gw > gwin_off[r] && bnd_flag[gw] && patch[gw].valid;
-    const bool has_t = gw + 1 < gwin_off[r + 1] && bnd_flag[gw + 1] && patch[gw + 1].valid;
+    const bool has_h = gw > gwin_off[r] && (bnd_flag[gw] & 1u) && patch[gw].valid;
+    const bool has_t = gw + 1 < gwin_off[r + 1] && (bnd_flag[gw + 1] & 1u) && patch[gw + 1].valid;
     if (!has_h && !has_t) return;
     const int lane = threadIdx.x;
     const int len = cwin_len[gw];
