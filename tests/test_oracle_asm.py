@@ -151,8 +151,9 @@ def _round_sets(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
 
 
 # After the FIRST round one or two reads of these sets still differ from hifiasm's (after the second round all 88 sets are
-# identical): where all overlaps insert two bases whose second equals the next backbone base, hifiasm's insertion consensus
-# (build_DAGCon, Correct.cpp:3219-3950) emits one base and this column vote both; the rest untraced.  Listed so that a fix shows.
+# identical): where the overlaps disagree about what is inserted between two columns, hifiasm walks a DAG of the inserted strings
+# and stops where the first string ends (15 x "CG" + 1 x "C" gives "C": build_DAGCon / generate_seq_from_node, Correct.cpp:3745-3951);
+# this column vote inserts the most frequent string.  Listed so that a fix shows.
 KNOWN_ROUND1_DEVIATIONS = {4, 9, 16, 18, 27, 30, 33, 46, 63, 74, 77, 82, 83, 86, 87}
 
 
