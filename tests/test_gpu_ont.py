@@ -52,3 +52,27 @@ def test_contigs_equal_the_oracle(ont):
         for h in (0, 1):
             oc, _ = O.assemble(regions[ri].reads[h], O.ont_params())
             assert [c for r2, hp, c in res.contigs if r2 == ri and hp == h + 1] == oc
+
+
+def test_second_consensus_pass_with_wide_bands_equals_the_oracle():
+    """second_round = 1 on ONT-profile reads (off in fsv_asm_ont_params): the junction tasks go through the wide-band K5 / K6 too;
+    corrected reads and contigs equal the oracle's bit for bit"""
+    from focalsv_amd import _lib
+    from tests.test_gpu_asm import gpu_assemble
+    ctx = _lib.Context(0)
+    try:
+        r = synth.make_region(5, width=30000, profile="ont")
+        sets = [r.reads[0], r.reads[1]]
+        p = ctx.ont_asm_params()
+        p.second_round = 1
+        contigs, cset, status, reads, b = gpu_assemble(ctx, sets, p)
+        po = O.ont_params()
+        po.second_round = 1
+        k = 0
+        for si, s in enumerate(sets):
+            oc, ocorr = O.assemble(s, po)
+            assert [reads[k + j] for j in range(len(s))] == ocorr, si
+            k += len(s)
+            assert [c for c, cs in zip(contigs, cset) if cs == si] == oc, si
+    finally:
+        ctx.close()
