@@ -1410,6 +1410,247 @@ __global__ void k_gwin_tab(const uint32_t *__restrict__ gwin_read, const uint32_
 // haplotype partition is marked (site_cnt[gw] = FSV_SITE_MARK) -- the consensus written here is then provisional: k_snp_sites and
 // k_hap_partition run next, and the windows of a read that lost overlaps to the partition are redone.  MODE 2: that redo.
 #define FSV_SITE_MARK 0xffffffffu
+// ---- what is inserted in front of a column: hifiasm's DAG of the inserted strings ---------------------------------------------
+// build_DAGCon / Merge_DAGCon / generate_best_seq_from_nodes (Correct.cpp:3219-3951), as oracle/asm.c:dagcon_insertion restates
+// them: one chain S -> b1 -> ... -> E per distinct string (here in ascending key order) weighted by its count, nodes gone through
+// in topological order merging per base the in-nodes with one out-edge and the out-nodes with one in-edge, node weight = sum of the
+// out-edges (E: in-edges), greedy walk forward from S's heaviest out-node or backward from E's heaviest in-node.  One lane runs it
+// on a scratch in LDS; beyond the bounds (FSV_DG_*) the caller inserts the most frequent string instead, as the oracle does.
+#define FSV_DG_N 64
+#define FSV_DG_E 128
+#define FSV_DG_A 8
+#define FSV_DG_D 8
+#define FSV_DG_K 64
+struct DagLds {
+    uint32_t keys[FSV_DG_K];
+    uint16_t e_w[FSV_DG_E];
+    uint8_t e_from[FSV_DG_E], e_to[FSV_DG_E], e_alive[FSV_DG_E], e_vis[FSV_DG_E];
+    uint8_t base[FSV_DG_N], alive[FSV_DG_N], out_n[FSV_DG_N], in_n[FSV_DG_N];
+    uint8_t out_e[FSV_DG_N][FSV_DG_A], in_e[FSV_DG_N][FSV_DG_A];
+    uint8_t queue[4 * FSV_DG_E];
+    uint8_t stk_node[16], stk_bi[16], stk_cons[16];
+    int n_node, n_edge, ok;
+};
+
+__device__ __forceinline__ int dg_node(DagLds &D, uint8_t b)
+{
+    const int id = D.n_node;
+    if (id >= FSV_DG_N) { D.ok = 0; return FSV_DG_N - 1; }
+    D.base[id] = b; D.alive[id] = 1; D.out_n[id] = 0; D.in_n[id] = 0; D.n_node = id + 1;
+    return id;
+}
+__device__ __forceinline__ void dg_edge(DagLds &D, int u, int v, int w, int vis)
+{
+    const int e = D.n_edge;
+    if (e >= FSV_DG_E || D.out_n[u] >= FSV_DG_A || D.in_n[v] >= FSV_DG_A) { D.ok = 0; return; }
+    D.e_from[e] = (uint8_t)u; D.e_to[e] = (uint8_t)v; D.e_w[e] = (uint16_t)w; D.e_alive[e] = 1; D.e_vis[e] = (uint8_t)vis; D.n_edge = e + 1;
+    D.out_e[u][D.out_n[u]++] = (uint8_t)e; D.in_e[v][D.in_n[v]++] = (uint8_t)e;
+}
+__device__ __forceinline__ int dg_find(const DagLds &D, int u, int v)
+{
+    for (int i = 0; i < D.in_n[v]; i++) { const int e = D.in_e[v][i]; if (D.e_alive[e] && D.e_from[e] == u) return e; }
+    return -1;
+}
+__device__ __forceinline__ int dg_outdeg(const DagLds &D, int u) { int c = 0; for (int i = 0; i < D.out_n[u]; i++) c += D.e_alive[D.out_e[u][i]]; return c; }
+__device__ __forceinline__ int dg_indeg(const DagLds &D, int u) { int c = 0; for (int i = 0; i < D.in_n[u]; i++) c += D.e_alive[D.in_e[u][i]]; return c; }
+__device__ __forceinline__ void dg_delete(DagLds &D, int x)
+{
+    D.alive[x] = 0; D.base[x] = 'D';
+    for (int i = 0; i < D.out_n[x]; i++) D.e_alive[D.out_e[x][i]] = 0;
+    for (int i = 0; i < D.in_n[x]; i++) D.e_alive[D.in_e[x][i]] = 0;
+    D.out_n[x] = 0; D.in_n[x] = 0;
+}
+// Merge_Out_Nodes (OUT) / Merge_In_Nodes (!OUT) with the recursion of the reference unrolled onto a small stack: a frame is
+// (node, next base); after the merges for one base the merged node is entered before the next base is looked at
+template <bool OUT>
+__device__ __forceinline__ void dg_merge(DagLds &D, int start)
+{
+    int sp = 0;
+    D.stk_node[0] = (uint8_t)start; D.stk_bi[0] = 0;
+    if (!D.alive[start] || (OUT ? dg_outdeg(D, start) : dg_indeg(D, start)) == 0) return;
+    while (sp >= 0 && D.ok) {
+        const int cur = D.stk_node[sp], bi = D.stk_bi[sp];
+        if (bi >= 4) { sp--; continue; }
+        D.stk_bi[sp] = (uint8_t)(bi + 1);
+        const uint8_t want = (uint8_t)("ACGT"[bi]);
+        int flag = 0, weight = 0, cons = -1;
+        const int nl = OUT ? D.out_n[cur] : D.in_n[cur];
+        for (int i = 0; i < nl; i++) {
+            const int e = OUT ? D.out_e[cur][i] : D.in_e[cur][i];
+            if (!D.e_alive[e]) continue;
+            const int g = OUT ? D.e_to[e] : D.e_from[e];
+            if (D.base[g] != want || (OUT ? dg_indeg(D, g) : dg_outdeg(D, g)) != 1) continue;
+            if (flag == 0) { flag = 1; cons = g; D.e_vis[e] = 1; weight = D.e_w[e]; }
+            else {
+                flag++;
+                weight += D.e_w[e];
+                const int ng = OUT ? D.out_n[g] : D.in_n[g];
+                for (int j = 0; j < ng; j++) {
+                    const int e2 = OUT ? D.out_e[g][j] : D.in_e[g][j];
+                    if (!D.e_alive[e2]) continue;
+                    const int o = OUT ? D.e_to[e2] : D.e_from[e2];
+                    const int e3 = OUT ? dg_find(D, cons, o) : dg_find(D, o, cons);
+                    if (e3 >= 0) { D.e_vis[e3] = 1; D.e_w[e3] = (uint16_t)(D.e_w[e3] + D.e_w[e2]); }
+                    else if (OUT) dg_edge(D, cons, o, D.e_w[e2], 1);
+                    else dg_edge(D, o, cons, D.e_w[e2], 1);
+                }
+                dg_delete(D, g);
+            }
+        }
+        if (flag > 1) { const int e = OUT ? dg_find(D, cur, cons) : dg_find(D, cons, cur); if (e >= 0) D.e_w[e] = (uint16_t)weight; }
+        if (flag > 0 && D.alive[cons] && (OUT ? dg_outdeg(D, cons) : dg_indeg(D, cons)) != 0) {
+            if (sp + 1 >= 16) { D.ok = 0; return; }
+            sp++;
+            D.stk_node[sp] = (uint8_t)cons; D.stk_bi[sp] = 0;
+        }
+    }
+}
+__device__ __forceinline__ int dg_weight(const DagLds &D, int u, bool in)
+{
+    int w = 0;
+    if (in) { for (int i = 0; i < D.in_n[u]; i++) if (D.e_alive[D.in_e[u][i]]) w += D.e_w[D.in_e[u][i]]; }
+    else for (int i = 0; i < D.out_n[u]; i++) if (D.e_alive[D.out_e[u][i]]) w += D.e_w[D.out_e[u][i]];
+    return w;
+}
+// D.keys[0 .. nk): the column's inserted strings (len << 24 | 2-bit bases).  Returns max_insertion_count (-1: beyond the bounds)
+__device__ __forceinline__ int dag_insertion(DagLds &D, int nk, uint32_t &out_key)
+{
+    out_key = 0;
+    if (nk > FSV_DG_K) return -1;
+    for (int z = 1; z < nk; z++) { const uint32_t kv = D.keys[z]; int z2 = z; for (; z2 > 0 && D.keys[z2 - 1] > kv; z2--) D.keys[z2] = D.keys[z2 - 1]; D.keys[z2] = kv; }
+    uint32_t distinct[FSV_DG_D]; int cnt[FSV_DG_D], nd = 0;
+    for (int i = 0; i < nk; i++) {
+        if (nd && distinct[nd - 1] == D.keys[i]) { cnt[nd - 1]++; continue; }
+        if (nd == FSV_DG_D) return -1;
+        distinct[nd] = D.keys[i]; cnt[nd] = 1; nd++;
+    }
+    if (nd == 1) { out_key = distinct[0]; return cnt[0]; }      // one string: the chain itself
+    D.n_node = 0; D.n_edge = 0; D.ok = 1;
+    const int S = dg_node(D, 'S'), E = dg_node(D, 'E');
+    for (int i = 0; i < nd; i++) {
+        const int len = (int)(distinct[i] >> 24);
+        int last = S;
+        for (int j = 0; j < len; j++) { const int nn = dg_node(D, (uint8_t)("ACGT"[(distinct[i] >> (2 * j)) & 3u])); dg_edge(D, last, nn, cnt[i], 0); last = nn; }
+        if (last != S) dg_edge(D, last, E, cnt[i], 0);
+    }
+    int qh = 0, qt = 0;
+    D.queue[qt++] = (uint8_t)S;
+    while (qh < qt && D.ok) {
+        const int cur = D.queue[qh++];
+        dg_merge<false>(D, cur);
+        dg_merge<true>(D, cur);
+        if (!D.alive[cur]) continue;
+        for (int i = 0; i < D.out_n[cur]; i++) if (D.e_alive[D.out_e[cur][i]]) D.e_vis[D.out_e[cur][i]] = 1;
+        for (int i = 0; i < D.out_n[cur]; i++) {
+            const int e = D.out_e[cur][i];
+            if (!D.e_alive[e]) continue;
+            const int o = D.e_to[e];
+            bool all = true;
+            for (int j = 0; j < D.in_n[o]; j++) if (D.e_alive[D.in_e[o][j]] && !D.e_vis[D.in_e[o][j]]) { all = false; break; }
+            if (all) { if (qt < 4 * FSV_DG_E) D.queue[qt++] = (uint8_t)o; else D.ok = 0; }
+        }
+    }
+    if (!D.ok) return -1;
+    int best_s = -1, best_e = -1, ws = 0, we = 0;
+    for (int i = 0; i < D.out_n[S]; i++) { const int e = D.out_e[S][i]; if (D.e_alive[e]) { const int o = D.e_to[e], w = o == E ? dg_weight(D, E, true) : dg_weight(D, o, false); if (w > ws) { ws = w; best_s = o; } } }
+    for (int i = 0; i < D.in_n[E]; i++) { const int e = D.in_e[E][i]; if (D.e_alive[e]) { const int o = D.e_from[e], w = dg_weight(D, o, false); if (w > we) { we = w; best_e = o; } } }
+    uint32_t seq = 0; int L = 0;
+    if (ws >= we) {
+        int cur = best_s;
+        while (cur >= 0 && cur != E && L < FSV_DG_N) {
+            int mx = 0, nx = -1;
+            if (L < FSV_INS_MAXLEN) seq |= (uint32_t)(D.base[cur] == 'A' ? 0u : D.base[cur] == 'C' ? 1u : D.base[cur] == 'G' ? 2u : 3u) << (2 * L);
+            L++;
+            for (int i = 0; i < D.out_n[cur]; i++) { const int e = D.out_e[cur][i]; if (D.e_alive[e]) { const int o = D.e_to[e], w = o == E ? dg_weight(D, E, true) : dg_weight(D, o, false); if (w > mx) { mx = w; nx = o; } } }
+            cur = nx;
+        }
+    } else {
+        // backward: the bases come out last first
+        uint8_t rb[FSV_INS_MAXLEN + 4];
+        int cur = best_e;
+        while (cur >= 0 && cur != S && L < FSV_DG_N) {
+            int mx = 0, nx = -1;
+            if (L < FSV_INS_MAXLEN + 4) rb[L] = D.base[cur];
+            L++;
+            for (int i = 0; i < D.in_n[cur]; i++) { const int e = D.in_e[cur][i]; if (D.e_alive[e]) { const int o = D.e_from[e], w = dg_weight(D, o, false); if (w > mx) { mx = w; nx = o; } } }
+            cur = nx;
+        }
+        const int Lc = min(L, FSV_INS_MAXLEN + 4);
+        for (int i = 0; i < Lc && i < FSV_INS_MAXLEN; i++) { const uint8_t b = rb[Lc - 1 - i]; seq |= (uint32_t)(b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : 3u) << (2 * i); }
+    }
+    if (L > FSV_INS_MAXLEN) L = FSV_INS_MAXLEN;
+    out_key = ((uint32_t)L << 24) | seq;
+    return ws >= we ? ws : we;
+}
+
+// get_seq_from_Graph (Correct.cpp:4010-4129) at the node in front of one backbone column, as oracle/asm.c:vote_consensus: the
+// edges to the four bases (the backbone's own first; weight minus the votes that arrived "after an insertion" while the node still
+// has insertions to place), the inserted strings' DAG, the deletion edge; the heaviest wins if it has 60 % of the total (51.5 % when
+// the PREVIOUS backbone base sits in a homopolymer run); an insertion is written and the node looked at again without it.
+// W[b]: votes for base b (the backbone's own + 1), Ifl[b]: of those, votes whose previous cigar run was an insertion, dl: votes
+// without a partner for the column, ni: overlaps inserting in front of it, (mi, ikey): the DAG's answer.  out[0] = bases written.
+__device__ __forceinline__ bool poa_decide(const int W[4], const int Ifl[4], int dl, int ni, int mi, uint32_t ikey, int own, bool homo, uint8_t *out)
+{
+    uint8_t nb = 0;
+    bool kept = true;
+    for (int visit = 0; visit < 2; visit++) {
+        int maxc = -1, type = 0, edge = own, total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int b = k == 0 ? own : (k - 1 < own ? k - 1 : k);     // own first, then the others in base order
+            if (W[b] == 0) continue;
+            const int cw = ni ? W[b] - Ifl[b] : W[b];
+            total += cw;
+            if (cw > maxc) { maxc = cw; type = 0; edge = b; }
+        }
+        if (ni) { total += ni; if (mi > maxc) { maxc = mi; type = 1; } }
+        if (dl) { total += dl; if (dl > maxc) { maxc = dl; type = 2; } }
+        if (maxc * 5 >= total * 3 || (homo && maxc * 1000 >= total * 515)) {
+            if (type == 1) { const int L = (int)(ikey >> 24); for (int b = 0; b < L; b++) out[1 + nb++] = (uint8_t)((ikey >> (2 * b)) & 3u); ni = 0; continue; }
+            if (type == 2) { kept = false; break; }
+            out[1 + nb++] = (uint8_t)edge;
+            break;
+        }
+        out[1 + nb++] = (uint8_t)own;
+        break;
+    }
+    out[0] = nb;
+    return kept;
+}
+
+// the insertion consensus of every column that has insertions, by lane 0 (a handful per window): the column's keyed events are
+// gathered from its list, the DAG (or, beyond its bounds, the most frequent string) answers, and the answer replaces the list's head
+// event (key, count); bit 16 of the head marks the column as answered
+#define FSV_INSLIST 128
+#define COV_LO(v) ((int)(int16_t)((v) & 0xffff))
+#define COV_HI(v) (((int)(v) - COV_LO(v)) >> 16)
+template <int EVC>
+__device__ __forceinline__ void answer_insertions(DagLds &D, uint32_t *s_evhead, uint32_t *s_evkey, uint16_t *s_evnext, const uint16_t *s_inslist, int n_list, int n_cols)
+{
+    const int n = n_list > FSV_INSLIST ? n_cols : n_list;      // the list overflowed: every column
+    for (int li = 0; li < n; li++) {
+        const int c = n_list > FSV_INSLIST ? li : (int)s_inslist[li];
+        const uint32_t head = s_evhead[c] & 0xffffu;
+        if (head == 0xffffu || (s_evhead[c] & 0x10000u)) continue;
+        int nk = 0;
+        for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) { if (nk < FSV_DG_K) D.keys[nk] = s_evkey[i]; nk++; }
+        uint32_t key = 0;
+        int mi = dag_insertion(D, nk, key);
+        if (mi < 0) {       // the most frequent string, the smaller key on a tie
+            int bc = 0; uint32_t bk = 0;
+            for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) {
+                const uint32_t k1 = s_evkey[i];
+                int cn = 0;
+                for (uint32_t j2 = head; j2 != 0xffffu; j2 = s_evnext[j2]) cn += (s_evkey[j2] == k1);
+                if (cn > bc || (cn == bc && k1 < bk)) { bc = cn; bk = k1; }
+            }
+            mi = bc; key = bk;
+        }
+        s_evkey[head] = key; s_evnext[head] = (uint16_t)mi;
+        s_evhead[c] |= 0x10000u;
+    }
+}
+
 struct SiteLists {
     uint32_t *site_cnt;        // per grid window: FSV_SITE_MARK after k_consensus<., 1>, the number of kept sites after k_snp_sites
     uint32_t *win_list;        // marked windows, [0] of win_n
@@ -1430,6 +1671,12 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     __shared__ uint32_t s_evkey[EVC];
     __shared__ uint32_t s_evhead[FSV_WINDOW + 1];
     __shared__ uint32_t s_evn, s_cover, s_anydev;   // s_anydev: some overlap deviates from the backbone somewhere in this window
+    // s_cov's upper halves: difference array of the match runs that follow an insertion (the votes hifiasm counts as "after an insertion")
+    __shared__ uint32_t s_fl[FSV_WINDOW + 1];      // the same for mismatch runs: per column, 8 bits per base
+    __shared__ uint16_t s_inslist[FSV_INSLIST];    // columns whose inserted strings disagree
+    __shared__ uint32_t s_nins;
+    static_assert(sizeof(DagLds) <= sizeof(uint32_t) * 64 * 27, "the DAG scratch lives in the path buffer between the tally and the decisions");
+    DagLds &s_dag = *reinterpret_cast<DagLds *>(&s_path[0][0]);
     __shared__ uint32_t s_xraw[28];                // raw store words covering x[gs-16 .. gs+glen+16)
     __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
@@ -1453,7 +1700,8 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_evhead[i] = 0xffffu;
-    if (lane == 0) { s_evn = 0; s_cover = 0; s_anydev = 0; }
+    for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_fl[i] = 0;
+    if (lane == 0) { s_evn = 0; s_cover = 0; s_anydev = 0; s_nins = 0; }
     __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
 #define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
@@ -1500,7 +1748,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
         }
         // deviations: skip the all-match remainder of a path word at a time; n2 / n3 = y-only / x-only ops seen so far
 #define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
-        int n2 = 0, n3 = 0;
+        int n2 = 0, n3 = 0, fstart = -1, fmm_pos = -1;
         if (clean_path && pend) { CNT_ADD(xs, 5u); pend = false; }   // the first op is a match at column xs
         for (int p = 0; !clean_path && p < plen;) {
             const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1); // this word from field p on (fields past plen are 0)
@@ -1508,7 +1756,9 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
             dev_here = true;
             const uint32_t op = rest & 3u;
             const int xp = xs + p - n2;
+            if (fstart >= 0 && op != 0u) { atomicAdd(&s_cov[fstart], 65536); atomicAdd(&s_cov[xp], -65536); fstart = -1; }   // the match run after an insertion ends here
             if (op == 2u) { // run of y-only ops in front of column xp
+                fmm_pos = -1;
                 int L = 1;
                 while (p + L < plen && OP(p + L) == 2u) L++;
                 if (xp < glen) {
@@ -1524,12 +1774,20 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
                 n2 += L; p += L;
                 continue;
             }
+            const bool after_ins = pend && p > 0;      // (a junction vote is no cigar run)
             if (pend) { CNT_ADD(xp, 5u); pend = false; }
-            if (op == 3u) { CNT_ADD(xp, 4u); n3++; }
-            else if (op == 1u) CNT_ADD(xp, YB(ry_start + p - n3));
+            if (op == 3u) { CNT_ADD(xp, 4u); n3++; fmm_pos = -1; }
+            else if (op == 1u) {
+                const uint32_t yb = YB(ry_start + p - n3);
+                CNT_ADD(xp, yb);
+                // add_mismatchEdge_weight (POA.h:492) looks at the previous cigar RUN: every base of the run that follows an insertion
+                // counts as "after an insertion", not only the first
+                if (after_ins || fmm_pos == p) { atomicAdd(&s_fl[xp], 1u << (yb << 3)); fmm_pos = p + 1; } else fmm_pos = -1;
+            } else { if (after_ins) fstart = xp; fmm_pos = -1; }
             p++;
         }
 #undef OP
+        if (fstart >= 0) { atomicAdd(&s_cov[fstart], 65536); atomicAdd(&s_cov[xs + plen - n2], -65536); }
         // coverage interval: every x base of the task is consumed exactly once
         const int xcols = plen - n2;
         atomicAdd(&s_cov[xs], 1);
@@ -1540,12 +1798,23 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     __syncthreads();
     // arrived[c] = prefix sum of the difference array; each lane owns the contiguous columns [c0, c1)
     const int per = (glen + 63) / 64, c0 = min(glen, lane * per), c1 = min(glen, c0 + per);
-    int run = 0;
-    for (int c = c0; c < c1; c++) run += s_cov[c];
-    s_scan[lane] = (uint32_t)run;
+    // (low half: coverage, high half: the flagged match runs; both small signed numbers, so the halves separate exactly)
+    int run = 0, frun = 0;
+    for (int c = c0; c < c1; c++) {
+        const int v = s_cov[c];
+        run += COV_LO(v); frun += COV_HI(v);
+        if (CNT_GET(c, 5u)) {       // inserted strings that disagree go through the DAG (lane 0, below); one string answers itself
+            const uint32_t head = s_evhead[c];
+            bool same = true;
+            if (head != 0xffffu) { const uint32_t k0 = s_evkey[head]; for (uint32_t i = s_evnext[head]; i != 0xffffu; i = s_evnext[i]) if (s_evkey[i] != k0) { same = false; break; } }
+            if (!same) { const uint32_t k = atomicAdd(&s_nins, 1u); if (k < FSV_INSLIST) s_inslist[k] = (uint16_t)c; }
+        }
+    }
+    s_scan[lane] = ((uint32_t)run & 0xffffu) | ((uint32_t)frun << 16);
     __syncthreads();
-    int before = 0;
-    for (int i = 0; i < lane; i++) before += (int)s_scan[i];
+    int before = 0, fbefore = 0;
+    for (int i = 0; i < lane; i++) { before += (int)(int16_t)(s_scan[i] & 0xffffu); fbefore += (int)(int16_t)(s_scan[i] >> 16); }
+    if (lane == 0 && s_nins) answer_insertions<EVC>(s_dag, s_evhead, s_evkey, s_evnext, s_inslist, (int)s_nins, glen);
     __syncthreads();
     uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]); // 375 x 14 B = 5.2 KB <= 64 x 27 x 4 B; paths are done
     uint8_t *dst = A.cwin + (size_t)gw * FSV_CW_STRIDE;
@@ -1553,10 +1822,11 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     const bool verbatim = s_cover < 3u || s_anydev == 0u;
     if (A.cov3 && lane == 0) A.cov3[gw] = s_cover >= 3u ? 1 : 0;
     if (s_evn > (uint32_t)EVC && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
-    int arrived = before;
+    int arrived = before, farrived = fbefore;
     bool differs = false, site = false;
     for (int c = c0; c < c1; c++) {
-        arrived += s_cov[c];
+        arrived += COV_LO(s_cov[c]);
+        farrived += COV_HI(s_cov[c]);
         const uint32_t own = XB(gs + c);
         uint8_t nb = 0;
         if (MODE == 1 && !verbatim) {
@@ -1577,39 +1847,26 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
         }
         if (verbatim) { s_out[c][1] = (uint8_t)own; nb = 1; }
         else {
-            const int p = gs + c;
-            bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < xlen && XB(p + 1) == own);
-            const int instot = (int)CNT_GET(c, 5u);
-            if (instot) {
-                int bc = 0; uint32_t bk = 0;
-                // the most frequent inserted string of this column, the smaller key on a tie (the order of the list does not matter)
-                for (uint32_t i = s_evhead[c]; i != 0xffffu; i = s_evnext[i]) {
-                    const uint32_t key = s_evkey[i];
-                    int cn = 0;
-                    for (uint32_t j2 = s_evhead[c]; j2 != 0xffffu; j2 = s_evnext[j2]) cn += (s_evkey[j2] == key);
-                    if (cn > bc || (cn == bc && key < bk)) { bc = cn; bk = key; }
-                }
-                const int none = arrived - instot + 1, total = arrived + 1;
-                if (bc > none && vote_wins(bc, total, homo)) {
-                    const int L = (int)(bk >> 24);
-                    for (int b = 0; b < L; b++) s_out[c][1 + nb++] = (uint8_t)((bk >> (2 * b)) & 3u);
+            // the node in front of column c (poa_decide); the homopolymer relief looks at the PREVIOUS backbone base
+            const int q = gs + c - 1;
+            const bool homo = c > 0 && ((q > 0 && XB(q - 1) == XB(q)) || (q + 1 < xlen && XB(q + 1) == XB(q)));
+            int W[4], Ifl[4], dev = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) { W[b] = (int)CNT_GET(c, (uint32_t)b); dev += W[b]; Ifl[b] = (int)((s_fl[c] >> (b << 3)) & 0xffu); }
+            const int dl = (int)CNT_GET(c, 4u), ni = (int)CNT_GET(c, 5u);
+#pragma unroll
+            for (int b = 0; b < 4; b++) if ((int)own == b) { W[b] += arrived - dev - dl + 1; Ifl[b] = farrived; }
+            int mi = 0; uint32_t ikey = 0;
+            if (ni) {
+                const uint32_t hv = s_evhead[c], head = hv & 0xffffu;
+                if (head != 0xffffu) {
+                    ikey = s_evkey[head];
+                    if (hv & 0x10000u) mi = (int)s_evnext[head];                                   // the DAG's answer
+                    else for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) mi++;              // one string, mi times
                 }
             }
-            int v[5];
-            int dev = 0;
-#pragma unroll
-            for (int b = 0; b < 5; b++) { v[b] = (int)CNT_GET(c, (uint32_t)b); dev += v[b]; }
-            // matches vote for the backbone base; + the backbone's own weight of 1 (POA.cpp:269-307)
-#pragma unroll
-            for (int b = 0; b < 4; b++) if ((int)own == b) v[b] += arrived - dev + 1;
-            const int total = arrived + 1;
-            int bestb = (int)own, bestc = 0;
-#pragma unroll
-            for (int b = 0; b < 5; b++) if ((int)own == b) bestc = v[b];
-#pragma unroll
-            for (int b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
-            if (bestb != (int)own && !vote_wins(bestc, total, homo)) bestb = (int)own;
-            if (bestb < 4) s_out[c][1 + nb++] = (uint8_t)bestb;
+            poa_decide(W, Ifl, dl, ni, mi, ikey, (int)own, homo, &s_out[c][0]);
+            nb = s_out[c][0];
         }
         s_out[c][0] = nb;
         if (nb != 1 || s_out[c][1] != (uint8_t)own) differs = true;
@@ -2170,7 +2427,11 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
     __shared__ uint32_t s_evhead[FSV_WINDOW + 1];
     __shared__ uint16_t s_off[FSV_WINDOW + 2];      // where a column's output starts in the consensus
     __shared__ uint8_t s_own[FSV_WINDOW + 1];       // the column keeps a base (its own or another one)
-    __shared__ uint32_t s_evn, s_cover, s_terr;
+    __shared__ uint32_t s_evn, s_cover, s_terr, s_nins;
+    __shared__ uint32_t s_fl[FSV_WINDOW + 1];      // votes of the mismatch runs that follow an insertion: 8 bits per base
+    __shared__ uint16_t s_inslist[FSV_INSLIST];
+    static_assert(sizeof(DagLds) <= sizeof(uint32_t) * 64 * 27, "the DAG scratch lives in the path buffer between the tally and the decisions");
+    DagLds &s_dag = *reinterpret_cast<DagLds *>(&s_path[0][0]);
     __shared__ uint32_t s_xraw[28];
     __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
@@ -2191,7 +2452,8 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
         for (int i = lane; i < (FSV_WINDOW + 1) * 3; i += 64) (&s_cnt[0][0])[i] = 0;
         for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
         for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_evhead[i] = 0xffffu;
-        if (lane == 0) { s_evn = 0; s_cover = 0; s_terr = 0; }
+        for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_fl[i] = 0;
+        if (lane == 0) { s_evn = 0; s_cover = 0; s_terr = 0; s_nins = 0; }
         __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
 #define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
@@ -2221,12 +2483,15 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
 #define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))
 #define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
                 bool pend = false;
+                int fstart = -1, fmm_pos = -1;
                 for (int p = 0; p < plen;) {
                     const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1);
                     if (rest == 0u && !pend) { p = ((p >> 4) + 1) << 4; continue; }
                     const uint32_t op = rest & 3u;
                     const int xp = p - n2;
+                    if (fstart >= 0 && op != 0u) { atomicAdd(&s_cov[fstart], 65536); atomicAdd(&s_cov[xp], -65536); fstart = -1; }
                     if (op == 2u) {
+                        fmm_pos = -1;
                         int L = 1;
                         while (p + L < plen && OP(p + L) == 2u) L++;
                         if (xp < blen) {
@@ -2242,11 +2507,17 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
                         n2 += L; p += L;
                         continue;
                     }
+                    const bool after_ins = pend;
                     if (pend) { CNT_ADD(xp, 5u); pend = false; }
-                    if (op == 3u) { CNT_ADD(xp, 4u); n3++; }
-                    else if (op == 1u) CNT_ADD(xp, YB(ry_start + p - n3));
+                    if (op == 3u) { CNT_ADD(xp, 4u); n3++; fmm_pos = -1; }
+                    else if (op == 1u) {
+                        const uint32_t yb = YB(ry_start + p - n3);
+                        CNT_ADD(xp, yb);
+                        if (after_ins || fmm_pos == p) { atomicAdd(&s_fl[xp], 1u << (yb << 3)); fmm_pos = p + 1; } else fmm_pos = -1;
+                    } else { if (after_ins) fstart = xp; fmm_pos = -1; }
                     p++;
                 }
+                if (fstart >= 0) { atomicAdd(&s_cov[fstart], 65536); atomicAdd(&s_cov[plen - n2], -65536); }
 #undef OP
 #undef YB
             }
@@ -2257,52 +2528,51 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
         if (s_cover < 3u || s_terr == 0u) continue;       // MIN_COVERAGE_THRESHOLD; "if there are no error, we do not need correction"
         if (s_evn > (uint32_t)EVC && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
         const int per = (blen + 63) / 64, c0 = min(blen, lane * per), c1 = min(blen, c0 + per);
-        int run = 0;
-        for (int c = c0; c < c1; c++) run += s_cov[c];
-        s_scan[lane] = (uint32_t)run;
+        int run = 0, frun = 0;
+        for (int c = c0; c < c1; c++) {
+            const int v = s_cov[c];
+            run += COV_LO(v); frun += COV_HI(v);
+            if (CNT_GET(c, 5u)) {
+                const uint32_t head = s_evhead[c];
+                bool same = true;
+                if (head != 0xffffu) { const uint32_t k0 = s_evkey[head]; for (uint32_t i = s_evnext[head]; i != 0xffffu; i = s_evnext[i]) if (s_evkey[i] != k0) { same = false; break; } }
+                if (!same) { const uint32_t k = atomicAdd(&s_nins, 1u); if (k < FSV_INSLIST) s_inslist[k] = (uint16_t)c; }
+            }
+        }
+        s_scan[lane] = ((uint32_t)run & 0xffffu) | ((uint32_t)frun << 16);
         __syncthreads();
-        int arrived = 0;
-        for (int i = 0; i < lane; i++) arrived += (int)s_scan[i];
+        int arrived = 0, farrived = 0;
+        for (int i = 0; i < lane; i++) { arrived += (int)(int16_t)(s_scan[i] & 0xffffu); farrived += (int)(int16_t)(s_scan[i] >> 16); }
+        if (lane == 0 && s_nins) answer_insertions<EVC>(s_dag, s_evhead, s_evkey, s_evnext, s_inslist, (int)s_nins, blen);
         __syncthreads();
         uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]);
         bool differs = false;
         int mine = 0;
         for (int c = c0; c < c1; c++) {
-            arrived += s_cov[c];
+            arrived += COV_LO(s_cov[c]);
+            farrived += COV_HI(s_cov[c]);
             const int p = cws + c;
             const uint32_t own = XB(p);
-            uint8_t nb = 0;
-            const bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < len_now && XB(p + 1) == own);
-            const int instot = (int)CNT_GET(c, 5u);
-            if (instot) {
-                int bc = 0; uint32_t bk = 0;
-                for (uint32_t i = s_evhead[c]; i != 0xffffu; i = s_evnext[i]) {
-                    const uint32_t key = s_evkey[i];
-                    int cn = 0;
-                    for (uint32_t j2 = s_evhead[c]; j2 != 0xffffu; j2 = s_evnext[j2]) cn += (s_evkey[j2] == key);
-                    if (cn > bc || (cn == bc && key < bk)) { bc = cn; bk = key; }
-                }
-                const int none = arrived - instot + 1, total = arrived + 1;
-                if (bc > none && vote_wins(bc, total, homo)) {
-                    const int L = (int)(bk >> 24);
-                    for (int b = 0; b < L; b++) s_out[c][1 + nb++] = (uint8_t)((bk >> (2 * b)) & 3u);
+            const int q = p - 1;
+            const bool homo = c > 0 && ((q > 0 && XB(q - 1) == XB(q)) || (q + 1 < len_now && XB(q + 1) == XB(q)));
+            int W[4], Ifl[4], dev = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) { W[b] = (int)CNT_GET(c, (uint32_t)b); dev += W[b]; Ifl[b] = (int)((s_fl[c] >> (b << 3)) & 0xffu); }
+            const int dl = (int)CNT_GET(c, 4u), ni = (int)CNT_GET(c, 5u);
+#pragma unroll
+            for (int b = 0; b < 4; b++) if ((int)own == b) { W[b] += arrived - dev - dl + 1; Ifl[b] = farrived; }
+            int mi = 0; uint32_t ikey = 0;
+            if (ni) {
+                const uint32_t hv = s_evhead[c], head = hv & 0xffffu;
+                if (head != 0xffffu) {
+                    ikey = s_evkey[head];
+                    if (hv & 0x10000u) mi = (int)s_evnext[head];
+                    else for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) mi++;
                 }
             }
-            int v[5], dev = 0;
-#pragma unroll
-            for (int b = 0; b < 5; b++) { v[b] = (int)CNT_GET(c, (uint32_t)b); dev += v[b]; }
-#pragma unroll
-            for (int b = 0; b < 4; b++) if ((int)own == b) v[b] += arrived - dev + 1;
-            const int total = arrived + 1;
-            int bestb = (int)own, bestc = 0;
-#pragma unroll
-            for (int b = 0; b < 5; b++) if ((int)own == b) bestc = v[b];
-#pragma unroll
-            for (int b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
-            if (bestb != (int)own && !vote_wins(bestc, total, homo)) bestb = (int)own;
-            s_own[c] = bestb < 4;
-            if (bestb < 4) s_out[c][1 + nb++] = (uint8_t)bestb;
-            s_out[c][0] = nb;
+            const bool kept = poa_decide(W, Ifl, dl, ni, mi, ikey, (int)own, homo, &s_out[c][0]);
+            const uint8_t nb = s_out[c][0];
+            s_own[c] = kept;
             mine += nb;
             if (nb != 1 || s_out[c][1] != (uint8_t)own) differs = true;
         }

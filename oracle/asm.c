@@ -474,10 +474,196 @@ static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ov
     return W;
 }
 
+/* ---------------------------------------------------------------- the consensus of the strings inserted in front of a column
+ * build_DAGCon (Correct.cpp:3893-3951): every distinct inserted string is a chain S -> b1 -> ... -> E weighted by the number of
+ * overlaps that insert it (in the order the strings first appear); Merge_DAGCon (:3550) goes through the nodes in topological order
+ * and merges, per base, the in-nodes of a node that have one out-edge and the out-nodes that have one in-edge (Merge_In_Nodes /
+ * Merge_Out_Nodes :3219-3430: from S a prefix trie, from E backwards the unary tails); generate_best_seq_from_nodes (:3804) gives
+ * every node the sum of its out-edges as weight (E: of its in-edges) and walks greedily -- forward from S's heaviest out-node when
+ * that weighs at least as much as E's heaviest in-node, else backward from that in-node; as E (S) carries the weight of ALL strings
+ * the walk ends at the first node where some string ends (starts).  Restated on small arrays, edge lists in insertion order with
+ * tombstones as in POA.h:214-490.  Returns the weight of the walk's first node (max_insertion_count) and the string. */
+#define DG_MAXN 64        /* bounds of the HIP path (FSV_DG_*): beyond them the most frequent string is inserted */
+#define DG_MAXE 128
+#define DG_MAXD 8         /* distinct strings */
+#define DG_MAXA 8         /* edges on one side of a node */
+#define DG_MAXK 64        /* inserted strings at one column */
+typedef struct {
+    int n_node, n_edge;
+    char base[DG_MAXN]; uint8_t alive[DG_MAXN];
+    int e_from[DG_MAXE], e_to[DG_MAXE], e_w[DG_MAXE]; uint8_t e_alive[DG_MAXE], e_vis[DG_MAXE];
+    int out_n[DG_MAXN], in_n[DG_MAXN];
+    int16_t out_e[DG_MAXN][DG_MAXA], in_e[DG_MAXN][DG_MAXA];
+    int ok;
+} dag_t;
+
+static int dg_node(dag_t *D, char b)
+{
+    int id = D->n_node;
+    if (id >= DG_MAXN) { D->ok = 0; return DG_MAXN - 1; }
+    D->base[id] = b; D->alive[id] = 1; D->out_n[id] = D->in_n[id] = 0; D->n_node++;
+    return id;
+}
+static void dg_edge(dag_t *D, int u, int v, int w, int vis)
+{
+    int e = D->n_edge;
+    if (e >= DG_MAXE || D->out_n[u] >= DG_MAXA || D->in_n[v] >= DG_MAXA) { D->ok = 0; return; }
+    D->e_from[e] = u; D->e_to[e] = v; D->e_w[e] = w; D->e_alive[e] = 1; D->e_vis[e] = (uint8_t)vis; D->n_edge++;
+    D->out_e[u][D->out_n[u]++] = (int16_t)e; D->in_e[v][D->in_n[v]++] = (int16_t)e;
+}
+static int dg_find(const dag_t *D, int u, int v) /* get_bi_Edge: the in-edges of v in order */
+{
+    int i;
+    for (i = 0; i < D->in_n[v]; i++) { int e = D->in_e[v][i]; if (D->e_alive[e] && D->e_from[e] == u) return e; }
+    return -1;
+}
+static int dg_outdeg(const dag_t *D, int u) { int i, c = 0; for (i = 0; i < D->out_n[u]; i++) c += D->e_alive[D->out_e[u][i]]; return c; }
+static int dg_indeg(const dag_t *D, int u) { int i, c = 0; for (i = 0; i < D->in_n[u]; i++) c += D->e_alive[D->in_e[u][i]]; return c; }
+static void dg_delete(dag_t *D, int x)
+{
+    int i;
+    D->alive[x] = 0; D->base[x] = 'D';
+    for (i = 0; i < D->out_n[x]; i++) D->e_alive[D->out_e[x][i]] = 0;
+    for (i = 0; i < D->in_n[x]; i++) D->e_alive[D->in_e[x][i]] = 0;
+    D->out_n[x] = D->in_n[x] = 0;
+}
+static void dg_merge_out(dag_t *D, int cur)
+{
+    static const char B4[4] = {'A', 'C', 'G', 'T'};
+    int bi;
+    if (!D->alive[cur] || dg_outdeg(D, cur) == 0) return;
+    for (bi = 0; bi < 4; bi++) {
+        int flag = 0, weight = 0, cons = -1, i;
+        for (i = 0; i < D->out_n[cur]; i++) {
+            int e = D->out_e[cur][i], g;
+            if (!D->e_alive[e]) continue;
+            g = D->e_to[e];
+            if (D->base[g] != B4[bi] || dg_indeg(D, g) != 1) continue;
+            if (flag == 0) { flag = 1; cons = g; D->e_vis[e] = 1; weight = D->e_w[e]; }
+            else {
+                int j;
+                flag++;
+                weight += D->e_w[e];
+                for (j = 0; j < D->out_n[g]; j++) {
+                    int e2 = D->out_e[g][j], o, e3;
+                    if (!D->e_alive[e2]) continue;
+                    o = D->e_to[e2];
+                    e3 = dg_find(D, cons, o);
+                    if (e3 >= 0) { D->e_vis[e3] = 1; D->e_w[e3] += D->e_w[e2]; }
+                    else dg_edge(D, cons, o, D->e_w[e2], 1);
+                }
+                dg_delete(D, g);
+            }
+        }
+        if (flag > 1) { int e = dg_find(D, cur, cons); if (e >= 0) D->e_w[e] = weight; }
+        if (flag > 0) dg_merge_out(D, cons);
+    }
+}
+static void dg_merge_in(dag_t *D, int cur)
+{
+    static const char B4[4] = {'A', 'C', 'G', 'T'};
+    int bi;
+    if (!D->alive[cur] || dg_indeg(D, cur) == 0) return;
+    for (bi = 0; bi < 4; bi++) {
+        int flag = 0, weight = 0, cons = -1, i;
+        for (i = 0; i < D->in_n[cur]; i++) {
+            int e = D->in_e[cur][i], g;
+            if (!D->e_alive[e]) continue;
+            g = D->e_from[e];
+            if (D->base[g] != B4[bi] || dg_outdeg(D, g) != 1) continue;
+            if (flag == 0) { flag = 1; cons = g; D->e_vis[e] = 1; weight = D->e_w[e]; }
+            else {
+                int j;
+                flag++;
+                weight += D->e_w[e];
+                for (j = 0; j < D->in_n[g]; j++) {
+                    int e2 = D->in_e[g][j], o, e3;
+                    if (!D->e_alive[e2]) continue;
+                    o = D->e_from[e2];
+                    e3 = dg_find(D, o, cons);
+                    if (e3 >= 0) { D->e_vis[e3] = 1; D->e_w[e3] += D->e_w[e2]; }
+                    else dg_edge(D, o, cons, D->e_w[e2], 1);
+                }
+                dg_delete(D, g);
+            }
+        }
+        if (flag > 1) { int e = dg_find(D, cons, cur); if (e >= 0) D->e_w[e] = weight; }
+        if (flag > 0) dg_merge_in(D, cons);
+    }
+}
+static int dg_weight(const dag_t *D, int u, int in) /* sum of the out-edges (E: in-edges) */
+{
+    int i, w = 0;
+    if (in) { for (i = 0; i < D->in_n[u]; i++) if (D->e_alive[D->in_e[u][i]]) w += D->e_w[D->in_e[u][i]]; }
+    else for (i = 0; i < D->out_n[u]; i++) if (D->e_alive[D->out_e[u][i]]) w += D->e_w[D->out_e[u][i]];
+    return w;
+}
+/* keys[i] = len << 24 | 2-bit bases (len <= INS_MAXLEN), one per overlap in overlap order; out: the consensus string as a key */
+static int dagcon_insertion(const uint32_t *keys, int n, uint32_t *out_key)
+{
+    static __thread dag_t D;
+    uint32_t distinct[DG_MAXD]; int cnt[DG_MAXD], nd = 0, i, j, S, E, qh = 0, qt = 0, best_s = -1, best_e = -1, ws = 0, we = 0, cur, L = 0;
+    static __thread int queue[4 * DG_MAXE];
+    char seq[DG_MAXN];
+    *out_key = 0;
+    for (i = 0; i < n; i++) {
+        for (j = 0; j < nd && distinct[j] != keys[i]; j++) {}
+        if (j == nd) { if (nd == DG_MAXD) return -1; distinct[nd] = keys[i]; cnt[nd] = 0; nd++; }
+        cnt[j]++;
+    }
+    D.n_node = D.n_edge = 0; D.ok = 1;
+    S = dg_node(&D, 'S'); E = dg_node(&D, 'E');
+    for (i = 0; i < nd; i++) {
+        int len = (int)(distinct[i] >> 24), last = S;
+        for (j = 0; j < len; j++) { int nn = dg_node(&D, "ACGT"[(distinct[i] >> (2 * j)) & 3]); dg_edge(&D, last, nn, cnt[i], 0); last = nn; }
+        if (last != S) dg_edge(&D, last, E, cnt[i], 0);
+    }
+    queue[qt++] = S;
+    while (qh < qt && D.ok) {
+        cur = queue[qh++];
+        dg_merge_in(&D, cur);
+        dg_merge_out(&D, cur);
+        if (!D.alive[cur]) continue;
+        for (i = 0; i < D.out_n[cur]; i++) if (D.e_alive[D.out_e[cur][i]]) D.e_vis[D.out_e[cur][i]] = 1;
+        for (i = 0; i < D.out_n[cur]; i++) {
+            int e = D.out_e[cur][i], o, all = 1;
+            if (!D.e_alive[e]) continue;
+            o = D.e_to[e];
+            for (j = 0; j < D.in_n[o]; j++) if (D.e_alive[D.in_e[o][j]] && !D.e_vis[D.in_e[o][j]]) { all = 0; break; }
+            if (all) { if (qt < 4 * DG_MAXE) queue[qt++] = o; else D.ok = 0; }
+        }
+    }
+    if (!D.ok) return -1;
+    for (i = 0; i < D.out_n[S]; i++) { int e = D.out_e[S][i]; if (D.e_alive[e]) { int o = D.e_to[e], w = o == E ? dg_weight(&D, E, 1) : dg_weight(&D, o, 0); if (w > ws) { ws = w; best_s = o; } } }
+    for (i = 0; i < D.in_n[E]; i++) { int e = D.in_e[E][i]; if (D.e_alive[e]) { int o = D.e_from[e], w = o == S ? dg_weight(&D, S, 0) : dg_weight(&D, o, 0); if (w > we) { we = w; best_e = o; } } }
+    if (ws >= we) {
+        cur = best_s;
+        while (cur >= 0 && cur != E && L < DG_MAXN) {
+            int mx = 0, nx = -1;
+            seq[L++] = D.base[cur];
+            for (i = 0; i < D.out_n[cur]; i++) { int e = D.out_e[cur][i]; if (D.e_alive[e]) { int o = D.e_to[e], w = o == E ? dg_weight(&D, E, 1) : dg_weight(&D, o, 0); if (w > mx) { mx = w; nx = o; } } }
+            cur = nx;
+        }
+    } else {
+        cur = best_e;
+        while (cur >= 0 && cur != S && L < DG_MAXN) {
+            int mx = 0, nx = -1;
+            seq[L++] = D.base[cur];
+            for (i = 0; i < D.in_n[cur]; i++) { int e = D.in_e[cur][i]; if (D.e_alive[e]) { int o = D.e_from[e], w = o == S ? dg_weight(&D, S, 0) : dg_weight(&D, o, 0); if (w > mx) { mx = w; nx = o; } } }
+            cur = nx;
+        }
+        for (i = 0; i < L / 2; i++) { char t = seq[i]; seq[i] = seq[L - 1 - i]; seq[L - 1 - i] = t; }
+    }
+    if (L > INS_MAXLEN) L = INS_MAXLEN;
+    *out_key = (uint32_t)L << 24;
+    for (i = 0; i < L; i++) *out_key |= (uint32_t)base2(seq[i]) << (2 * i);
+    return ws >= we ? ws : we;
+}
+
 /* One alignment of a partner read against a stretch of a backbone: the votes it casts (addmatchedSeqToGraph, POA.cpp:309). */
 typedef struct { const char *y; int ylen, rev, ry_start, xs, path_len, pend0; const uint8_t *path; uint32_t pend_key; } vote_aln;
 
-typedef struct { int32_t (*cnt)[6]; int32_t *instot; ins_list ins; } vote_ws;
+typedef struct { int32_t (*cnt)[6]; int32_t *instot; ins_list ins; int32_t (*flg)[4]; } vote_ws;
 
 /* Consensus of the backbone xf[gs, gs+glen) given the alignments (get_seq_from_Graph, Correct.cpp:4010-4129, as a per-column
  * vote); homopolymer tests look at xf[0, xf_len).  Writes the consensus to out, and for every backbone column where its own
@@ -488,12 +674,14 @@ static int vote_consensus(const char *xf, int xf_len, int gs, int glen, const vo
     memset(V->cnt, 0, sizeof(int32_t[6]) * (ORC_WINDOW + 1));
     V->ins.n = 0;
     memset(V->instot, 0, sizeof(int32_t) * (ORC_WINDOW + 1));
+    memset(V->flg, 0, sizeof(int32_t[4]) * (ORC_WINDOW + 1));
     for (i = 0; i < nA; i++) {
         const vote_aln *a = &A[i];
-        int xp = a->xs, yp = a->ry_start, p, pend = a->pend0;
+        int xp = a->xs, yp = a->ry_start, p, pend = a->pend0, prev_run = -1, cur_run = -1;
         if (pend && (a->pend_key >> 24)) ins_vote(&V->ins, 0, a->pend_key);
         for (p = 0; p < a->path_len; ) {
             int op = a->path[p];
+            if (op != cur_run) { prev_run = cur_run; cur_run = op; }
             if (op == 2) { /* run of y-only bases in front of column xp */
                 int L = 0;
                 while (p + L < a->path_len && a->path[p + L] == 2) L++;
@@ -511,35 +699,59 @@ static int vote_consensus(const char *xf, int xf_len, int gs, int glen, const vo
             V->cnt[xp][5]++;               /* reads arriving at this column */
             if (pend) { V->instot[xp]++; pend = 0; } /* ... of which after an insertion */
             if (op == 3) V->cnt[xp][4]++;  /* x base without partner: deletion vote */
-            else { V->cnt[xp][base2(ybase(a->y, a->ylen, a->rev, yp))]++; yp++; }
+            else {
+                const int yb = base2(ybase(a->y, a->ylen, a->rev, yp));
+                V->cnt[xp][yb]++; yp++;
+                /* add_mismatchEdge_weight (POA.h:492): last_operation is the previous cigar RUN, so every base of the run that follows an
+                 * insertion counts as "after an insertion" on its edge, not only the first */
+                if (prev_run == 2) V->flg[xp][yb]++;
+            }
             xp++; p++;
         }
     }
-    for (c = 0; c < glen; c++) {
-        int homo = is_homopolymer_site(xf, xf_len, gs + c), b, bestb, bestc, total;
-        /* (1) what sits between column c-1 and c: nothing, or an inserted string */
-        {
-            int none = V->cnt[c][5] - V->instot[c] + 1; /* + the read itself */
-            uint32_t key = 0;
-            int bc = V->instot[c] ? ins_winner(&V->ins, c, &key) : 0;
-            total = V->cnt[c][5] + 1;
-            if (bc > none && wins(bc, total, homo)) {
-                int L = (int)(key >> 24);
-                for (b = 0; b < L; b++) out[outn++] = "ACGT"[(key >> (2 * b)) & 3];
+    {
+        /* get_seq_from_Graph (Correct.cpp:4010-4129) at the node in front of column c, statement by statement */
+        for (c = 0; c < glen; c++) {
+            const int own = base2(xf[gs + c]);
+            const int homo = c > 0 && is_homopolymer_site(xf, xf_len, gs + c - 1);   /* if_is_homopolymer_strict(r_string_site + currentNodeID - 1) */
+            int NI = V->instot[c], visit, b;
+            for (visit = 0; visit < 2; visit++) {
+                int W[4], maxc = -1, type = 0, edge = own, total = 0, order[4], k = 0;
+                uint32_t key = 0;
+                for (b = 0; b < 4; b++) W[b] = V->cnt[c][b] + (b == own);
+                order[k++] = own;
+                for (b = 0; b < 4; b++) if (b != own) order[k++] = b;
+                for (k = 0; k < 4; k++) {
+                    int cw;
+                    b = order[k];
+                    if (W[b] == 0) continue;
+                    cw = NI ? W[b] - V->flg[c][b] : W[b];
+                    total += cw;
+                    if (cw > maxc) { maxc = cw; type = 0; edge = b; }
+                }
+                if (NI) {
+                    uint32_t ks[DG_MAXK + 1]; int nk = 0, z, mi, z2;
+                    total += NI;
+                    for (z = 0; z < V->ins.n && nk <= DG_MAXK; z++) if (V->ins.e[z].col == c) ks[nk++] = V->ins.e[z].key;
+                    /* hifiasm meets the strings in the order of its overlap list; here they are taken in ascending key order (only
+                     * ties between strings of equal weight depend on it), so that the oracle and the HIP path agree */
+                    for (z = 1; z < nk; z++) { const uint32_t kv = ks[z]; for (z2 = z; z2 > 0 && ks[z2 - 1] > kv; z2--) ks[z2] = ks[z2 - 1]; ks[z2] = kv; }
+                    mi = nk == 0 ? 0 : (nk > DG_MAXK ? -1 : dagcon_insertion(ks, nk, &key));
+                    if (mi < 0) mi = ins_winner(&V->ins, c, &key);   /* beyond the DAG's bounds: the most frequent string */
+                    if (mi > maxc) { maxc = mi; type = 1; }
+                }
+                if (V->cnt[c][4]) { total += V->cnt[c][4]; if (V->cnt[c][4] > maxc) { maxc = V->cnt[c][4]; type = 2; } }
+                if (maxc * 5 >= total * 3 || (homo && maxc * 1000 >= total * 515)) {
+                    if (type == 1) { int L = (int)(key >> 24); for (b = 0; b < L; b++) out[outn++] = "ACGT"[(key >> (2 * b)) & 3]; NI = 0; continue; }
+                    if (type == 2) { if (col_idx) col_idx[c] = -1; break; }
+                    if (col_idx) col_idx[c] = outn;
+                    out[outn++] = "ACGT"[edge];
+                    break;
+                }
+                if (col_idx) col_idx[c] = outn;
+                out[outn++] = "ACGT"[own];
+                break;
             }
-        }
-        /* (2) the column itself: A/C/G/T or deleted */
-        {
-            int own = base2(xf[gs + c]);
-            int v[5];
-            for (b = 0; b < 5; b++) v[b] = V->cnt[c][b];
-            v[own]++; /* backbone's own base starts with weight 1 (POA.cpp:269-307) */
-            total = v[0] + v[1] + v[2] + v[3] + v[4];
-            bestb = own; bestc = v[own];
-            for (b = 0; b < 5; b++) if (v[b] > bestc) { bestc = v[b]; bestb = b; }
-            if (bestb != own && !wins(bestc, total, homo)) bestb = own;
-            if (col_idx) col_idx[c] = bestb < 4 ? outn : -1;
-            if (bestb < 4) out[outn++] = "ACGT"[bestb];
         }
     }
     return outn;
@@ -569,6 +781,7 @@ static int correct_read(const readset *R, const orc_asm_params *P, int q, const 
     while (o1 < n_ov && (int)ov[o1].q == q) o1++;
     V.cnt = (int32_t (*)[6])malloc(sizeof(int32_t[6]) * (ORC_WINDOW + 1));
     V.instot = (int32_t *)malloc(sizeof(int32_t) * (ORC_WINDOW + 1));
+    V.flg = (int32_t (*)[4])malloc(sizeof(int32_t[4]) * (ORC_WINDOW + 1));
     V.ins.e = NULL; V.ins.n = V.ins.cap = 0;
     A = (vote_aln *)malloc(sizeof(vote_aln) * (size_t)(o1 - o0 + 1));
 
@@ -685,7 +898,7 @@ static int correct_read(const readset *R, const orc_asm_params *P, int q, const 
         }
         free(rs); free(rstr); free(tw);
     }
-    free(V.cnt); free(V.ins.e); free(V.instot); free(A); free(lb); free(covered);
+    free(V.cnt); free(V.ins.e); free(V.instot); free(V.flg); free(A); free(lb); free(covered);
     return outn;
 }
 
