@@ -311,7 +311,7 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
     if (!p) return;
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
-    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0; p->partition = 1; p->second_round = 1;
+    p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0; p->partition = 1; p->second_round = 1; p->ins_dag = 1;
 }
 
 extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
@@ -325,6 +325,7 @@ extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
     p->w_later = 63;                            // after one round the reads are ~99 % accurate: sparser seeds keep a pair's anchors below 1 024
     p->partition = 0;                           // coincident errors of 10 % reads would pass for alleles and split the set
     p->second_round = 0;                        // the junction vote: what the ONT outcome was validated with (and a third less work)
+    p->ins_dag = 0;                             // at 10 % error nearly every column has inserted strings that disagree: the most frequent one, per lane
     p->min_contig_reads = 2;                    // reads of 10-30 kb tile a 50 kb window with three or four uncontained reads: hifiasm's tip rule (4) would drop them
 }
 
@@ -715,6 +716,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         C.changed = (uint32_t *)W.changed.p;
         C.read_dirty = nullptr;
         C.junction_vote = P.second_round ? 0 : 1;
+        C.ins_dag = P.ins_dag ? 1 : 0;
         C.cov3 = nullptr;
         if (P.second_round && B.n_pairs) { TRY(ensure(ctx, W.cov3, (size_t)std::max(1u, n_gwin))); C.cov3 = (uint8_t *)W.cov3.p; }
         if (B.n_pairs) {

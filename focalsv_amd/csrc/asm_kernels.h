@@ -1355,6 +1355,7 @@ struct ConsArgs {
     const uint32_t *read_dirty;  // per read: some accepted overlap deviates from it somewhere (k_read_dirty); nullptr: not known
     uint8_t *cov3;               // per grid window: at least three overlaps voted (the window went through window_consensus); nullptr: not kept
     int junction_vote;           // 1: bases skipped between two windows of an overlap are voted as an insertion (the stand-in for the second pass)
+    int ins_dag;                 // 1: inserted strings that disagree go through hifiasm's DAG (lane 0); 0: the most frequent string (ONT profile)
 };
 
 __device__ __forceinline__ bool vote_wins(int cnt, int total, bool homo)
@@ -1618,6 +1619,19 @@ __device__ __forceinline__ bool poa_decide(const int W[4], const int Ifl[4], int
     return kept;
 }
 
+// the most frequent inserted string of a column's event list, the smaller key on a tie
+__device__ __forceinline__ void most_frequent_insertion(const uint32_t *s_evkey, const uint16_t *s_evnext, uint32_t head, int &mi, uint32_t &key)
+{
+    int bc = 0; uint32_t bk = 0;
+    for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) {
+        const uint32_t k1 = s_evkey[i];
+        int cn = 0;
+        for (uint32_t j2 = head; j2 != 0xffffu; j2 = s_evnext[j2]) cn += (s_evkey[j2] == k1);
+        if (cn > bc || (cn == bc && k1 < bk)) { bc = cn; bk = k1; }
+    }
+    mi = bc; key = bk;
+}
+
 // the insertion consensus of every column that has insertions, by lane 0 (a handful per window): the column's keyed events are
 // gathered from its list, the DAG (or, beyond its bounds, the most frequent string) answers, and the answer replaces the list's head
 // event (key, count); bit 16 of the head marks the column as answered
@@ -1636,16 +1650,7 @@ __device__ __forceinline__ void answer_insertions(DagLds &D, uint32_t *s_evhead,
         for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) { if (nk < FSV_DG_K) D.keys[nk] = s_evkey[i]; nk++; }
         uint32_t key = 0;
         int mi = dag_insertion(D, nk, key);
-        if (mi < 0) {       // the most frequent string, the smaller key on a tie
-            int bc = 0; uint32_t bk = 0;
-            for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) {
-                const uint32_t k1 = s_evkey[i];
-                int cn = 0;
-                for (uint32_t j2 = head; j2 != 0xffffu; j2 = s_evnext[j2]) cn += (s_evkey[j2] == k1);
-                if (cn > bc || (cn == bc && k1 < bk)) { bc = cn; bk = k1; }
-            }
-            mi = bc; key = bk;
-        }
+        if (mi < 0) most_frequent_insertion(s_evkey, s_evnext, head, mi, key);
         s_evkey[head] = key; s_evnext[head] = (uint16_t)mi;
         s_evhead[c] |= 0x10000u;
     }
@@ -1807,7 +1812,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
             const uint32_t head = s_evhead[c];
             bool same = true;
             if (head != 0xffffu) { const uint32_t k0 = s_evkey[head]; for (uint32_t i = s_evnext[head]; i != 0xffffu; i = s_evnext[i]) if (s_evkey[i] != k0) { same = false; break; } }
-            if (!same) { const uint32_t k = atomicAdd(&s_nins, 1u); if (k < FSV_INSLIST) s_inslist[k] = (uint16_t)c; }
+            if (!same && A.ins_dag) { const uint32_t k = atomicAdd(&s_nins, 1u); if (k < FSV_INSLIST) s_inslist[k] = (uint16_t)c; }
         }
     }
     s_scan[lane] = ((uint32_t)run & 0xffffu) | ((uint32_t)frun << 16);
@@ -1862,7 +1867,8 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
                 if (head != 0xffffu) {
                     ikey = s_evkey[head];
                     if (hv & 0x10000u) mi = (int)s_evnext[head];                                   // the DAG's answer
-                    else for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) mi++;              // one string, mi times
+                    else if (A.ins_dag) { for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) mi++; }   // one string, mi times
+                    else most_frequent_insertion(s_evkey, s_evnext, head, mi, ikey);
                 }
             }
             poa_decide(W, Ifl, dl, ni, mi, ikey, (int)own, homo, &s_out[c][0]);
@@ -2536,7 +2542,7 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
                 const uint32_t head = s_evhead[c];
                 bool same = true;
                 if (head != 0xffffu) { const uint32_t k0 = s_evkey[head]; for (uint32_t i = s_evnext[head]; i != 0xffffu; i = s_evnext[i]) if (s_evkey[i] != k0) { same = false; break; } }
-                if (!same) { const uint32_t k = atomicAdd(&s_nins, 1u); if (k < FSV_INSLIST) s_inslist[k] = (uint16_t)c; }
+                if (!same && A.ins_dag) { const uint32_t k = atomicAdd(&s_nins, 1u); if (k < FSV_INSLIST) s_inslist[k] = (uint16_t)c; }
             }
         }
         s_scan[lane] = ((uint32_t)run & 0xffffu) | ((uint32_t)frun << 16);
@@ -2567,7 +2573,8 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
                 if (head != 0xffffu) {
                     ikey = s_evkey[head];
                     if (hv & 0x10000u) mi = (int)s_evnext[head];
-                    else for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) mi++;
+                    else if (A.ins_dag) { for (uint32_t i = head; i != 0xffffu; i = s_evnext[i]) mi++; }
+                    else most_frequent_insertion(s_evkey, s_evnext, head, mi, ikey);
                 }
             }
             const bool kept = poa_decide(W, Ifl, dl, ni, mi, ikey, (int)own, homo, &s_out[c][0]);

@@ -165,6 +165,8 @@ typedef struct fsv_asm_params {
     int32_t second_round;     /* 1 (default): hifiasm's second consensus pass over the window junctions (process_boundary, Correct.cpp:4453): K5 + K6 +
                                * consensus once more per junction.  0: a vote on the bases both window alignments skip at a junction stands in for
                                * it -- a quarter faster, same reads after three rounds on all but one of 7 800 golden reads (ONT profile: 0) */
+    int32_t ins_dag;          /* 1 (default): inserted strings that disagree go through hifiasm's DAG of inserted strings (build_DAGCon, Correct.cpp:3893);
+                               * 0: the most frequent string is inserted (ONT profile) */
 } fsv_asm_params;
 void fsv_asm_default_params(fsv_asm_params *p);
 /* ONT-profile reads (BASELINE configs[4]: ~10 % error): k = 15, w = 15 without homopolymer compression (a 30 kb read then has ~3 750 minimizers: below the 4 096 a list holds), chain indel budget 0.15 / 0.05,

@@ -668,7 +668,7 @@ typedef struct { int32_t (*cnt)[6]; int32_t *instot; ins_list ins; int32_t (*flg
 /* Consensus of the backbone xf[gs, gs+glen) given the alignments (get_seq_from_Graph, Correct.cpp:4010-4129, as a per-column
  * vote); homopolymer tests look at xf[0, xf_len).  Writes the consensus to out, and for every backbone column where its own
  * output base (kept or replaced) sits in out, or -1 when the column was deleted (col_idx may be NULL).  Returns the length. */
-static int vote_consensus(const char *xf, int xf_len, int gs, int glen, const vote_aln *A, int nA, vote_ws *V, char *out, int *col_idx)
+static int vote_consensus(const char *xf, int xf_len, int gs, int glen, const vote_aln *A, int nA, vote_ws *V, char *out, int *col_idx, int use_dag)
 {
     int i, c, outn = 0;
     memset(V->cnt, 0, sizeof(int32_t[6]) * (ORC_WINDOW + 1));
@@ -736,7 +736,7 @@ static int vote_consensus(const char *xf, int xf_len, int gs, int glen, const vo
                     /* hifiasm meets the strings in the order of its overlap list; here they are taken in ascending key order (only
                      * ties between strings of equal weight depend on it), so that the oracle and the HIP path agree */
                     for (z = 1; z < nk; z++) { const uint32_t kv = ks[z]; for (z2 = z; z2 > 0 && ks[z2 - 1] > kv; z2--) ks[z2] = ks[z2 - 1]; ks[z2] = kv; }
-                    mi = nk == 0 ? 0 : (nk > DG_MAXK ? -1 : dagcon_insertion(ks, nk, &key));
+                    mi = nk == 0 ? 0 : (nk > DG_MAXK || !use_dag ? -1 : dagcon_insertion(ks, nk, &key));
                     if (mi < 0) mi = ins_winner(&V->ins, c, &key);   /* beyond the DAG's bounds: the most frequent string */
                     if (mi > maxc) { maxc = mi; type = 1; }
                 }
@@ -816,7 +816,7 @@ static int correct_read(const readset *R, const orc_asm_params *P, int q, const 
         if (cover < 3) { /* MIN_COVERAGE_THRESHOLD: copy verbatim */
             memcpy(out + outn, x + gs, (size_t)glen); outn += glen;
         } else {
-            outn += vote_consensus(x, xlen, gs, glen, A, nA, &V, out + outn, NULL);
+            outn += vote_consensus(x, xlen, gs, glen, A, nA, &V, out + outn, NULL, P->ins_dag);
             covered[g] = 1;
         }
         lb[g] = outn;
@@ -872,7 +872,7 @@ static int correct_read(const readset *R, const orc_asm_params *P, int q, const 
             if (nA < 3 || terr == 0) continue;
             sb = ORC_BOUNDARY_SIDE; eb = blen - 1 - ORC_BOUNDARY_SIDE;
             if (eb <= sb) continue;
-            cn = vote_consensus(out, len_now, cws, blen, A, nA, &V, cons, col_idx);
+            cn = vote_consensus(out, len_now, cws, blen, A, nA, &V, cons, col_idx, P->ins_dag);
             if (cn == blen && !memcmp(cons, out + cws, (size_t)blen)) continue;   /* the new cigar is one run of matches */
             for (c = sb; c < blen && xs_ < 0; c++) if (col_idx[c] >= 0) xs_ = c;
             for (c = eb; c < blen && xe_ < 0; c++) if (col_idx[c] >= 0) xe_ = c;
@@ -1143,7 +1143,7 @@ void orc_asm_default_params(orc_asm_params *P)
 {
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->partition = 1;
-    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1;
+    P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1; P->ins_dag = 1;
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),

@@ -37,6 +37,7 @@ typedef struct {
     int32_t bw_rechain;       /* indel budget per mille when the final pass re-chains a pair without an exact overlap: 1 (max_ov_diff_final 0.001) */
     int32_t w_later;          /* minimizer window from the second correction round on (0 = w throughout, as hifiasm) */
     int32_t second_round;     /* 1: the junctions between grid windows get a second consensus (process_boundary, Correct.cpp:4453) */
+    int32_t ins_dag;          /* 1: inserted strings that disagree go through hifiasm's DAG (build_DAGCon); 0: the most frequent string (ONT profile) */
 } orc_asm_params;
 
 typedef struct {

@@ -89,7 +89,7 @@ def sketch(seq: str, w=51, k=51, hpc=1):
 
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "partition",
-                                         "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "second_round")]
+                                         "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "second_round", "ins_dag")]
 
 
 def default_params():
@@ -105,6 +105,7 @@ def ont_params():
     p.win_rate_pm, p.k_cap, p.accept_err_pm, p.bw_rechain, p.min_contig_reads, p.w_later = 250, 95, 300, 50, 2, 63
     p.partition = 0
     p.second_round = 0
+    p.ins_dag = 0
     return p
 
 

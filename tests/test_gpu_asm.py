@@ -168,8 +168,7 @@ def test_partition_on_mixed_sets_of_many_shapes_matches_oracle(ctx):
 @pytest.mark.parametrize("rounds", [1, 2])
 def test_every_round_equals_hifiasm(ctx, golden_dir, rounds):
     """all 88 read sets of tests/golden/hifiasm_rounds.json in one call with n_rounds = 1 and 2: the corrected reads the GPU path
-    returns equal `hifiasm -r 1` / `-r 2` md5 for md5 (after one round on 73 sets: KNOWN_ROUND1_DEVIATIONS, hifiasm's insertion
-    consensus), i.e. the HIP path is pinned to the reference round by round, not only through the oracle"""
+    returns equal `hifiasm -r 1` / `-r 2` md5 for md5 (after one round on 86 sets: KNOWN_ROUND1_DEVIATIONS), i.e. the HIP path is pinned to the reference round by round, not only through the oracle"""
     from tests.test_oracle_asm import KNOWN_ROUND1_DEVIATIONS
     gold = json.load(open(os.path.join(golden_dir, "hifiasm_rounds.json")))["sets"]
     sets = []
