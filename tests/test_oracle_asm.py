@@ -151,7 +151,9 @@ def _round_sets(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
 
 
 # After the FIRST round one read of each of these two sets still differs from hifiasm's (after the second round all 88 sets are
-# identical): a read's last base (74), a base in the middle of a window (77).  Listed so that a fix shows.
+# identical): a read's last base (74); a window hifiasm corrects with a third alignment that its left-extension rescue pass
+# (recalcate_window_advance, Correct.cpp:2745-2905: not restated, it needs the path of the window to its right) supplies (77).
+# Listed so that a fix shows.
 KNOWN_ROUND1_DEVIATIONS = {74, 77}
 
 
