@@ -1719,6 +1719,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
         const uint32_t ti = oc.y + (uint32_t)j;
         const fsv_wpath *P = A.paths + ti;
         const uint4 h0 = *reinterpret_cast<const uint4 *>(P);                      // ry_start, ry_end, path_len|err, state|rev|pad
+        atomicAdd(&s_cover, 1u);       // get_available_interval (Correct.cpp:113): every accepted overlap that overlaps the window counts, matched there or not
         if ((h0.w & 0xffu) != 1u) continue;
         const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16); // y_word, y_len
         // a path at distance 0 is all matches (every window from the second round on, a fifth of them in the first): its 104 op
@@ -1730,7 +1731,6 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
             for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
         }
         bool dev_here = false;
-        atomicAdd(&s_cover, 1u);
         const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
         const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
 #define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))

@@ -794,8 +794,8 @@ static int correct_read(const readset *R, const orc_asm_params *P, int q, const 
             vote_aln *a;
             if (o->is_match != 1 || j < 0 || j >= o->n_win) continue;
             w = &W[o->first_win + j];
+            cover++;                      /* get_available_interval (Correct.cpp:113): every accepted overlap that overlaps the window counts, matched there or not */
             if (w->err < 0) continue;
-            cover++;
             a = &A[nA++];
             a->y = R->seq[o->t]; a->ylen = R->len[o->t]; a->rev = o->rev; a->ry_start = w->ry_start; a->xs = w->x_start - gs;
             a->path = w->path; a->path_len = w->path_len; a->pend0 = 0; a->pend_key = 0;

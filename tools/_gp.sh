@@ -1,2 +1,2 @@
 set -o pipefail
-bash tools/profile_round.sh r02_f && python bench.py --profile ont --lanes 1 --cpu-sample 0 --holdout 0 > gpurun_out/prof_r02_f/bench_ont_1lane.json && python bench.py --workload bed --bed chr21 > gpurun_out/prof_r02_f/bed_chr21_n1.json && python bench.py --second-round 0 --cpu-sample 0 --holdout 0 > gpurun_out/prof_r02_f/bench_junction_vote.json && python bench.py --second-round 0 --lanes 1 --cpu-sample 0 --holdout 0 > gpurun_out/prof_r02_f/bench_junction_vote_1lane.json && timeout 600 python -m pytest tests/test_gpu_bed.py -m gpu -q 2>&1 | tail -2
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 && python bench.py --lanes 1 --cpu-sample 0 --holdout 0 > gpurun_out/b1.json
