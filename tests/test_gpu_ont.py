@@ -76,3 +76,29 @@ def test_second_consensus_pass_with_wide_bands_equals_the_oracle():
             assert [c for c, cs in zip(contigs, cset) if cs == si] == oc, si
     finally:
         ctx.close()
+
+
+def test_insertion_dag_under_stress_equals_the_oracle():
+    """ins_dag = 1 on ONT-profile reads (off in fsv_asm_ont_params): at 10 % error nearly every column has inserted strings that
+    disagree, many beyond the DAG's bounds (8 distinct strings, 64 nodes, 64 strings per column -> the most frequent string) -- the
+    lane-0 DAG of the HIP path and oracle/asm.c:dagcon_insertion must agree on all of them: corrected reads bit for bit after one
+    round and after three"""
+    from focalsv_amd import _lib
+    from tests.test_gpu_asm import gpu_assemble
+    ctx = _lib.Context(0)
+    try:
+        r = synth.make_region(9, width=20000, profile="ont")
+        sets = [r.reads[0], r.reads[1]]
+        for rounds in (1, 3):
+            p = ctx.ont_asm_params()
+            p.ins_dag, p.n_rounds = 1, rounds
+            contigs, cset, status, reads, b = gpu_assemble(ctx, sets, p)
+            po = O.ont_params()
+            po.ins_dag, po.n_rounds = 1, rounds
+            k = 0
+            for si, s in enumerate(sets):
+                oc, ocorr = O.assemble(s, po)
+                assert [reads[k + j] for j in range(len(s))] == ocorr, (rounds, si)
+                k += len(s)
+    finally:
+        ctx.close()
