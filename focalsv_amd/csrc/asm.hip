@@ -53,7 +53,7 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
        CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -68,7 +68,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -732,7 +732,9 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         if (partition) {
             const size_t vec_cap = (size_t)B.n_pairs * 64 + (1u << 20);
             TRY(ensure(ctx, W.site_cnt, (size_t)std::max(1u, n_gwin) * 4));
-            TRY(ensure(ctx, W.site_rec, (size_t)std::max(1u, n_gwin) * FSV_SITE_WIN_CAP * sizeof(uint2)));
+            const size_t rec_cap = (size_t)n_gwin * 4 + 65536;
+            TRY(ensure(ctx, W.site_rec, rec_cap * sizeof(uint2)));
+            TRY(ensure(ctx, W.site_off, (size_t)std::max(1u, n_gwin) * 4));
             TRY(ensure(ctx, W.site_vec, vec_cap));
             TRY(ensure(ctx, W.site_cursor, 16));
             TRY(ensure(ctx, W.redo, (size_t)B.n_reads * 4));
@@ -740,6 +742,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             FSV_HIP(ctx, hipMemsetAsync(W.site_cursor.p, 0, 16, ctx->stream));
             FSV_HIP(ctx, hipMemsetAsync(W.redo.p, 0, (size_t)B.n_reads * 4, ctx->stream));
             SA.site_cnt = (uint32_t *)W.site_cnt.p; SA.site_rec = (uint2 *)W.site_rec.p; SA.vec = (int8_t *)W.site_vec.p;
+            SA.site_off = (uint32_t *)W.site_off.p; SA.rec_cursor = (uint32_t *)W.site_cursor.p + 3; SA.rec_cap = (uint32_t)std::min<size_t>(rec_cap, 0xfffffff0u);
             SA.vec_cursor = (uint32_t *)W.site_cursor.p; SA.vec_cap = (uint32_t)std::min<size_t>(vec_cap, 0xfffffff0u);
             SA.read_sites = (uint32_t *)W.redo.p;
             SL.site_cnt = SA.site_cnt; SL.win_list = (uint32_t *)W.site_lists.p; SL.redo_list = SL.win_list + std::max(1u, n_gwin);

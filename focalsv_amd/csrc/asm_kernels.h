@@ -1935,12 +1935,15 @@ __global__ __launch_bounds__(64) void k_consensus_redo(ConsArgs A, SiteLists L)
 //                   enumerated (Preorder_Merge_Advance_Repeat :6233), a chain with support for both alleles
 //                   (if_snp_vector_useful :6356) makes the overlaps with the other allele trans (is_match 2).
 // oracle/asm.c:partition_read is the same algorithm, statement by statement.
-#define FSV_SITE_WIN_CAP 16        // kept sites per grid window
-#define FSV_SITE_READ_CAP 256      // kept sites per read
+#define FSV_SITE_WIN_CAP 255       // kept sites per grid window (their index in the window is a byte)
+#define FSV_SITE_RAW_CAP 1024      // kept sites per read before the sites beside another site are dropped
+#define FSV_SITE_READ_CAP 512      // ... and after (the chain DP's predecessor sets are 512-bit)
 #define FSV_K7_GROUP_CAP 10000     // chains enumerated per read (the enumeration is exponential in ties; hifiasm has no bound)
 struct SiteArgs {
     uint32_t *site_cnt;            // per grid window
-    uint2 *site_rec;               // per grid window x FSV_SITE_WIN_CAP: {position in the read | homopolymer << 31, byte offset of the vector}
+    uint2 *site_rec;               // site records, handed out from a pool: {position in the read | homopolymer << 31, byte offset of the vector}
+    uint32_t *site_off;            // per grid window: its first record
+    uint32_t *rec_cursor; uint32_t rec_cap;
     int8_t *vec;                   // vector pool: one byte per overlap of the read, -1 = does not cover the site
     uint32_t *vec_cursor;          // bytes handed out
     uint32_t vec_cap;
@@ -1954,7 +1957,7 @@ __device__ __forceinline__ void snp_sites_window(const ConsArgs &A, const uint32
     __shared__ uint32_t s_path[64][27];
     __shared__ uint8_t s_alt[FSV_WINDOW + 1];      // 0, or 1 + the dominating other base of a kept site
     __shared__ uint8_t s_sidx[FSV_WINDOW + 1];     // kept site -> its index in the window
-    __shared__ uint32_t s_cover, s_nsite, s_vbase;
+    __shared__ uint32_t s_cover, s_nsite, s_vbase, s_rbase;
     __shared__ uint32_t s_xraw[28];
     __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
@@ -2071,9 +2074,9 @@ __device__ __forceinline__ void snp_sites_window(const ConsArgs &A, const uint32
         if (all == 0) break;
         if (all > FSV_SITE_WIN_CAP) { if (lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_SITES); break; }
         if (lane == 0) {
-            const uint32_t off = atomicAdd(S.vec_cursor, (uint32_t)all * vstride);
-            s_vbase = off;
-            s_nsite = off + (uint32_t)all * vstride <= S.vec_cap ? (uint32_t)all : 0u;
+            const uint32_t off = atomicAdd(S.vec_cursor, (uint32_t)all * vstride), roff = atomicAdd(S.rec_cursor, (uint32_t)all);
+            s_vbase = off; s_rbase = roff;
+            s_nsite = (off + (uint32_t)all * vstride <= S.vec_cap && roff + (uint32_t)all <= S.rec_cap) ? (uint32_t)all : 0u;
             if (!s_nsite) atomicOr(&A.warn[r], (uint32_t)FSV_W_SITES);
         }
         __syncthreads();
@@ -2085,10 +2088,10 @@ __device__ __forceinline__ void snp_sites_window(const ConsArgs &A, const uint32
             const int p = gs + c;
             const uint32_t own = XB(p);
             const bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < xlen && XB(p + 1) == own);
-            S.site_rec[(size_t)gw * FSV_SITE_WIN_CAP + k] = make_uint2((uint32_t)p | (homo ? 0x80000000u : 0u), s_vbase + (uint32_t)k * vstride);
+            S.site_rec[(size_t)s_rbase + k] = make_uint2((uint32_t)p | (homo ? 0x80000000u : 0u), s_vbase + (uint32_t)k * vstride);
             k++;
         }
-        if (lane == 0) { S.site_cnt[gw] = (uint32_t)all; S.read_sites[r] = 1u; }
+        if (lane == 0) { S.site_cnt[gw] = (uint32_t)all; S.site_off[gw] = s_rbase; S.read_sites[r] = 1u; }
         __threadfence_block();
         __syncthreads();
     }
@@ -2109,12 +2112,12 @@ __global__ __launch_bounds__(64) void k_snp_sites(ConsArgs A, SiteArgs S, SiteLi
 
 __global__ __launch_bounds__(64) void k_hap_partition(ConsArgs A, SiteArgs S, fsv_ovl *__restrict__ ovl, uint4 *__restrict__ ovl_c, SiteLists L)
 {
-    __shared__ int32_t s_pos[FSV_SITE_READ_CAP];
-    __shared__ uint32_t s_voff[FSV_SITE_READ_CAP];
+    __shared__ int32_t s_pos[FSV_SITE_RAW_CAP];
+    __shared__ uint32_t s_voff[FSV_SITE_RAW_CAP];
     __shared__ uint16_t s_max[FSV_SITE_READ_CAP], s_order[FSV_SITE_READ_CAP];
     __shared__ uint32_t s_bt[FSV_SITE_READ_CAP][FSV_SITE_READ_CAP / 32];   // predecessors on a longest chain, as a bit set
     __shared__ uint16_t s_buf[FSV_SITE_READ_CAP], s_cur[FSV_SITE_READ_CAP]; // the chain being walked; per depth, the next predecessor to try
-    __shared__ uint8_t s_visit[FSV_SITE_READ_CAP], s_keep[FSV_SITE_READ_CAP];
+    __shared__ uint8_t s_visit[FSV_SITE_READ_CAP], s_keep[FSV_SITE_RAW_CAP];
     __shared__ uint32_t s_n;
     const int lane = threadIdx.x;
     __shared__ uint32_t s_redo;
@@ -2135,14 +2138,14 @@ __global__ __launch_bounds__(64) void k_hap_partition(ConsArgs A, SiteArgs S, fs
         for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
         const uint32_t base = s_n + incl - c;
         for (uint32_t k = 0; k < c; k++)
-            if (base + k < FSV_SITE_READ_CAP) { const uint2 rec = S.site_rec[(size_t)gw * FSV_SITE_WIN_CAP + k]; s_pos[base + k] = (int32_t)rec.x; s_voff[base + k] = rec.y; }
+            if (base + k < FSV_SITE_RAW_CAP) { const uint2 rec = S.site_rec[(size_t)S.site_off[gw] + k]; s_pos[base + k] = (int32_t)rec.x; s_voff[base + k] = rec.y; }
         __syncthreads();
         if (lane == 63) s_n = base + c;
         __syncthreads();
     }
     int nS = (int)s_n;
     if (nS == 0) return;
-    if (nS > FSV_SITE_READ_CAP) { if (lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_SITES); return; }
+    if (nS > FSV_SITE_RAW_CAP) { if (lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_SITES); return; }
     // a site directly beside another one is dropped
     if (nS > 1) {
         for (int j = lane; j < nS; j += 64) {
@@ -2160,6 +2163,7 @@ __global__ __launch_bounds__(64) void k_hap_partition(ConsArgs A, SiteArgs S, fs
         nS = (int)s_n;
         if (nS == 0) return;
     }
+    if (nS > FSV_SITE_READ_CAP) { if (lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_SITES); return; }
     // informative, not informative, informative again: the overlap is set aside
     for (uint32_t i = lane; i < n_ovl; i += 64) {
         if (!(ovl_c[pbase + i].z >> 31)) continue;

@@ -220,7 +220,8 @@ typedef struct fsv_contigs {
 #define FSV_W_INS_EVENTS   8  /* a consensus window saw more inserted-base events than its buffer holds; the extra votes were dropped */
 #define FSV_W_WINDOW_KEPT 16  /* a corrected window would have outgrown its slot; the read keeps that window uncorrected */
 #define FSV_W_INTERNAL    32  /* a minimizer slot overflowed (cannot happen: one minimizer per base at most) */
-#define FSV_W_SITES       64  /* haplotype partition: more than 16 candidate sites in a window or 256 in a read (or the site pool ran out);
+#define FSV_W_SITES       64  /* haplotype partition: more than 255 candidate sites in a window, 1 024 in a read (512 once sites beside another site are
+                                 * dropped), or the site pool ran out;
                                  * that window's sites / that read's partition were skipped */
 
 /* capacity needed for fsv_contigs.seq / contig count for these read sets */

@@ -912,8 +912,9 @@ static int correct_read(const readset *R, const orc_asm_params *P, int q, const 
  * site vectors are enumerated (Preorder_Merge_Advance_Repeat :6233) and a chain whose two alleles both have support
  * (if_snp_vector_useful :6356) turns the overlaps carrying the other allele into trans overlaps (is_match 2,
  * try_to_remove_reads :6467).  Runs for every read of every set, as hifiasm does -- it has no notion of a phased input. */
-#define ORC_SITE_WIN_CAP 16
-#define ORC_SITE_READ_CAP 256
+#define ORC_SITE_WIN_CAP 255
+#define ORC_SITE_RAW_CAP 1024
+#define ORC_SITE_READ_CAP 512
 typedef struct { int site, occ0, occ1, occ2, homo; int8_t *vec; } snp_site;
 
 static int vec_conflict(const int8_t *a, const int8_t *b, int n)
@@ -1045,11 +1046,11 @@ static void partition_read(const readset *R, int q, orc_ovl *ov, int n_ov, const
             S[nS].vec = ev;
             nS++;
         }
-        /* bounds of the HIP path (FSV_SITE_WIN_CAP, FSV_SITE_READ_CAP; hifiasm has none): a window with more than 16 kept sites
-         * contributes none, a read with more than 256 is not partitioned */
+        /* bounds of the HIP path (FSV_SITE_WIN_CAP, FSV_SITE_RAW_CAP, FSV_SITE_READ_CAP; hifiasm has none): a window with more than 255 kept sites
+         * contributes none, a read with more than 1 024 (512 once the sites beside another site are gone) is not partitioned */
         if (nS - nS_win > ORC_SITE_WIN_CAP) { while (nS > nS_win) free(S[--nS].vec); }
     }
-    if (nS > ORC_SITE_READ_CAP) { for (j = 0; j < nS; j++) free(S[j].vec); free(S); return; }
+    if (nS > ORC_SITE_RAW_CAP) { for (j = 0; j < nS; j++) free(S[j].vec); free(S); return; }
     if (nS == 0) { free(S); return; }
     /* generate_haplotypes_DP: a site directly beside another one is dropped */
     if (nS > 1) {
@@ -1063,6 +1064,7 @@ static void partition_read(const readset *R, int q, orc_ovl *ov, int n_ov, const
         free(keep);
         nS = m;
     }
+    if (nS > ORC_SITE_READ_CAP) { for (j = 0; j < nS; j++) free(S[j].vec); free(S); return; }
     for (i = 0; i < n; i++) { /* informative, not informative, informative again: set aside */
         int st = -1;
         if (ov[o0 + i].is_match != 1) continue;
