@@ -50,10 +50,10 @@ struct Span {
 // per-round block of device counters (one 64-byte slot per correction round + one for the final pass, zeroed once per batch and
 // read back with the round's one synchronisation or at the end): u32 indices
 enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4, CT_COLS_HI = 5, CT_DP_WIDE = 6, CT_DP_SB = 7, CT_DP_GEN = 8, CT_DP_XW = 9,
-       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_SLOT = 16 };
+       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_DP_SB16 = 14, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -68,7 +68,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -354,8 +354,8 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
     }
     const int k_cap = kmax > FSV_K_MAX ? kmax : FSV_K_MAX;     // a threshold above 31 anywhere: K5 of the whole list through the wide kernel
     FSV_HIP(ctx, hipSetDevice(ctx->device));
-    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_list2, d_list3, d_wide, d_xwide, d_cnt, d_cols, d_cols_sb, d_cols_wide;
-    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_list2, &d_list3, &d_wide, &d_xwide, &d_cnt, &d_cols, &d_cols_sb, &d_cols_wide}) if (b->p) (void)hipFree(b->p); };
+    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_list2, d_list3, d_list16, d_wide, d_xwide, d_cnt, d_cols, d_cols_sb, d_cols_wide;
+    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_list2, &d_list3, &d_list16, &d_wide, &d_xwide, &d_cnt, &d_cols, &d_cols_sb, &d_cols_wide}) if (b->p) (void)hipFree(b->p); };
     int rc = FSV_OK;
     auto run = [&]() -> int {
         std::vector<fsv_wtask> t(tasks, tasks + n_tasks);
@@ -368,7 +368,7 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         TRY(upload(ctx, d_ovl, std::vector<fsv_ovl>{o}));
         TRY(ensure(ctx, d_res, (size_t)n_tasks * sizeof(fsv_wres)));
         TRY(ensure(ctx, d_paths, (size_t)n_tasks * sizeof(fsv_wpath)));
-        for (DevBuf *b : {&d_list, &d_list2, &d_list3, &d_wide, &d_xwide}) TRY(ensure(ctx, *b, (size_t)n_tasks * 4));
+        for (DevBuf *b : {&d_list, &d_list2, &d_list3, &d_list16, &d_wide, &d_xwide}) TRY(ensure(ctx, *b, (size_t)n_tasks * 4));
         TRY(ensure(ctx, d_cnt, CT_SLOT * 4));
         uint32_t *ct = (uint32_t *)d_cnt.p;
         FSV_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, CT_SLOT * 4, ctx->stream));
@@ -381,12 +381,15 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         FSV_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
                            (const fsv_wres *)d_res.p, (const uint32_t *)d_list.p, 0u, (fsv_wpath *)d_paths.p, (uint32_t *)d_list2.p, ct + CT_DP_SB,
-                           (const uint32_t *)(ct + CT_DP), (uint32_t *)d_list3.p, ct + CT_DP_GEN);
+                           (const uint32_t *)(ct + CT_DP), (uint32_t *)d_list3.p, ct + CT_DP_GEN, (uint32_t *)d_list16.p, ct + CT_DP_SB16);
         FSV_HIP(ctx, hipGetLastError());
         const uint32_t grid = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 8u * (uint32_t)ctx->n_cu);
         TRY(ensure(ctx, d_cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
-        hipLaunchKernelGGL(k_path_sb<false>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+        hipLaunchKernelGGL((k_path_sb<false, false>), dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
                            (const uint32_t *)d_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)d_paths.p, (uint4 *)d_cols_sb.p, (unsigned long long *)nullptr);
+        FSV_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL((k_path_sb<false, true>), dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+                           (const uint32_t *)d_list16.p, (const uint32_t *)(ct + CT_DP_SB16), (fsv_wpath *)d_paths.p, (uint4 *)d_cols_sb.p, (unsigned long long *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
         const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 2u * (uint32_t)ctx->n_cu);
         TRY(ensure(ctx, d_cols, (size_t)gridg * 64 * (FSV_WINDOW + 2) * 3 * 8));
@@ -437,7 +440,7 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
     // (distance <= FSV_SB_MAXERR) or to the general one
     hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, tasks,
                        res, (const uint32_t *)W.dp_list.p, 0u, paths, (uint32_t *)W.dp_list2.p, ct + CT_DP_SB,
-                       (const uint32_t *)(ct + CT_DP), (uint32_t *)W.dp_list3.p, ct + CT_DP_GEN);
+                       (const uint32_t *)(ct + CT_DP), (uint32_t *)W.dp_list3.p, ct + CT_DP_GEN, (uint32_t *)W.dp_list16.p, ct + CT_DP_SB16);
     FSV_HIP(ctx, hipGetLastError());
     // persistent grids: as many blocks as the device holds at once, each striding through its list, so the column scratch
     // is a fixed few hundred MB whatever the number of windows
@@ -459,8 +462,12 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
             fprintf(stderr, "[fsv] k_path_sb round %d: %llu waves, cycles per wave: forward %.0f, walk %.0f, finish %.0f (grid %u)\n", round, h[3],
                     h[3] ? (double)h[0] / h[3] : 0.0, h[3] ? (double)h[1] / h[3] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0, grid);
         } else
-        hipLaunchKernelGGL(k_path_sb<false>, dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
+        hipLaunchKernelGGL((k_path_sb<false, false>), dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
                            (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
+        FSV_HIP(ctx, hipGetLastError());
+        // distance <= 3 (nine in ten): the 16-bit sub-band, half the scratch; the same slices, after the launch above on this stream
+        hipLaunchKernelGGL((k_path_sb<false, true>), dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
+                           (const uint32_t *)W.dp_list16.p, (const uint32_t *)(ct + CT_DP_SB16), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
         // the general kernel's lists are short (rescue windows, distances above 7): two blocks per CU are plenty
         const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 2u * (uint32_t)ctx->n_cu), stride = gridg * 64;
@@ -665,6 +672,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         TRY(ensure(ctx, W.dp_list, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_list2, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_list3, (size_t)task_cap * 4));
+        TRY(ensure(ctx, W.dp_list16, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_wide, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_xwide, wide_bands ? (size_t)task_cap * 4 : 64));
         // ONT-profile batches: dense seeds and 4 096-anchor tiles for the first round only (noisy reads share few minimizers, but nothing bounds
@@ -964,8 +972,8 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         if (sl == P.n_rounds) { W.stats.n_inexact_candidates = c[CT_INEXACT]; break; }
         W.stats.n_windows += c[CT_TASKS];
         W.stats.dp_columns += (uint64_t)c[CT_COLS_LO] | (uint64_t)c[CT_COLS_HI] << 32;      // rescue re-runs (k_rescue_accept)
-        W.stats.n_path_dp += (uint64_t)c[CT_DP_SB] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW];
-        W.stats.n_path_indel1 += (uint64_t)c[CT_DP] - c[CT_DP_SB] - c[CT_DP_GEN];
+        W.stats.n_path_dp += (uint64_t)c[CT_DP_SB] + c[CT_DP_SB16] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW];
+        W.stats.n_path_indel1 += (uint64_t)c[CT_DP] - c[CT_DP_SB] - c[CT_DP_SB16] - c[CT_DP_GEN];
         // algorithmic bytes of the round's launches, now that the counts are known: a window task is
         // 94 + 102 B of 2-bit operands + 16 B of result; a K6 window leaves a 128 B path record instead;
         // k_chain reads every unique-minimizer list once (two sorted copies, 16 B entries) and writes the overlap slots and
@@ -974,7 +982,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         if ((size_t)sl < W.bpm_rec.size()) W.kt.recs[W.bpm_rec[sl]].bytes = nt * 212ull;
         if ((size_t)sl < W.rescue_rec.size()) W.kt.recs[W.rescue_rec[sl]].bytes += nt * 16ull;
         if ((size_t)sl < W.fast_rec.size()) W.kt.recs[W.fast_rec[sl]].bytes = nt * (16ull + 196ull) + (nt - c[CT_DP] - c[CT_DP_WIDE] - c[CT_DP_XW]) * 128ull;
-        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = ((uint64_t)c[CT_DP_SB] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW]) * (196ull + 128ull);
+        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = ((uint64_t)c[CT_DP_SB] + c[CT_DP_SB16] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW]) * (196ull + 128ull);
         if ((size_t)sl < W.cons_rec.size()) W.kt.recs[W.cons_rec[sl]].bytes += nt * 128ull;
     }
     for (size_t i = 0; i < W.chain_rec.size(); i++) {

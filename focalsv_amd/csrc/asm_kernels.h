@@ -24,6 +24,7 @@
 #define FSV_INS_MAXLEN   12
 #define FSV_SB_MAXERR    7   // k_path_sb: distances it holds in one word per column (2 x 7 + 1 rows x 2 bits)
 #define FSV_SB_QUADS ((FSV_WINDOW + 3) / 4)
+#define FSV_SB16_MAXERR  3   // k_path_sb<., true>: distances whose sub-band (2 x 3 + 1 rows x 2 bits) fits 16 bits a column
 #define FSV_EV_CAP_WIDE 2048 // ... for ONT-profile batches (wide bands): ~25 inserted-base events per overlap and window
 #define FSV_EV_CAP     256   // insertion events per grid window (HiFi at 30x: ~8; more sets the read's warning bit 8 and drops the excess)
 
@@ -937,7 +938,8 @@ __device__ __forceinline__ int path_prefix_match(const uint32_t *__restrict__ st
 __global__ __launch_bounds__(256) void k_path_indel1(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
                                                      const fsv_wres *__restrict__ res, const uint32_t *__restrict__ dp_list, uint32_t n_list,
                                                      fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list2, uint32_t *__restrict__ n_list2,
-                                                     const uint32_t *__restrict__ n_list_dev, uint32_t *__restrict__ dp_list3, uint32_t *__restrict__ n_list3)
+                                                     const uint32_t *__restrict__ n_list_dev, uint32_t *__restrict__ dp_list3, uint32_t *__restrict__ n_list3,
+                                                     uint32_t *__restrict__ dp_list16 = nullptr, uint32_t *__restrict__ n_list16 = nullptr)
 {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_list_dev) n_list = *n_list_dev;    // the grid covers the largest the list can be; its length stays on the device
@@ -1002,7 +1004,12 @@ __global__ __launch_bounds__(256) void k_path_indel1(const uint32_t *__restrict_
         }
     }
     // what is left: distance <= FSV_SB_MAXERR goes to the sub-band kernel, the few beyond it to the general one
-    if (!done) { if (r.err <= FSV_SB_MAXERR) dp_list2[atomicAdd(n_list2, 1u)] = tid; else dp_list3[atomicAdd(n_list3, 1u)] = tid; }
+    // (distance <= FSV_SB16_MAXERR: the sub-band of 7 rows fits 16 bits a column: k_path_sb<., true>, half the scratch)
+    if (!done) {
+        if (dp_list16 && r.err <= FSV_SB16_MAXERR) dp_list16[atomicAdd(n_list16, 1u)] = tid;
+        else if (r.err <= FSV_SB_MAXERR) dp_list2[atomicAdd(n_list2, 1u)] = tid;
+        else dp_list3[atomicAdd(n_list3, 1u)] = tid;
+    }
 }
 
 // base access through one cached 16-base word (forward position >> 4 is the key)
@@ -1181,6 +1188,8 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
 // four at a time ([block][column quad][lane] as uint4: 1 KB per wave store); the walk reads them back a quad ahead of where it
 // stands, so no step waits on memory -- round 1's walk was a chain of ~375 dependent loads per window (62 % of its wave cycles
 // parked in s_waitcnt, profiles/r01_i_pmc_sq_summary.txt).  Scratch traffic: 1.5 KB per window, written once, read once.
+// HALF: distance <= 3 -- seven rows, 7 + 7 code bits in a 16-bit word, eight columns to a uint4 (half the scratch bytes)
+template <bool HALF>
 struct SubbandSink {
     uint4 *slot;             // this lane's uint4 of quad 0; quad q sits 64 x q further
     uint32_t sr, sl, lmask;  // band word -> sub-band: (w >> sr) << sl; rows that may step left
@@ -1189,17 +1198,30 @@ struct SubbandSink {
     {
         const uint32_t u = vp << 1, l = hp & lmask;
         const uint32_t w1 = d0 & (u | l), w0 = ~d0 | (l & ~u);
-        const uint32_t word = (((w0 >> sr) << sl) & 0xffffu) | (((w1 >> sr) << sl) << 16);
-        if ((j & 3) == 0) a0 = word; else if ((j & 3) == 1) a1 = word; else if ((j & 3) == 2) a2 = word; else a3 = word;
-        if ((j & 3) == 3) slot[(size_t)((blk + j) >> 2) * 64] = make_uint4(a0, a1, a2, a3);
+        if (HALF) {
+            const uint32_t h = (((w0 >> sr) << sl) & 0x7fu) | ((((w1 >> sr) << sl) & 0x7fu) << 8);
+            const int e = j & 7;     // blk is a multiple of 16
+            const uint32_t v = (e & 1) ? h << 16 : h;
+            if ((e >> 1) == 0) a0 = (e & 1) ? (a0 | v) : v; else if ((e >> 1) == 1) a1 = (e & 1) ? (a1 | v) : v;
+            else if ((e >> 1) == 2) a2 = (e & 1) ? (a2 | v) : v; else a3 = (e & 1) ? (a3 | v) : v;
+            if (e == 7) slot[(size_t)((blk + j) >> 3) * 64] = make_uint4(a0, a1, a2, a3);
+        } else {
+            const uint32_t word = (((w0 >> sr) << sl) & 0xffffu) | (((w1 >> sr) << sl) << 16);
+            if ((j & 3) == 0) a0 = word; else if ((j & 3) == 1) a1 = word; else if ((j & 3) == 2) a2 = word; else a3 = word;
+            if ((j & 3) == 3) slot[(size_t)((blk + j) >> 2) * 64] = make_uint4(a0, a1, a2, a3);
+        }
     }
-    __device__ __forceinline__ void flush(int n) { if (n & 3) slot[(size_t)(n >> 2) * 64] = make_uint4(a0, a1, a2, a3); }
+    __device__ __forceinline__ void flush(int n)
+    {
+        if (HALF) { if (n & 7) slot[(size_t)(n >> 3) * 64] = make_uint4(a0, a1, a2, a3); }
+        else if (n & 3) slot[(size_t)(n >> 2) * 64] = make_uint4(a0, a1, a2, a3);
+    }
 };
 
 __device__ __forceinline__ uint32_t quad_elem(const uint4 &q, int e) { return e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w; }
 
 // STAMP: diagnostic build only (FSV_K6_STAMPS=1): shader-clock cycles of the three phases summed per wave into `stamps`
-template <bool STAMP>
+template <bool STAMP, bool HALF = false>
 __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res,
                                                 const uint32_t *__restrict__ dp_list, const uint32_t *__restrict__ n_dev,
                                                 fsv_wpath *__restrict__ paths, uint4 *__restrict__ cols, unsigned long long *__restrict__ stamps)
@@ -1216,8 +1238,9 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
         fsv_wpath *P = paths + tid;
         const int n = t.x_len, k = t.k, band = 2 * k + 1;
         const int end = r0.end_site, err = r0.err;
-        const int row0 = band - (n + 2 * k - end), lo = row0 - FSV_SB_MAXERR;
-        SubbandSink sink;
+        constexpr int ME = HALF ? FSV_SB16_MAXERR : FSV_SB_MAXERR, QSH = HALF ? 3 : 2;
+        const int row0 = band - (n + 2 * k - end), lo = row0 - ME;
+        SubbandSink<HALF> sink;
         sink.slot = slot; sink.sr = (uint32_t)max(lo, 0); sink.sl = (uint32_t)max(-lo, 0);
         sink.lmask = band == 1 ? 1u : (1u << (band - 1)) - 1u;
         sink.a0 = sink.a1 = sink.a2 = sink.a3 = 0;
@@ -1227,20 +1250,20 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
         if (STAMP) t1 = __builtin_amdgcn_s_memtime();
         if (r.err != err || r.end_site != end) { P->state = 0; continue; }   // cannot happen: the same DP as K5
         for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
-        int cur = err, ci = n - 1, plen = 0, start = end, rel = FSV_SB_MAXERR, dir = 0;
+        int cur = err, ci = n - 1, plen = 0, start = end, rel = ME, dir = 0;
         uint32_t acc = 0;
         // The walk, a quad of columns per phase: every lane walks until it leaves its current quad (four column steps plus its
         // "up" steps), then all lanes move one quad down together.  Three quads rotate through registers and the one just left
         // is refilled with the quad three below, so a quad is requested two phases before it is walked and no lane ever waits
         // for a load another lane has just issued (with a per-lane "switch when I cross" every crossing waited out the full
         // memory latency of the neighbour's request: 1 500 cycles per step, FSV_K6_STAMPS).
-        int qi = ci >> 2;
+        int qi = ci >> QSH;
         auto quad = [&](int q) { return q >= 0 ? slot[(size_t)q * 64] : make_uint4(0, 0, 0, 0); };
         uint4 qa = quad(qi), qb = quad(qi - 1), qc = quad(qi - 2);
         auto phase = [&](const uint4 &q4) {
-            while (cur != 0 && ci >= 0 && (ci >> 2) == qi) {
-                const uint32_t w = quad_elem(q4, ci & 3);
-                const uint32_t code = ((w >> rel) & 1u) | (((w >> (16 + rel)) & 1u) << 1);
+            while (cur != 0 && ci >= 0 && (ci >> QSH) == qi) {
+                const uint32_t w = HALF ? (quad_elem(q4, (ci & 7) >> 1) >> ((ci & 1) << 4)) & 0xffffu : quad_elem(q4, ci & 3);
+                const uint32_t code = ((w >> rel) & 1u) | (((w >> ((HALF ? 8 : 16) + rel)) & 1u) << 1);
                 acc |= code << ((plen & 15) << 1);
                 if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
                 plen++;
