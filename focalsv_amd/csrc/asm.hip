@@ -205,8 +205,8 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
                        (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed, 0u, 1024u, mz_total);
     FSV_HIP(ctx, hipGetLastError());
     if (G.max_words * 16u > 1024u) {   // at most one minimizer per base: shorter reads cannot have a longer list
-        hipLaunchKernelGGL(k_uniq<FSV_UQ_MAX>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
-                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed, 1024u, 0xffffffffu, mz_total);
+        hipLaunchKernelGGL(k_uniq_walk<FSV_UQ_MAX>, dim3(std::min<uint32_t>(B.n_reads, 2u * (uint32_t)ctx->n_cu)), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
+                           (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed, 1024u, 0xffffffffu, mz_total, B.n_reads);
         FSV_HIP(ctx, hipGetLastError());
     }
     W.kt.end(ctx);

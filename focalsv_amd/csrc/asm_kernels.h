@@ -210,14 +210,13 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
 // ------------------------------------------------------------------------------------------------ k_uniq
 // One workgroup per read: bitonic sort of (hash, pos) in LDS, keep hashes that occur exactly once.
 template <int UQ_MAX>
-__global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
-                                              uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed = nullptr,
-                                              uint32_t lo_cnt = 0u, uint32_t hi_cnt = 0xffffffffu, unsigned long long *__restrict__ total = nullptr)
+__device__ __forceinline__ void uniq_read(const uint32_t r, fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
+                                          uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed, uint32_t lo_cnt, uint32_t hi_cnt,
+                                          unsigned long long *__restrict__ total)
 {
     __shared__ uint64_t s_hash[UQ_MAX];
     __shared__ uint64_t s_pay[UQ_MAX]; // pos | rev << 32 | span << 40
     __shared__ uint32_t s_scan[256];
-    const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
     if (only_changed && !only_changed[r]) return;   // lists of an unchanged read are already in place
     // The sort holds a read's list in LDS, so the kernel is instantiated for short and for long lists (many reads per CU for
@@ -299,6 +298,28 @@ __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uin
             }
         for (uint32_t i = tid; i < m; i += 256) { fsv_mz x; x.hash = s_hash[i]; const uint64_t p = s_pay[i]; x.pos = (uint32_t)p; x.rev = (uint8_t)(p >> 32); x.span = (uint8_t)(p >> 40); x.pad = 0; a[m + i] = x; }
     } else if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_INTERNAL); // cannot happen: at most one minimizer per base and slots hold len + 64
+}
+
+template <int UQ_MAX>
+__global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
+                                              uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed = nullptr,
+                                              uint32_t lo_cnt = 0u, uint32_t hi_cnt = 0xffffffffu, unsigned long long *__restrict__ total = nullptr)
+{
+    uniq_read<UQ_MAX>(blockIdx.x, mz, mz_off, mz_cnt, warn, only_changed, lo_cnt, hi_cnt, total);
+}
+
+// the same for a size class that is usually empty (lists above 1 024 entries in a HiFi batch): a few blocks walk all reads, so the
+// 64 KB of LDS a block of this instantiation needs are claimed a few hundred times, not once per read (under three lanes the
+// one-block-per-read launch averaged 2.8 ms against 0.01 alone: every block waited for LDS only to find its read in the other class)
+template <int UQ_MAX>
+__global__ __launch_bounds__(256) void k_uniq_walk(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
+                                                   uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed, uint32_t lo_cnt, uint32_t hi_cnt,
+                                                   unsigned long long *__restrict__ total, uint32_t n_reads)
+{
+    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        uniq_read<UQ_MAX>(r, mz, mz_off, mz_cnt, warn, only_changed, lo_cnt, hi_cnt, total);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_chain
