@@ -2949,7 +2949,7 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
         const uint64_t r0 = ~lo & kmask, r1 = ~hi & kmask;
         const int z = f1 < r1 ? 0 : 1;
         if (z_out) *z_out = z;
-        return z ? mix64(r0) + mix64(r1) : mix64(f0) + mix64(f1);
+        return mix64(z ? r0 : f0) + mix64(z ? r1 : f1);   // the strand is chosen first: two hashes per entry, not four
     };
     auto emit = [&](int p) {
         int z = 0;
@@ -2968,14 +2968,17 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
         const int NW = SKF_T + 2 * (w - 1);
         int p2 = 1;
         while (p2 * 2 <= w) p2 <<= 1;
-        auto pass = [&](const uint64_t *src, int d, bool is_max) {   // s_wmin[i] = op(src[i], src[i+d]) for every i < NW
-            uint64_t v[SKF_V];
+        // every thread keeps its own elements in registers between the passes and only reads its partner's from the tile
+        uint64_t v[SKF_V];
+#pragma unroll
+        for (int c = 0; c < SKF_V; c++) { const int i = tid + 256 * c; v[c] = i < NW ? s_h[i] : NONE; }
+        auto pass = [&](const uint64_t *src, int d, bool is_max) {   // s_wmin[i] = op(own[i], src[i+d]) for every i < NW
 #pragma unroll
             for (int c = 0; c < SKF_V; c++) {
                 const int i = tid + 256 * c;
                 if (i < NW) {
-                    const uint64_t a = src[i], b = i + d < NW ? src[i + d] : (is_max ? 0ull : NONE);
-                    v[c] = is_max ? max(a, b) : min(a, b);
+                    const uint64_t b = i + d < NW ? src[i + d] : (is_max ? 0ull : NONE);
+                    v[c] = is_max ? max(v[c], b) : min(v[c], b);
                 }
             }
             __syncthreads();
@@ -3010,7 +3013,7 @@ __global__ __launch_bounds__(256) void k_sketch_fast(const uint32_t *__restrict_
 #pragma unroll
                 for (int c = 0; c < SKF_V; c++) {
                     const int i = tid + 256 * c, t = t0 + i;
-                    if (i < NW && !(t >= T0 && t <= M - 1 && i < SKF_T + w - 1)) s_wmin[i] = 0ull;
+                    if (i < NW && !(t >= T0 && t <= M - 1 && i < SKF_T + w - 1)) { s_wmin[i] = 0ull; v[c] = 0ull; }
                 }
                 __syncthreads();
             }

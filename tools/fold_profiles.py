@@ -29,9 +29,15 @@ def kname(row):
     return re.sub(r"\(.*", "", name).strip()
 
 
+def newest(files):
+    return sorted(files, key=os.path.getmtime)[-1:]
+
+
 def fold(d):
     acc, n = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    # gpurun merges each call's files into the local directory, so a pass that was run more than once leaves one file per
+    # run behind (named by pid): only the newest one is this round's
+    for f in newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 k = kname(row)
@@ -59,7 +65,7 @@ def main():
     prof = os.path.join(ROOT, "profiles")
     st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if st:
-        shutil.copy(st[0], os.path.join(prof, tag + "_kernel_stats.csv"))
+        shutil.copy(newest(st)[0], os.path.join(prof, tag + "_kernel_stats.csv"))
     for b in glob.glob(os.path.join(src, "bench*.json")):
         shutil.copy(b, os.path.join(prof, tag + "_" + os.path.basename(b)))
     fe, fn = fold(os.path.join(src, "fetch"))
