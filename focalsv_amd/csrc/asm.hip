@@ -224,12 +224,29 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     // 65 536 bases), so the tile no longer has to be cut to the batch's longest list to keep several pairs per CU
     A.upair_tab = (const uint4 *)W.upair_tab.p; A.pair_list = nullptr; A.n_list_dev = nullptr;
     A.amax = wide_anchors ? FSV_AMAX_WIDE : FSV_AMAX;
+    A.stamps = nullptr;
+    if (getenv("FSV_CHAIN_STAMPS")) {   // diagnostic: where a k_chain wave spends its cycles (never in a measured run)
+        TRY(ensure(ctx, W.tmp, 128));
+        FSV_HIP(ctx, hipMemsetAsync(W.tmp.p, 0, 128, ctx->stream));
+        A.stamps = (unsigned long long *)W.tmp.p;
+    }
     // algorithmic bytes of the launch are filled in when the batch ends (they need the counts this launch leaves on the device)
     W.chain_rec.push_back(W.kt.begin(ctx, KN_CHAIN, 0));
-    if (short_reads) hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A.amax), ctx->stream, A);
-    else hipLaunchKernelGGL(k_chain<false>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(false, A.amax), ctx->stream, A);
+    const uint32_t n_chunks = (B.n_upairs + FSV_CHAIN_CH - 1) / FSV_CHAIN_CH;
+    if (short_reads) hipLaunchKernelGGL(k_chain_chunks<true>, dim3(n_chunks), dim3(64), chain_lds_bytes(true, A.amax), ctx->stream, A, B.n_upairs);
+    else hipLaunchKernelGGL(k_chain_chunks<false>, dim3(n_chunks), dim3(64), chain_lds_bytes(false, A.amax), ctx->stream, A, B.n_upairs);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
+    if (A.stamps) {
+        unsigned long long h[16];
+        FSV_HIP(ctx, hipMemcpyAsync(h, W.tmp.p, 128, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        static const char *nm[7] = {"stage lists", "lookups", "exit: few anchors", "compaction", "chain DP", "best + walk", "tasks + records"};
+        fprintf(stderr, "[fsv] k_chain (%u pairs, tasks %d):", B.n_upairs, emit_tasks ? 1 : 0);
+        for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.0f cyc x %llu;", nm[i], h[8 + i] ? (double)h[i] / h[8 + i] : 0.0, h[8 + i]);
+        fprintf(stderr, "\n");
+        A.stamps = nullptr;
+    }
     W.last_chain = A;
     tc.stop();
     return FSV_OK;

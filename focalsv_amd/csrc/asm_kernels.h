@@ -368,6 +368,7 @@ struct ChainArgs {
     const uint8_t *thr_tab;      // 376 entries: threshold for a window of that length
     uint32_t n_sets;
     int32_t k_score, min_anchors, min_ovlp, bw, emit_tasks;
+    unsigned long long *stamps;  // diagnostic (FSV_CHAIN_STAMPS=1): shader cycles per phase summed over the waves, else nullptr
 };
 
 // The unordered pairs of every set, enumerated once per batch: block b of k_chain reads one 16-byte record instead of
@@ -398,10 +399,11 @@ __global__ void k_pair_tab(const uint32_t *__restrict__ set_start, const uint32_
 // in the 8 B the DP arrays do not need yet (position / span / strand of a hit come from the L2-resident list).  Round 1 used
 // 24 B (64-bit keys, 32-bit DP arrays, 12-byte staged records), which capped the kernel at 1-2 waves per SIMD on the batch's
 // longest lists; the long layout is kept for batches with a read of 65 536 bases or more.
+#define FSV_CHAIN_QR 12   // the query list sits in registers when it has at most 64 x this many entries (768: reads up to ~27 kb; 16 would cost the third wave per SIMD)
 template <bool SHORT>
-__global__ __launch_bounds__(64) void k_chain(ChainArgs A)
+__device__ __forceinline__ void chain_pair(const ChainArgs &A, unsigned char *s_raw, const uint4 pt, const int lenq, const int lent, const int nq, const int nt,
+                                           const fsv_mz *mq, const fsv_mz *mt, const uint4 (&qa)[FSV_CHAIN_QR])
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int AMAX = A.amax;
     using key_t = typename std::conditional<SHORT, uint32_t, uint64_t>::type;   // qe << 16 | te   or   qe << 32 | te
     using dp_t = typename std::conditional<SHORT, uint16_t, int32_t>::type;
@@ -418,46 +420,87 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
 #define KEY_Q(i) ((int)((uint64_t)s_key[i] >> KSH))
 #define KEY_T(i) ((int)((uint64_t)s_key[i] & KMASK))
 #define MAKE_KEY(q_, t_) ((key_t)(((uint64_t)(uint32_t)(q_) << KSH) | (uint64_t)(uint32_t)(t_)))
-    const int lane = threadIdx.x;
-    if (A.pair_list && A.n_list_dev && blockIdx.x >= *A.n_list_dev) return;
-    const uint4 pt = A.upair_tab[A.pair_list ? A.pair_list[blockIdx.x] : blockIdx.x];
+    int lane_ = threadIdx.x;
+    // (opaque to the optimiser: called in a loop, the compiler otherwise hoists every lane-derived constant of the body out of it
+    // and holds them in ~80 extra registers -- two waves per SIMD instead of three)
+    asm volatile("" : "+v"(lane_));
+    const int lane = lane_;
     const uint32_t q = pt.y & 0xffffu, t = pt.y >> 16;
     const uint32_t p = pt.z, pm = pt.w;     // ordered slots (q, t) and (t, q)
     const uint32_t rq = pt.x + q, rt = pt.x + t;
-    const int lenq = A.read_len[rq], lent = A.read_len[rt];
-    const int nq = (int)A.mz_cnt[rq], nt = (int)A.mz_cnt[rt];
-    const fsv_mz *mq = A.mz + A.mz_off[rq] + nq, *mt = A.mz + A.mz_off[rt]; // q: position-sorted copy, t: hash-sorted
     fsv_ovl o;
     o.q = q; o.t = t; o.x_s = o.x_e = o.y_s = o.y_e = 0; o.score = 0; o.n_chain = 0; o.chain_off = 0; o.first_win = 0; o.n_win = 0;
     o.align_len = 0; o.err_sum = 0; o.rev = 0; o.is_match = 0; o.exact = 0; o.valid = 0;
     fsv_ovl om = o; // the mirrored overlap (t on q)
     om.q = t; om.t = q;
 #define PUT_BOTH() do { if (lane == 0) { A.ovl[p] = o; A.ovl[pm] = om; } } while (0)
+    const bool stamped = A.stamps && (blockIdx.x & 63u) == 0u;   // one block in 64: the atomics must not become the load
+    unsigned long long tm = stamped ? __builtin_amdgcn_s_memtime() : 0ull;
+#define CH_MARK(i_) do { if (stamped) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) { atomicAdd(&A.stamps[i_], t_ - tm); atomicAdd(&A.stamps[8 + (i_)], 1ull); } tm = t_; } } while (0)
 
     // 1. anchors: every q minimizer is looked up in t's sorted unique list.  All global loads are issued up front -- t's
     //    hashes go to LDS (the long layout also stages {pos, span, strand}: 12 B per entry in the DP arrays, free until the
     //    DP), q's records to registers (16 B per lane per 64 minimizers) -- so a pair pays one memory latency instead of two
     //    per batch of 64 lookups; the ~10 probes of a lookup are LDS reads.
     uint64_t *s_th = (uint64_t *)s_rest;
-    uint32_t *s_tp = (uint32_t *)(s_rest + 8 * (size_t)AMAX);   // long layout only
+    uint32_t *s_tp = (uint32_t *)(s_rest + 8 * (size_t)AMAX);   // long layout only (staging them for SHORT too -- 16 B per anchor, 9 pairs per CU -- was slower)
     const bool t_in_lds = nt <= AMAX && lent < (1 << 23);
     const uint4 *mq4 = (const uint4 *)mq, *mt4 = (const uint4 *)mt;
-    constexpr int QR = FSV_AMAX / 64;   // the query list sits in registers when it has at most FSV_AMAX entries (AMAX itself may be larger: FSV_AMAX_WIDE)
-    uint4 qa[QR];
-    const bool q_in_regs = nq <= FSV_AMAX;
-    if (q_in_regs) {
+    constexpr int QR = FSV_CHAIN_QR;
+    const bool q_in_regs = nq <= 64 * FSV_CHAIN_QR;   // (the caller loaded them)
+    if (t_in_lds) {
+        // eight loads in flight per lane: written as a plain loop the compiler waits for every load before it issues the next
+        // (s_waitcnt vmcnt(0) in front of each LDS write) -- seven dependent round trips for a 15 kb read's list, which was
+        // most of the kernel's time
+        for (int base = 0; base < nt; base += 512) {
+            if (SHORT) {
+                uint2 v[8];
 #pragma unroll
-        for (int u = 0; u < QR; u++) { const int i = u * 64 + lane; qa[u] = i < nq ? mq4[i] : make_uint4(0, 0, 0, 0); }
-    }
-    if (t_in_lds)
-        for (int i = lane; i < nt; i += 64) {
-            const uint4 b = mt4[i];
-            s_th[i] = (uint64_t)b.x | (uint64_t)b.y << 32;
-            if (!SHORT) s_tp[i] = b.z | (b.w & 0xffu) << 31 | ((b.w >> 8) & 0xffu) << 23; // pos < 2^23 | span << 23 | strand << 31
+                for (int u = 0; u < 8; u++) { const int i = base + u * 64 + lane; if (i < nt) v[u] = *reinterpret_cast<const uint2 *>(mt4 + i); }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = base + u * 64 + lane; if (i < nt) s_th[i] = (uint64_t)v[u].x | (uint64_t)v[u].y << 32; }
+            } else {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = base + u * 64 + lane; if (i < nt) v[u] = mt4[i]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = base + u * 64 + lane;
+                    if (i < nt) {
+                        s_th[i] = (uint64_t)v[u].x | (uint64_t)v[u].y << 32;
+                        s_tp[i] = v[u].z | (v[u].w & 0xffu) << 31 | ((v[u].w >> 8) & 0xffu) << 23; // pos < 2^23 | span << 23 | strand << 31
+                    }
+                }
+            }
         }
+    }
     if (SHORT) for (int i = lane; i < AMAX / 32; i += 64) s_strand[i] = 0u;
     __syncthreads();
+    // the hashes are uniform, so their top six bits cut the sorted list into 64 buckets of a few entries each: one search per
+    // lane finds the bucket bounds, and a lookup then needs ~3 probes instead of log2(nt) ~ 9 (the lookups were nearly all of
+    // the kernel's instructions: every q minimizer against every t list of the set, overlapping or not)
+    __shared__ uint32_t s_bk[65];
+    if (t_in_lds) {
+        int l2 = 0, h2 = nt;
+        while (l2 < h2) { const int mid = (l2 + h2) >> 1; if ((uint32_t)(s_th[mid] >> 58) < (uint32_t)lane) l2 = mid + 1; else h2 = mid; }
+        s_bk[lane] = (uint32_t)l2;
+        if (lane == 0) s_bk[64] = (uint32_t)nt;
+        __syncthreads();
+    }
+    CH_MARK(0);
     int n = 0, nrev = 0, nfwd = 0;
+    auto commit = [&](bool hit, key_t key, uint32_t srev, uint32_t tspan) {
+        uint64_t m = __ballot(hit);
+        int at = n + __popcll(m & ((1ull << lane) - 1));
+        if (hit && at < AMAX) {
+            s_key[at] = key;
+            if (SHORT) { if (srev) atomicOr(&s_strand[at >> 5], 1u << (at & 31)); }
+            else s_aux[at] = (uint16_t)(tspan | (srev << 8));
+        }
+        nrev += __popcll(__ballot(hit && srev));
+        nfwd += __popcll(__ballot(hit && !srev));
+        n += __popcll(m);
+    };
     auto lookup = [&](int i, const uint4 av) {
         bool hit = false; key_t key = 0; uint32_t srev = 0, tspan = 0;
         if (i < nq) {
@@ -468,6 +511,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
             const uint32_t qrev = (uint32_t)(lenq - 1) - (av.z - ((av.w >> 8) & 0xffu) + 1);
             int l2 = 0, h2 = nt;
             if (t_in_lds) {
+                l2 = (int)s_bk[av.y >> 26]; h2 = (int)s_bk[(av.y >> 26) + 1];
                 while (l2 < h2) { int mid = (l2 + h2) >> 1; if (s_th[mid] < ah) l2 = mid + 1; else h2 = mid; }
                 if (l2 < nt && s_th[l2] == ah) {
                     uint32_t tpos;
@@ -484,24 +528,66 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
                 }
             }
         }
-        uint64_t m = __ballot(hit);
-        int at = n + __popcll(m & ((1ull << lane) - 1));
-        if (hit && at < AMAX) {
-            s_key[at] = key;
-            if (SHORT) { if (srev) atomicOr(&s_strand[at >> 5], 1u << (at & 31)); }
-            else s_aux[at] = (uint16_t)(tspan | (srev << 8));
-        }
-        nrev += __popcll(__ballot(hit && srev));
-        nfwd += __popcll(__ballot(hit && !srev));
-        n += __popcll(m);
+        commit(hit, key, srev, tspan);
     };
-    if (q_in_regs) {
+    if (q_in_regs && t_in_lds) {
+        // four batches of 64 lookups at a time: their probe chains are independent, so the four LDS reads of a step (and the
+        // four fetches of the hits' records) are in flight together -- one batch at a time a wave spent ~1 700 cycles per batch
+        // on dependent LDS / memory latency (FSV_CHAIN_STAMPS)
 #pragma unroll
-        for (int u = 0; u < QR; u++) { if (u * 64 < nq) lookup(u * 64 + lane, qa[u]); }
+        for (int u0 = 0; u0 < QR; u0 += 4) {
+            if (u0 * 64 < nq) {
+                int l[4], h[4];
+                uint64_t ah[4];
+                bool val[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint4 av = qa[u0 + j];
+                    val[j] = (u0 + j) * 64 + lane < nq;
+                    ah[j] = (uint64_t)av.x | (uint64_t)av.y << 32;
+                    const uint32_t b = av.y >> 26;
+                    l[j] = val[j] ? (int)s_bk[b] : 0; h[j] = val[j] ? (int)s_bk[b + 1] : 0;
+                }
+                for (;;) {
+                    bool more = false;
+                    uint64_t v[4];
+                    int mid[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { mid[j] = (l[j] + h[j]) >> 1; v[j] = s_th[mid[j]]; }   // (mid <= nt <= AMAX: inside the tile)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool act = l[j] < h[j], lt = v[j] < ah[j];
+                        l[j] = act && lt ? mid[j] + 1 : l[j]; h[j] = act && !lt ? mid[j] : h[j];
+                        more |= act;
+                    }
+                    if (!__any(more)) break;
+                }
+                uint64_t c[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) c[j] = s_th[l[j]];
+                bool hit[4];
+                uint32_t tz[4] = {0, 0, 0, 0}, tw[4] = {0, 0, 0, 0};   // position; strand | span << 8
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    hit[j] = val[j] && l[j] < nt && c[j] == ah[j];
+                    if (SHORT) { if (hit[j]) { const uint2 b = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(mt4 + l[j]) + 8); tz[j] = b.x; tw[j] = b.y; } }
+                    else if (hit[j]) { const uint32_t tp = s_tp[l[j]]; tz[j] = tp & 0x7fffffu; tw[j] = (tp >> 31) | ((tp >> 23) & 0xffu) << 8; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((u0 + j) * 64 < nq) {
+                        const uint4 av = qa[u0 + j];
+                        const uint32_t qrev = (uint32_t)(lenq - 1) - (av.z - ((av.w >> 8) & 0xffu) + 1);
+                        const uint32_t srev = (av.w & 0xffu) ^ (tw[j] & 0xffu);
+                        commit(hit[j], MAKE_KEY(srev ? qrev : av.z, tz[j]), hit[j] ? srev : 0u, (tw[j] >> 8) & 0xffu);
+                    }
+            }
+        }
     } else
         for (int base = 0; base < nq; base += 64) { const int i = base + lane; lookup(i, i < nq ? mq4[i] : make_uint4(0, 0, 0, 0)); }
     if (n > AMAX) { if (lane == 0) atomicOr(&A.warn[rq], (uint32_t)FSV_W_ANCHOR_TRUNC); n = AMAX; }
     __syncthreads();
+    CH_MARK(1);
     // 2. majority strand, compaction
     const int rev = nrev > nfwd;
     int m2 = 0;
@@ -520,7 +606,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         __syncthreads();
     }
     n = m2;
-    if (n < A.min_anchors) { PUT_BOTH(); return; }
+    if (n < A.min_anchors) { PUT_BOTH(); CH_MARK(2); return; }
     // 3. anchors are in query order: q's minimizers were walked by position and both compactions keep the order (query positions
     //    are distinct, so (qe, te) order == qe order) -- for a reverse-strand pair that is decreasing order on the query's reverse
     //    strand, so the list is turned around
@@ -533,6 +619,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     //    the DP provably links each anchor to its nearest predecessor -- gap 0 means no indel penalty, and
     //    f[i-1] + min(d_i,k) >= f[j] + min(qe_i - qe_j, k) for every j < i-1 because min(.,k) is sub-additive, with the
     //    nearest predecessor winning ties -- so the chain is the whole list and the score a running sum.
+    CH_MARK(3);
     bool colinear;
     {
         const int d0 = KEY_T(0) - KEY_Q(0);
@@ -601,12 +688,26 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
             __syncthreads();
             if (in) { s_f[i] = (dp_t)fi; s_ind[i] = (dp_t)ti; s_sl[i] = (dp_t)tl; }
             __syncthreads();
+            // The look-back stops where no earlier anchor can matter any more: P[j] = max f over the 64 anchors before the block
+            // and the block up to j never decreases with j, so once P[i-d] + k <= f[i] nothing at distance d or beyond can beat
+            // the hypothesis.  Scores grow by ~35 an anchor, so that is after two or three steps -- the loop used to run all 63
+            // (a dependent LDS read each) whenever the block had that many predecessors: most of the round-1 DP's time.
+            // f and P of the 128 anchors sit in registers; distance d is a lane rotation.
+            const int pj0 = i0 - 64 + lane;
+            const int pf = pj0 >= 0 ? (int)s_f[pj0] : 0, cf = in ? fi : 0;
+            int pP = pf, cP = cf;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o1 = __shfl_up(pP, off, 64), o2 = __shfl_up(cP, off, 64);
+                if (lane >= off) { pP = max(pP, o1); cP = max(cP, o2); }
+            }
+            cP = max(cP, __shfl(pP, 63, 64));
+            bool live = in && !bad;
             for (int d = 2; d <= 64; d++) {
-                const int j = i - d;
-                const bool live = in && !bad && j >= 0;
+                const int j = i - d, src = (lane - d) & 63;
+                const int f_c = __shfl(cf, src, 64), f_p = __shfl(pf, src, 64), P_c = __shfl(cP, src, 64), P_p = __shfl(pP, src, 64);
+                const int fj = lane >= d ? f_c : f_p, Pj = lane >= d ? P_c : P_p;
+                live = live && !bad && j >= 0 && Pj + kk > fi;
                 if (!__any(live)) break;
-                int fj = 0;
-                if (live) fj = (int)s_f[j];
                 const bool need = live && fj + kk > fi;
                 if (__any(need)) {
                     if (need) {
@@ -652,6 +753,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         }
         __syncthreads();
     }
+    CH_MARK(4);
     // 5. best chain end: highest score, smallest index on ties
     long long bk = -1;
     for (int i = lane; i < n; i += 64) { long long v = (long long)s_f[i] * 4096 + (4095 - i); bk = v > bk ? v : bk; }
@@ -685,6 +787,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
         }
     }
     __syncthreads();
+    CH_MARK(5);
     if (cnt < A.min_anchors) { PUT_BOTH(); return; }
     const int first = s_chain[cnt - 1];
     int xs = KEY_Q(first), ys = KEY_T(first);
@@ -781,10 +884,89 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
 #undef CH_Q
 #undef CH_T
     PUT_BOTH();
+    CH_MARK(6);
+#undef CH_MARK
 #undef PUT_BOTH
 #undef KEY_Q
 #undef KEY_T
 #undef MAKE_KEY
+}
+
+template <bool SHORT>
+__device__ __forceinline__ void chain_load_query(uint4 (&qa)[FSV_CHAIN_QR], const fsv_mz *mq, int nq)
+{
+    const uint4 *mq4 = (const uint4 *)mq;
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));   // (see chain_pair)
+    if (nq <= 64 * FSV_CHAIN_QR) {
+#pragma unroll
+        for (int u = 0; u < FSV_CHAIN_QR; u++) { const int i = u * 64 + lane; qa[u] = i < nq ? mq4[i] : make_uint4(0, 0, 0, 0); }
+    }
+}
+
+// one block per listed pair (the re-chaining of a few pairs with another band width)
+template <bool SHORT>
+__global__ __launch_bounds__(64) void k_chain(ChainArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    if (A.pair_list && A.n_list_dev && blockIdx.x >= *A.n_list_dev) return;
+    const uint4 pt = A.upair_tab[A.pair_list ? A.pair_list[blockIdx.x] : blockIdx.x];
+    const uint32_t rq = pt.x + (pt.y & 0xffffu), rt = pt.x + (pt.y >> 16);
+    const int lenq = A.read_len[rq], lent = A.read_len[rt];
+    const int nq = (int)A.mz_cnt[rq], nt = (int)A.mz_cnt[rt];
+    const fsv_mz *mq = A.mz + A.mz_off[rq] + nq, *mt = A.mz + A.mz_off[rt]; // q: position-sorted copy, t: hash-sorted
+    uint4 qa[FSV_CHAIN_QR];
+    chain_load_query<SHORT>(qa, mq, nq);
+    chain_pair<SHORT>(A, s_raw, pt, lenq, lent, nq, nt, mq, mt, qa);
+}
+
+// The full pass: one block per FSV_CHAIN_CH consecutive pairs of the pair table (row-major: the pairs of a chunk nearly always
+// share their query).  A block per pair paid three dependent memory round trips before its first lookup (pair record -> lengths /
+// counts / offsets -> the two lists: two thirds of the kernel's wave cycles, FSV_CHAIN_STAMPS); here the chunk's records and
+// its targets' lengths, counts and offsets arrive in two trips for all its pairs, and a pair waits for one round trip -- the two
+// lists.  (One block per whole row was slower: rows have 0 .. ns-1 pairs.)
+#define FSV_CHAIN_CH 8
+template <bool SHORT>
+__global__ __launch_bounds__(64) void k_chain_chunks(ChainArgs A, uint32_t n_upairs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int lane = threadIdx.x;
+    const uint32_t first = blockIdx.x * FSV_CHAIN_CH;
+    if (first >= n_upairs) return;
+    const int np = (int)min((uint32_t)FSV_CHAIN_CH, n_upairs - first);
+    uint4 ptv = make_uint4(0, 0, 0, 0);
+    int lent_v = 0, nt_v = 0;
+    uint32_t offt_v = 0;
+    if (lane < np) {
+        ptv = A.upair_tab[first + lane];
+        const uint32_t rt = ptv.x + (ptv.y >> 16);
+        lent_v = A.read_len[rt]; nt_v = (int)A.mz_cnt[rt]; offt_v = A.mz_off[rt];
+    }
+    // q's list stays in registers while the query does not change: the kernel is bound by the L2 -> L1 traffic of the lists
+    // (13.8 KB per pair when both are loaded for every pair: ~2.9 TB/s), not by latency
+    uint32_t cur_rq = 0xffffffffu;
+    int lenq = 0, nq = 0;
+    uint32_t offq = 0;
+    uint4 qa[FSV_CHAIN_QR];
+#pragma nounroll
+    for (int i = 0; i < np; i++) {
+        // readlane: the pair's values are wave-uniform and must live in scalar registers
+#define RL(v_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), i))
+        const uint4 pt = make_uint4(RL(ptv.x), RL(ptv.y), RL(ptv.z), RL(ptv.w));
+        const int lent = (int)RL(lent_v), nt = (int)RL(nt_v);
+        const uint32_t offt = RL(offt_v);
+#undef RL
+        const uint32_t rq = pt.x + (pt.y & 0xffffu);
+        if (rq != cur_rq) {
+            cur_rq = rq;
+            lenq = __builtin_amdgcn_readfirstlane(A.read_len[rq]); nq = __builtin_amdgcn_readfirstlane((int)A.mz_cnt[rq]);
+            offq = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.mz_off[rq]);
+            chain_load_query<SHORT>(qa, A.mz + offq + nq, nq);   // the position-sorted copy
+        }
+        const fsv_mz *mq = A.mz + offq + nq;
+        chain_pair<SHORT>(A, s_raw, pt, lenq, lent, nq, nt, mq, A.mz + offt, qa);
+        __syncthreads();   // the next pair reuses the tile
+    }
 }
 
 // LDS bytes of a k_chain block
