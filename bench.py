@@ -390,7 +390,8 @@ def main():
         pmc_name, pmc = newest_profile("_pmc_hbm_traffic.json")
         sq_name, sq = newest_profile("_pmc_sq.json")
         alias = {"k_sketch": ["k_sketch_fast", "k_sketch"], "k5_bpm": ["k5_bpm_kernel"], "k_path_dp": ["k_path_sb", "k_path_dp", "k_path_indel1"],
-                 "k_uniq": ["k_uniq"], "k_chain": ["k_chain"]}
+                 "k_uniq": ["k_uniq", "k_uniq_walk"], "k_chain": ["k_chain", "k_chain_chunks"], "k_consensus": ["k_consensus", "k_consensus_redo", "k_read_dirty"],
+                 "k_bnd_tasks": ["k_bnd_tasks", "k_newlen"], "k_bnd_consensus": ["k_bnd_consensus", "k_bnd_apply"]}
 
         def prof_rows(table, name):
             """profile rows of the kernels a library statistic covers (template instances together)"""
@@ -446,7 +447,8 @@ def main():
                     "valu": {"achieved_lane_ops_per_s": kd.get("valu_lane_ops_per_s"), "peak": PEAK_LANE_OPS, "frac": kd.get("valu_frac_of_peak"),
                              "note": "SQ_INSTS_VALU x 64 / the kernel's solo time / 78.6e12 (SURVEY.md 7: the binding roof of the integer DP kernels)"},
                     "sources": {"algo_bytes": "per launch, from the task counts the library reports (DESIGN.md section 3: window x 212 B, K6 window x 324 B, k_chain = "
-                                              "unique minimizers x 32 B + overlap slots x 56 B + task records x 32 B): SURVEY.md 8(d) streamed-operand model",
+                                              "unique minimizers x 32 B + overlap slots x 56 B + task records x 32 B; the second consensus pass's junction tasks counted like window tasks, "
+                                              "k_bnd_consensus = junction path records x 128 B + patches): SURVEY.md 8(d) streamed-operand model",
                                 "durations": "HIP events on the lanes' streams over the timed region (achieved) / one lane alone (exclusive)",
                                 "traffic": f"profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 (gfx950), per launch" if kd.get("traffic_per_launch") else
                                            f"null: profiles/{pmc_name} was measured on other sources (digest {pmc.get('source_sha') if pmc else None} != {sha})",

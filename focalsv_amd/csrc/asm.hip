@@ -35,10 +35,10 @@ struct KTimes {
     void reset() { recs.clear(); used = 0; }
     ~KTimes() { for (auto e : pool) (void)hipEventDestroy(e); }
 };
-enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_PARTITION, KN_BND, KN_COUNT,
+enum { KN_SKETCH, KN_UNIQ, KN_CHAIN, KN_BPM, KN_RESCUE, KN_PATH_FAST, KN_PATH_DP, KN_CONSENSUS, KN_REPACK, KN_EXACT, KN_STITCH, KN_PARTITION, KN_BND, KN_BND_CONS, KN_COUNT,
        ST_SKETCH = KN_COUNT, ST_CHAIN, ST_VERIFY, ST_PATH, ST_CONSENSUS, ST_FINAL };
 const char *const kn_names[KN_COUNT] = {"k_sketch", "k_uniq", "k_chain", "k5_bpm", "k_rescue_accept", "k_path_fast", "k_path_dp", "k_consensus",
-                                        "k_repack", "k_exact", "k_stitch", "k_partition", "k_bnd"};
+                                        "k_repack", "k_exact", "k_stitch", "k_partition", "k_bnd_tasks", "k_bnd_consensus"};
 
 // a stage: from construction to stop(), in stream order
 struct Span {
@@ -56,7 +56,7 @@ struct AsmWs {
     DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
-    std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
+    std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -446,7 +446,7 @@ extern "C" int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out)
 static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_wtask *tasks, const fsv_wres *res, fsv_wpath *paths, uint32_t task_cap,
                       const uint32_t *n_tasks_dev, uint32_t *ct, int round, bool wide_bands, const fsv_asm_params &P, bool first_pass)
 {
-    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_FAST, 0); if (first_pass) W.fast_rec.push_back(rec_); }
+    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_FAST, 0); (first_pass ? W.fast_rec : W.fast2_rec).push_back(rec_); }
     hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
                        tasks, res, task_cap, paths,
                        (uint32_t *)W.dp_list.p, ct + CT_DP, (uint32_t *)W.dp_wide.p, ct + CT_DP_WIDE, false, n_tasks_dev,
@@ -455,13 +455,13 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
     W.kt.end(ctx);
     // single-indel windows are settled without the DP (k_path_indel1); what is left goes to the sub-band kernel
     // (distance <= FSV_SB_MAXERR) or to the general one
+    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_DP, 0); (first_pass ? W.dp_rec : W.dp2_rec).push_back(rec_); }
     hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, tasks,
                        res, (const uint32_t *)W.dp_list.p, 0u, paths, (uint32_t *)W.dp_list2.p, ct + CT_DP_SB,
                        (const uint32_t *)(ct + CT_DP), (uint32_t *)W.dp_list3.p, ct + CT_DP_GEN, (uint32_t *)W.dp_list16.p, ct + CT_DP_SB16);
     FSV_HIP(ctx, hipGetLastError());
     // persistent grids: as many blocks as the device holds at once, each striding through its list, so the column scratch
     // is a fixed few hundred MB whatever the number of windows
-    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_DP, 0); if (first_pass) W.dp_rec.push_back(rec_); }
     {
         int per_cu = 0;
         FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_sb<false>, 64, 0));
@@ -517,7 +517,7 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
 {
     // where window g starts in the first pass's result, and that result as a 2-bit store behind a copy of the round's reads
     TRY(ensure(ctx, W.lb, (size_t)std::max(1u, n_gwin) * 4));
-    W.kt.begin(ctx, KN_BND, 0);
+    W.bnd_rec.push_back(W.kt.begin(ctx, KN_BND, 0));
     hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
                        (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p, (uint32_t *)W.lb.p);
     FSV_HIP(ctx, hipGetLastError());
@@ -562,7 +562,7 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
     hipLaunchKernelGGL(k_bnd_tasks, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
-    W.kt.begin(ctx, KN_BPM, 0);
+    W.bpm2_rec.push_back(W.kt.begin(ctx, KN_BPM, 0));
     // K5, once more with the doubled threshold for the tasks without an alignment, K6
     TRY(fsv_bpm_windows_dev_n(ctx, store2, (const fsv_wtask *)W.tasks2.p, task_cap, ct2 + CT_TASKS, (fsv_wres *)W.res2.p, P.k_cap));
     hipLaunchKernelGGL(k_bnd_retry, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, (fsv_wtask *)W.tasks2.p, (const fsv_wres *)W.res2.p,
@@ -577,7 +577,7 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
                    round, wide_bands, P, false));
     // the junctions' consensus, handed to the windows as patches
     const uint32_t grid_l = std::min<uint32_t>(std::max(1u, n_gwin), (uint32_t)ctx->n_cu * 16);
-    W.kt.begin(ctx, KN_BND, 0);
+    W.bndc_rec.push_back(W.kt.begin(ctx, KN_BND_CONS, 0));
     if (wide_bands) hipLaunchKernelGGL(k_bnd_consensus<FSV_EV_CAP_WIDE>, dim3(grid_l), dim3(64), 0, ctx->stream, C, A, (const fsv_wpath *)W.paths2.p, (const uint32_t *)store2,
                                        (BndPatch *)W.bnd_patch.p, (uint8_t *)W.bnd_bytes.p);
     else hipLaunchKernelGGL(k_bnd_consensus<FSV_EV_CAP>, dim3(grid_l), dim3(64), 0, ctx->stream, C, A, (const fsv_wpath *)W.paths2.p, (const uint32_t *)store2,
@@ -597,6 +597,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     memset(&W.stats, 0, sizeof(W.stats));
     W.kt.reset();
     W.chain_rec.clear(); W.bpm_rec.clear(); W.rescue_rec.clear(); W.fast_rec.clear(); W.dp_rec.clear(); W.cons_rec.clear();
+    W.bnd_rec.clear(); W.bpm2_rec.clear(); W.fast2_rec.clear(); W.dp2_rec.clear(); W.bndc_rec.clear();
     const auto t_enter = std::chrono::steady_clock::now();
 
     Batch B;
@@ -673,7 +674,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     // counts the kernels produce stay in the round's counter slot.  One synchronisation per round is left: the corrected reads'
     // lengths, which the host turns into the next round's geometry -- the round's counters ride along with it.
     auto ct_of = [&](int slot) { return (uint32_t *)W.counters.p + (size_t)slot * CT_SLOT; };
-    std::vector<uint32_t> h_ct((size_t)(P.n_rounds + 1) * CT_SLOT, 0u);
+    std::vector<uint32_t> h_ct((size_t)(2 * P.n_rounds + 2) * CT_SLOT, 0u);   // rows as on the device: rounds, final pass, the rounds' second passes
     for (int round = 0; round < P.n_rounds; round++) {
         uint32_t *ct = ct_of(round);
         TRY(upload(ctx, W.word_off, G.word_off));
@@ -807,6 +808,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         std::vector<int32_t> nlen(B.n_reads);
         FSV_HIP(ctx, hipMemcpyAsync(nlen.data(), W.new_len.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipMemcpyAsync(h_ct.data() + (size_t)round * CT_SLOT, ct, CT_SLOT * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipMemcpyAsync(h_ct.data() + (size_t)(P.n_rounds + 1 + round) * CT_SLOT, ct_of(P.n_rounds + 1 + round), CT_SLOT * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (h_ct[(size_t)round * CT_SLOT + CT_OVERFLOW]) return fsv_fail(ctx, FSV_ECAP, "internal window task buffer overflow");
         Geometry G2;
@@ -982,7 +984,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     tf.stop();
     W.h_word_off = G.word_off; W.h_len = len; W.cur_store = store; W.n_reads = B.n_reads;
     // statistics out of the counter slots (one per correction round, one for the final pass)
-    uint64_t mz_total[17] = {0};
+    uint64_t mz_total[17] = {0}, n_windows2 = 0;
     for (int sl = 0; sl <= P.n_rounds; sl++) {
         const uint32_t *c = h_ct.data() + (size_t)sl * CT_SLOT;
         mz_total[sl] = (uint64_t)c[CT_MZ_LO] | (uint64_t)c[CT_MZ_HI] << 32;
@@ -999,8 +1001,21 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         if ((size_t)sl < W.bpm_rec.size()) W.kt.recs[W.bpm_rec[sl]].bytes = nt * 212ull;
         if ((size_t)sl < W.rescue_rec.size()) W.kt.recs[W.rescue_rec[sl]].bytes += nt * 16ull;
         if ((size_t)sl < W.fast_rec.size()) W.kt.recs[W.fast_rec[sl]].bytes = nt * (16ull + 196ull) + (nt - c[CT_DP] - c[CT_DP_WIDE] - c[CT_DP_XW]) * 128ull;
-        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = ((uint64_t)c[CT_DP_SB] + c[CT_DP_SB16] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW]) * (196ull + 128ull);
+        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = ((uint64_t)c[CT_DP] + c[CT_DP_WIDE] + c[CT_DP_XW]) * (196ull + 128ull);   // k_path_indel1's windows included
         if ((size_t)sl < W.cons_rec.size()) W.kt.recs[W.cons_rec[sl]].bytes += nt * 128ull;
+        // the round's second consensus pass (its counters sit n_rounds + 1 rows further): the junction tasks are window tasks like
+        // the first pass's; k_bnd_tasks reads every first-pass task and path record and writes the junction tasks; the junctions'
+        // consensus reads their path records and writes a patch per junction
+        if ((size_t)sl < W.bnd_rec.size()) {
+            const uint32_t *c2 = h_ct.data() + (size_t)(P.n_rounds + 1 + sl) * CT_SLOT;
+            const uint64_t n2 = c2[CT_TASKS], n3 = c2[CT_B_RETRY];
+            n_windows2 += n2 + n3;
+            W.kt.recs[W.bnd_rec[sl]].bytes = nt * (sizeof(fsv_wtask) + 128ull) + n2 * sizeof(fsv_wtask);
+            if ((size_t)sl < W.bpm2_rec.size()) W.kt.recs[W.bpm2_rec[sl]].bytes = (n2 + n3) * 212ull;
+            if ((size_t)sl < W.fast2_rec.size()) W.kt.recs[W.fast2_rec[sl]].bytes = n2 * (16ull + 196ull) + (n2 - c2[CT_DP] - c2[CT_DP_WIDE] - c2[CT_DP_XW]) * 128ull;
+            if ((size_t)sl < W.dp2_rec.size()) W.kt.recs[W.dp2_rec[sl]].bytes = ((uint64_t)c2[CT_DP] + c2[CT_DP_WIDE] + c2[CT_DP_XW]) * (196ull + 128ull);
+            if ((size_t)sl < W.bndc_rec.size()) W.kt.recs[W.bndc_rec[sl]].bytes = n2 * 128ull + (uint64_t)c2[CT_B_LIST] * (sizeof(BndPatch) + 2ull * FSV_BND_HALF);
+        }
     }
     for (size_t i = 0; i < W.chain_rec.size(); i++) {
         const uint32_t *c = h_ct.data() + i * CT_SLOT;
@@ -1008,7 +1023,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     }
     for (uint32_t s2 = 0; s2 < B.n_sets; s2++) if (B.set_start[s2] < B.n_reads && B.set_start[s2 + 1] > B.set_start[s2]) W.stats.dp_columns += h_setcols[B.set_start[s2]];   // K5 windows
     // algorithmic bytes: 2-bit operands + result of every DP task, reads in once per pass, contigs out
-    W.stats.algo_bytes = W.stats.n_windows * 212ull + reads_in_bytes * (uint64_t)(P.n_rounds + 1) + used;
+    W.stats.algo_bytes = (W.stats.n_windows + n_windows2) * 212ull + reads_in_bytes * (uint64_t)(P.n_rounds + 1) + used;
     W.stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
     // resolve the per-kernel event timings
     W.stats.n_kernels = KN_COUNT;

@@ -942,8 +942,8 @@ __global__ __launch_bounds__(64) void k_chain_chunks(ChainArgs A, uint32_t n_upa
         const uint32_t rt = ptv.x + (ptv.y >> 16);
         lent_v = A.read_len[rt]; nt_v = (int)A.mz_cnt[rt]; offt_v = A.mz_off[rt];
     }
-    // q's list stays in registers while the query does not change: the kernel is bound by the L2 -> L1 traffic of the lists
-    // (13.8 KB per pair when both are loaded for every pair: ~2.9 TB/s), not by latency
+    // q's list stays in registers while the query does not change (half the list traffic; FSV_CHAIN_QR keeps the kernel at three
+    // waves per SIMD with it)
     uint32_t cur_rq = 0xffffffffu;
     int lenq = 0, nq = 0;
     uint32_t offq = 0;

@@ -249,37 +249,65 @@ __device__ __forceinline__ void bpm_run32(const uint32_t *__restrict__ store, co
     uint32_t vp = 0, vn = 0;
     int err = 0;
     const uint32_t band = (2u << (2 * k)) - 1u;
-    uint32_t xb = fetch16_x(store, t.x_word, t.x_start);
-    Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1);
-    for (int blk = 0; blk < n; blk += 16) {
-        // next block's operands are requested before this block's 16 columns are computed
-        const uint32_t xn = fetch16_x(store, t.x_word, t.x_start + blk + 16);
-        const Bases16 yn = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + 2 * k + 1 + blk + 16);
-        ylo |= (uint64_t)compress_even16(yb.bits) << (2 * k + 1);
-        yhi |= (uint64_t)compress_even16(yb.bits >> 1) << (2 * k + 1);
-        yv |= (uint64_t)(yb.valid & 0xffffu) << (2 * k + 1);
-        const int lim = min(16, n - blk);
+    // Operands arrive 64 bases (five words) at a time, a chunk ahead of the columns that use them.  Fetched a 16-base block at a
+    // time -- two words each of x and y every 16 columns -- a 64-byte sector of the store was touched sixteen times over ~3 000
+    // instructions, and with 16 000 windows in flight per XCD a quarter of those touches missed the L2 again: the counters showed
+    // 5.7 times the kernel's algorithmic bytes (profiles/r02_f_pmc_hbm_traffic.json before this change).
+    const uint32_t *const xw = store + t.x_word, *const yw = store + t.y_word;
+    const int ynw = (t.y_len + 15) >> 4, Y0 = win0 + 2 * k + 1;
+    // forward start of chunk c: the strand position itself, or (reverse strand) the mirror of the chunk's last block
+    const int yf0 = t.y_rev ? t.y_len - 64 - Y0 : Y0;
+    const uint32_t xsh = (uint32_t)(t.x_start & 15) << 1, ysh = (uint32_t)(yf0 & 15) << 1;   // the same in every chunk
+    uint32_t X[5], Y[5], XN[5] = {0, 0, 0, 0, 0}, YN[5] = {0, 0, 0, 0, 0};
+    auto load_x = [&](int cb, uint32_t (&W)[5]) {
+        const int a = (t.x_start + cb) >> 4;   // (the store keeps 4 words of slack behind the last read)
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (j < lim) {
-                const uint32_t c0 = (uint32_t)(((int32_t)(xb << (31 - 2 * j))) >> 31), c1 = (uint32_t)(((int32_t)(xb << (30 - 2 * j))) >> 31);
-                const uint32_t eq = ~((uint32_t)(ylo >> j) ^ c0) & ~((uint32_t)(yhi >> j) ^ c1) & (uint32_t)(yv >> j) & band;
-                const uint32_t x = eq | vn;
-                const uint32_t d0 = ((vp + (x & vp)) ^ vp) | x;
-                const uint32_t hn = vp & d0;
-                const uint32_t hp = vn | ~(vp | d0);
-                const uint32_t sh = d0 >> 1;
-                vn = sh & hp;
-                vp = hn | ~(sh | hp);
-                err += (int)(~d0 & 1u);
-                sink(blk, j, d0, hp, vp, vn);
+        for (int i = 0; i < 5; i++) W[i] = xw[a + i];
+    };
+    auto load_y = [&](int cb, uint32_t (&W)[5]) {
+        const int a = (t.y_rev ? yf0 - cb : yf0 + cb) >> 4;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { const int wi = a + i; W[i] = (wi >= 0 && wi < ynw) ? yw[wi] : 0u; }
+    };
+    load_x(0, X); load_y(0, Y);
+    for (int cb = 0; cb < n; cb += 64) {
+        if (cb + 64 < n) { load_x(cb + 64, XN); load_y(cb + 64, YN); }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int blk = cb + 16 * b;
+            if (blk < n) {
+                const uint32_t xb = __builtin_amdgcn_alignbit(X[b + 1], X[b], xsh);
+                // strand base j of the block = complement of forward base (block's forward start + 15 - j)
+                const uint32_t ybits = t.y_rev ? ~rev_fields2(__builtin_amdgcn_alignbit(Y[4 - b], Y[3 - b], ysh)) : __builtin_amdgcn_alignbit(Y[b + 1], Y[b], ysh);
+                const uint32_t yvalid = range_mask16(Y0 + blk, t.y_len);
+                ylo |= (uint64_t)compress_even16(ybits) << (2 * k + 1);
+                yhi |= (uint64_t)compress_even16(ybits >> 1) << (2 * k + 1);
+                yv |= (uint64_t)(yvalid & 0xffffu) << (2 * k + 1);
+                const int lim = min(16, n - blk);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (j < lim) {
+                        const uint32_t c0 = (uint32_t)(((int32_t)(xb << (31 - 2 * j))) >> 31), c1 = (uint32_t)(((int32_t)(xb << (30 - 2 * j))) >> 31);
+                        const uint32_t eq = ~((uint32_t)(ylo >> j) ^ c0) & ~((uint32_t)(yhi >> j) ^ c1) & (uint32_t)(yv >> j) & band;
+                        const uint32_t x = eq | vn;
+                        const uint32_t d0 = ((vp + (x & vp)) ^ vp) | x;
+                        const uint32_t hn = vp & d0;
+                        const uint32_t hp = vn | ~(vp | d0);
+                        const uint32_t sh = d0 >> 1;
+                        vn = sh & hp;
+                        vp = hn | ~(sh | hp);
+                        err += (int)(~d0 & 1u);
+                        sink(blk, j, d0, hp, vp, vn);
+                    }
+                }
+                // Levenshtein_distance.h:367-375 gives up at the first column where err - 2k > k; err never decreases, so looking once
+                // per block ends in the same "no match" (and the end-site scan below could not find a row <= k either)
+                if (err - 2 * k > k) return;
+                ylo >>= 16; yhi >>= 16; yv >>= 16;
             }
         }
-        // Levenshtein_distance.h:367-375 gives up at the first column where err - 2k > k; err never decreases, so looking once
-        // per block ends in the same "no match" (and the end-site scan below could not find a row <= k either)
-        if (err - 2 * k > k) return;
-        ylo >>= 16; yhi >>= 16; yv >>= 16;
-        xb = xn; yb = yn;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { X[i] = XN[i]; Y[i] = YN[i]; }
     }
     sink.flush(n);
     BpmState s; s.eq0 = s.eq1 = s.eq2 = s.eq3 = 0; s.vp = vp; s.vn = vn;
