@@ -533,8 +533,8 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
     FSV_HIP(ctx, hipMemcpyAsync(W.sr_store.p, store, (size_t)a_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
     TRY(upload(ctx, W.brel_off, brel));
     uint32_t *store2 = (uint32_t *)W.sr_store.p;
-    hipLaunchKernelGGL(k_repack, dim3(fsv_grid_for(b_words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p, (const uint16_t *)W.cwin_len.p,
-                       (const uint8_t *)W.cwin.p, (const uint32_t *)W.brel_off.p, (const int32_t *)W.new_len.p, B.n_reads, b_words, 0, store2 + a_words,
+    hipLaunchKernelGGL(k_repack, dim3(B.n_reads), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p, (const uint32_t *)W.lb.p,
+                       (const uint8_t *)W.cwin.p, (const uint32_t *)W.brel_off.p, (const int32_t *)W.new_len.p, B.n_reads, 0, store2 + a_words,
                        (const uint32_t *)W.read_dirty.p);
     FSV_HIP(ctx, hipGetLastError());
     FSV_HIP(ctx, hipMemsetAsync(store2 + a_words + b_words, 0, 32, ctx->stream));
@@ -801,8 +801,9 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         }
         if (P.second_round && B.n_pairs)
             TRY(second_pass(ctx, W, B, G, store, P, C, n_gwin, task_cap, (const uint32_t *)(ct + CT_TASKS), ct_of(P.n_rounds + 1 + round), round, wide_bands));
+        TRY(ensure(ctx, W.lb, (size_t)std::max(1u, n_gwin) * 4));
         hipLaunchKernelGGL(k_newlen, dim3(fsv_grid_for(B.n_reads, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
-                           (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p, (uint32_t *)nullptr);
+                           (const uint16_t *)W.cwin_len.p, B.n_reads, (int32_t *)W.new_len.p, (uint32_t *)W.lb.p);
         FSV_HIP(ctx, hipGetLastError());
         // the round's one synchronisation: new read lengths (+ this round's counters)
         std::vector<int32_t> nlen(B.n_reads);
@@ -819,9 +820,9 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         // k_repack needs the new offsets/lengths while the old ones are still in use by nothing else: stage them in mz_cnt/new_len
         TRY(upload(ctx, W.unpack_off, G2.word_off));
         W.kt.begin(ctx, KN_REPACK, (uint64_t)n_gwin * 384 + (uint64_t)total_words * 4);
-        hipLaunchKernelGGL(k_repack, dim3(fsv_grid_for(total_words, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
-                           (const uint16_t *)W.cwin_len.p, (const uint8_t *)W.cwin.p, (const uint32_t *)W.unpack_off.p,
-                           (const int32_t *)W.new_len.p, B.n_reads, total_words, round + 1 < P.n_rounds ? 1 : 0, (uint32_t *)dst.p);
+        hipLaunchKernelGGL(k_repack, dim3(B.n_reads), dim3(256), 0, ctx->stream, (const uint32_t *)W.gwin_off.p,
+                           (const uint32_t *)W.lb.p, (const uint8_t *)W.cwin.p, (const uint32_t *)W.unpack_off.p,
+                           (const int32_t *)W.new_len.p, B.n_reads, round + 1 < P.n_rounds ? 1 : 0, (uint32_t *)dst.p);
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);
         FSV_HIP(ctx, hipMemsetAsync((uint8_t *)dst.p + (size_t)total_words * 4, 0, 32, ctx->stream));

@@ -999,8 +999,17 @@ __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict
     fsv_wres *R = res + o.first_win;
     int align = 0;
     unsigned long long cols = 0;
-    for (int j = 0; j < o.n_win; j++) if (R[j].err >= 0) align += T[j].x_len;
-    for (int j = o.n_win - 1; j >= 0; j--) {
+    // one pass settles an overlap whose windows all matched (nearly all of them): aligned length, total length and error sum;
+    // four windows per trip so that their loads are in flight together (a lane walks ~20 windows, a memory round trip each)
+    int n_bad = 0;
+    long long tlen0 = 0, terr0 = 0;
+#pragma unroll 4
+    for (int j = 0; j < o.n_win; j++) {
+        const int e = R[j].err, xl = T[j].x_len;
+        if (e >= 0) { align += xl; terr0 += e; } else n_bad++;
+        tlen0 += xl;
+    }
+    for (int j = n_bad ? o.n_win - 1 : -1; j >= 0; j--) {
         if (R[j].err < 0) continue;
         int next = R[j].y_beg + R[j].end_site - R[j].extra_begin + 1;
         for (int k2 = j + 1; k2 < o.n_win && R[k2].err < 0; k2++) {
@@ -1020,8 +1029,12 @@ __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict
             next = r.y_beg + r.end_site - r.extra_begin + 1;
         }
     }
-    long long tlen = 0, terr = 0;
-    for (int j = 0; j < o.n_win; j++) { tlen += T[j].x_len; terr += R[j].err >= 0 ? R[j].err : T[j].x_len; }
+    long long tlen = tlen0, terr = terr0;
+    if (n_bad) {   // the rescue may have changed results and window lengths never change: only the error sum is taken again
+        terr = 0;
+#pragma unroll 4
+        for (int j = 0; j < o.n_win; j++) { const int e = R[j].err; terr += e >= 0 ? e : T[j].x_len; }
+    }
     o.align_len = align; o.err_sum = (int32_t)terr;
     o.is_match = ((long long)(o.x_e - o.x_s + 1) * 9 <= (long long)align * 10 && terr * 1000 <= tlen * accept_err_pm) ? 1 : 0;
     ovl[p] = o;
@@ -1066,20 +1079,27 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
         int mm = 0;
         const int win0 = t.y_start - t.k;
 #pragma unroll
-        for (int b = 0; b < 24; b++) {
-            if (b * 16 < n) {
-                const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + b * 16);
-                const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + start + b * 16);
-                uint32_t d = xb ^ yb.bits;
-                d = (d | (d >> 1)) & 0x55555555u;
-                // columns outside the read ('N') never match; columns past the window do not count
-                uint32_t inval = ~yb.valid & 0xffffu, spread = 0;
-                for (int j = 0; j < 16; j++) spread |= ((inval >> j) & 1u) << (2 * j);
-                d |= spread;
-                const int lim = min(16, n - b * 16);
-                if (lim < 16) d &= (1u << (2 * lim)) - 1u;
-                ops32[b] = d;
-                mm += __popc(d);
+        for (int c = 0; c < 6; c++) {
+            if (c * 64 < n) {
+                uint32_t xb4[4], yb4[4], yv4[4];
+                fetch64_x(store, t.x_word, t.x_start + c * 64, xb4);
+                fetch64(store, t.y_word, t.y_len, t.y_rev, win0 + start + c * 64, yb4, yv4);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int b = c * 4 + q;
+                    if (b * 16 < n) {
+                        uint32_t d = xb4[q] ^ yb4[q];
+                        d = (d | (d >> 1)) & 0x55555555u;
+                        // columns outside the read ('N') never match; columns past the window do not count
+                        uint32_t inval = ~yv4[q] & 0xffffu, spread = 0;
+                        for (int j = 0; j < 16; j++) spread |= ((inval >> j) & 1u) << (2 * j);
+                        d |= spread;
+                        const int lim = min(16, n - b * 16);
+                        if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+                        ops32[b] = d;
+                        mm += __popc(d);
+                    }
+                }
             }
         }
         ok = (mm == r.err);
@@ -2521,41 +2541,54 @@ __global__ void k_newlen(const uint32_t *__restrict__ gwin_off, const uint16_t *
     new_len[r] = L;
 }
 
-// One thread per output word: gathers 16 bases from the corrected windows of its read (optionally reverse-complemented).
-__global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwin_off, const uint16_t *__restrict__ cwin_len,
+// One workgroup per read, a thread per output word: 16 bases gathered from the corrected windows of the read (optionally
+// reverse-complemented).  The windows' starts in the corrected read (k_newlen's lb) are staged in LDS and searched there; with one
+// thread per word of the whole store every thread searched the read table (15 dependent loads) and then walked its read's windows
+// one dependent load at a time.
+#define FSV_RP_WIN 1024
+__global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwin_off, const uint32_t *__restrict__ lb,
                                                 const uint8_t *__restrict__ cwin, const uint32_t *__restrict__ new_word_off,
-                                                const int32_t *__restrict__ new_len, uint32_t n_reads, uint32_t total_words, int rc,
+                                                const int32_t *__restrict__ new_len, uint32_t n_reads, int rc,
                                                 uint32_t *__restrict__ out, const uint32_t *__restrict__ only = nullptr)
 {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= total_words) return;
-    uint32_t lo = 0, hi = n_reads;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (new_word_off[mid] <= w) lo = mid; else hi = mid; }
-    const uint32_t r = lo;
+    __shared__ int s_lb[FSV_RP_WIN + 1];
+    const uint32_t r = blockIdx.x;
+    if (r >= n_reads) return;
     if (only && !only[r]) return;      // the second pass only looks at reads some overlap deviates from
+    const uint32_t g0 = gwin_off[r], nw = gwin_off[r + 1] - g0;
     const int len = new_len[r];
-    const int b0 = (int)(w - new_word_off[r]) * 16;
-    uint32_t v = 0;
-    if (b0 < len) {
-        // locate the window holding the first source base, then step window by window
-        const uint32_t g0 = gwin_off[r], g1 = gwin_off[r + 1];
-        int src = rc ? len - 1 - b0 : b0;
-        uint32_t g = g0; int acc = 0;
-        while (g + 1 < g1 && acc + (int)cwin_len[g] <= src) { acc += cwin_len[g]; g++; }
-        for (int j = 0; j < 16 && b0 + j < len; j++) {
-            uint32_t code = cwin[(size_t)g * FSV_CW_STRIDE + (src - acc)];
-            if (rc) {
-                code = 3u - code;
-                src--;
-                while (src < acc && g > g0) { g--; acc -= cwin_len[g]; }
-            } else {
-                src++;
-                while (g + 1 < g1 && src - acc >= (int)cwin_len[g]) { acc += cwin_len[g]; g++; }
-            }
-            v |= code << (2 * j);
-        }
+    const uint32_t w0 = new_word_off[r], slot = new_word_off[r + 1] - w0;
+    const bool in_lds = nw <= FSV_RP_WIN;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < nw; i += 256) s_lb[i] = (int)lb[g0 + i];
+        if (threadIdx.x == 0) s_lb[nw] = len;
     }
-    out[w] = v;
+    __syncthreads();
+    auto LB = [&](uint32_t i) -> int { return in_lds ? s_lb[i] : (i < nw ? (int)lb[g0 + i] : len); };
+    for (uint32_t w = threadIdx.x; w < slot; w += 256) {
+        const int b0 = (int)w * 16;
+        uint32_t v = 0;
+        if (b0 < len && nw) {
+            int src = rc ? len - 1 - b0 : b0;
+            // the window holding the first source base: the last one that starts at or before it (empty windows share their start
+            // with the next one), then step window by window
+            uint32_t g = 0, hi = nw;
+            while (hi - g > 1) { const uint32_t mid = (g + hi) >> 1; if (LB(mid) <= src) g = mid; else hi = mid; }
+            for (int j = 0; j < 16 && b0 + j < len; j++) {
+                uint32_t code = cwin[(size_t)(g0 + g) * FSV_CW_STRIDE + (src - LB(g))];
+                if (rc) {
+                    code = 3u - code;
+                    src--;
+                    while (g > 0 && src < LB(g)) g--;
+                } else {
+                    src++;
+                    while (g + 1 < nw && src >= LB(g + 1)) g++;
+                }
+                v |= code << (2 * j);
+            }
+        }
+        out[w0 + w] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ second consensus pass

@@ -113,6 +113,48 @@ __device__ __forceinline__ uint32_t fetch16_x(const uint32_t *__restrict__ store
     return sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
 }
 
+// ---- 64 bases at a time ---------------------------------------------------------------------------------------------------
+// Five consecutive words of a read from word a (any dword alignment: global_load_dwordx4 + global_load_dword); words outside
+// [0, nwords) read as 0.  One wide load where the 16-base fetches above issue eight narrow ones.
+struct __attribute__((packed, aligned(4))) Words4 { uint32_t w[4]; };
+__device__ __forceinline__ void load_words5(const uint32_t *__restrict__ w, int a, int nwords, uint32_t (&W)[5])
+{
+    if (a >= 0 && a + 4 < nwords) {
+        const Words4 v = *reinterpret_cast<const Words4 *>(w + a);
+        W[0] = v.w[0]; W[1] = v.w[1]; W[2] = v.w[2]; W[3] = v.w[3]; W[4] = w[a + 4];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { const int wi = a + i; W[i] = (wi >= 0 && wi < nwords) ? w[wi] : 0u; }
+    }
+}
+// x windows lie inside their read and the store keeps 4 words of slack behind its last read: no bounds
+__device__ __forceinline__ void load_words5_x(const uint32_t *__restrict__ w, int a, uint32_t (&W)[5])
+{
+    const Words4 v = *reinterpret_cast<const Words4 *>(w + a);
+    W[0] = v.w[0]; W[1] = v.w[1]; W[2] = v.w[2]; W[3] = v.w[3]; W[4] = w[a + 4];
+}
+// the four 16-base blocks at strand positions p, p+16, p+32, p+48: what fetch16_x / fetch16 return for each of them
+__device__ __forceinline__ void fetch64_x(const uint32_t *__restrict__ store, uint32_t word_off, int p, uint32_t (&xb)[4])
+{
+    uint32_t W[5];
+    load_words5_x(store + word_off, p >> 4, W);
+    const uint32_t sh = (uint32_t)(p & 15) << 1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) xb[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], sh);
+}
+__device__ __forceinline__ void fetch64(const uint32_t *__restrict__ store, uint32_t word_off, int len, int rev, int p, uint32_t (&bits)[4], uint32_t (&valid)[4])
+{
+    uint32_t W[5];
+    const int f = rev ? len - 64 - p : p;   // forward start of the lowest block (reverse strand: the mirror of the last one)
+    load_words5(store + word_off, f >> 4, (len + 15) >> 4, W);
+    const uint32_t sh = (uint32_t)(f & 15) << 1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        bits[j] = rev ? ~rev_fields2(__builtin_amdgcn_alignbit(W[4 - j], W[3 - j], sh)) : __builtin_amdgcn_alignbit(W[j + 1], W[j], sh);
+        valid[j] = range_mask16(p + 16 * j, len);
+    }
+}
+
 // Hooks for K6: `sink` sees every DP column (D0 and the post-update VP/VN).
 struct BpmNoSink {
     __device__ __forceinline__ void operator()(int, uint64_t, uint64_t, uint64_t) const {}
@@ -259,16 +301,8 @@ __device__ __forceinline__ void bpm_run32(const uint32_t *__restrict__ store, co
     const int yf0 = t.y_rev ? t.y_len - 64 - Y0 : Y0;
     const uint32_t xsh = (uint32_t)(t.x_start & 15) << 1, ysh = (uint32_t)(yf0 & 15) << 1;   // the same in every chunk
     uint32_t X[5], Y[5], XN[5] = {0, 0, 0, 0, 0}, YN[5] = {0, 0, 0, 0, 0};
-    auto load_x = [&](int cb, uint32_t (&W)[5]) {
-        const int a = (t.x_start + cb) >> 4;   // (the store keeps 4 words of slack behind the last read)
-#pragma unroll
-        for (int i = 0; i < 5; i++) W[i] = xw[a + i];
-    };
-    auto load_y = [&](int cb, uint32_t (&W)[5]) {
-        const int a = (t.y_rev ? yf0 - cb : yf0 + cb) >> 4;
-#pragma unroll
-        for (int i = 0; i < 5; i++) { const int wi = a + i; W[i] = (wi >= 0 && wi < ynw) ? yw[wi] : 0u; }
-    };
+    auto load_x = [&](int cb, uint32_t (&W)[5]) { load_words5_x(xw, (t.x_start + cb) >> 4, W); };
+    auto load_y = [&](int cb, uint32_t (&W)[5]) { load_words5(yw, (t.y_rev ? yf0 - cb : yf0 + cb) >> 4, ynw, W); };
     load_x(0, X); load_y(0, Y);
     for (int cb = 0; cb < n; cb += 64) {
         if (cb + 64 < n) { load_x(cb + 64, XN); load_y(cb + 64, YN); }
