@@ -53,7 +53,7 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
        CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_DP_SB16 = 14, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -68,7 +68,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -553,7 +553,7 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
     FSV_HIP(ctx, hipMemsetAsync(W.bnd_flag.p, 0, (size_t)(n_gwin + 2) * 4, ctx->stream));
     BndArgs A;
     A.tasks = (const fsv_wtask *)W.tasks.p; A.paths = (const fsv_wpath *)W.paths.p; A.n_tasks = n_tasks_dev;
-    A.ovl_c = (const uint4 *)W.ovl_c.p; A.pair_base = (const uint32_t *)W.pair_base.p; A.set_start = (const uint32_t *)W.set_start.p; A.n_sets = B.n_sets;
+    A.ovl_c = (const uint4 *)W.ovl_c.p; A.pair_base = (const uint32_t *)W.pair_base.p; A.set_start = (const uint32_t *)W.set_start.p; A.n_sets = B.n_sets; A.pair_read = (const uint32_t *)W.pair_read.p;
     A.gwin_off = (const uint32_t *)W.gwin_off.p; A.lb = (const uint32_t *)W.lb.p; A.cwin_len = (const uint16_t *)W.cwin_len.p;
     A.cov3 = (const uint8_t *)W.cov3.p; A.read_dirty = (const uint32_t *)W.read_dirty.p;
     A.brel_off = (const uint32_t *)W.brel_off.p; A.b_base = a_words; A.thr_tab = (const uint8_t *)W.thr_tab.p;
@@ -633,8 +633,9 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     TRY(upload(ctx, W.upair_base, B.upair_base));
     if (B.n_upairs) {
         TRY(ensure(ctx, W.upair_tab, (size_t)B.n_upairs * sizeof(uint4)));
+        TRY(ensure(ctx, W.pair_read, (size_t)B.n_pairs * 4));
         hipLaunchKernelGGL(k_pair_tab, dim3((B.n_upairs + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)W.set_start.p,
-                           (const uint32_t *)W.pair_base.p, (const uint32_t *)W.upair_base.p, B.n_sets, B.n_upairs, (uint4 *)W.upair_tab.p);
+                           (const uint32_t *)W.pair_base.p, (const uint32_t *)W.upair_base.p, B.n_sets, B.n_upairs, (uint4 *)W.upair_tab.p, (uint32_t *)W.pair_read.p);
         FSV_HIP(ctx, hipGetLastError());
     }
     TRY(ensure(ctx, W.warn, (size_t)B.n_reads * 4));

@@ -374,7 +374,7 @@ struct ChainArgs {
 // The unordered pairs of every set, enumerated once per batch: block b of k_chain reads one 16-byte record instead of
 // searching the set table and inverting the triangular index (a dozen dependent global loads per block).
 __global__ void k_pair_tab(const uint32_t *__restrict__ set_start, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ upair_base,
-                           uint32_t n_sets, uint32_t n_upairs, uint4 *__restrict__ tab)
+                           uint32_t n_sets, uint32_t n_upairs, uint4 *__restrict__ tab, uint32_t *__restrict__ pair_read)
 {
     const uint32_t up = blockIdx.x * blockDim.x + threadIdx.x;
     if (up >= n_upairs) return;
@@ -388,6 +388,9 @@ __global__ void k_pair_tab(const uint32_t *__restrict__ set_start, const uint32_
     while ((uint64_t)(q + 1) * (2ull * ns - q - 2) / 2 <= idx) q++;
     const uint32_t t = q + 1 + (idx - (uint32_t)((uint64_t)q * (2ull * ns - q - 1) / 2));
     tab[up] = make_uint4(r0, q | t << 16, pair_base[s] + q * (ns - 1) + (t - 1), pair_base[s] + t * (ns - 1) + q);
+    // the query read of either ordered slot (k_bnd_tasks: one load instead of a search of the set table)
+    pair_read[pair_base[s] + q * (ns - 1) + (t - 1)] = r0 + q;
+    pair_read[pair_base[s] + t * (ns - 1) + q] = r0 + t;
 }
 
 // One wavefront per UNORDERED read pair (q < t) of a set: the chain is computed with q as the query and the overlap of t on
@@ -1142,18 +1145,26 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
 __device__ __forceinline__ int path_prefix_match(const uint32_t *__restrict__ store, const fsv_wtask &t, int win0, int off, int n)
 {
     // number of leading i with x[i] == ywin[off + i]; columns outside read y never match
-    for (int b = 0; b * 16 < n; b++) {
-        const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + b * 16);
-        const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + off + b * 16);
-        uint32_t d = xb ^ yb.bits;
-        d = (d | (d >> 1)) & 0x55555555u;
-        uint32_t inval = ~yb.valid & 0xffffu;
-        inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
-        inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
-        d |= inval;
-        const int lim = min(16, n - b * 16);
-        if (lim < 16) d &= (1u << (2 * lim)) - 1u;
-        if (d) return b * 16 + (__ffs((int)d) - 1) / 2;
+    // 64 bases a trip (the exit test once per fetch: a long matching prefix -- the usual case -- is 6 round trips, not 24)
+    for (int c = 0; c * 64 < n; c++) {
+        uint32_t xb4[4], yb4[4], yv4[4];
+        fetch64_x(store, t.x_word, t.x_start + c * 64, xb4);
+        fetch64(store, t.y_word, t.y_len, t.y_rev, win0 + off + c * 64, yb4, yv4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = c * 4 + j;
+            if (b * 16 < n) {
+                uint32_t d = xb4[j] ^ yb4[j];
+                d = (d | (d >> 1)) & 0x55555555u;
+                uint32_t inval = ~yv4[j] & 0xffffu;
+                inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
+                inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
+                d |= inval;
+                const int lim = min(16, n - b * 16);
+                if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+                if (d) return b * 16 + (__ffs((int)d) - 1) / 2;
+            }
+        }
     }
     return n;
 }
@@ -1182,19 +1193,26 @@ __global__ __launch_bounds__(256) void k_path_indel1(const uint32_t *__restrict_
         // behind the gap the end diagonal must be all matches: x[c .. n) against ywin[E - n + 1 + i]
         bool clean = c >= 1;
         if (clean) {
-            for (int b = c >> 4; b * 16 < n && clean; b++) {
-                const uint32_t xb = fetch16_x(store, t.x_word, t.x_start + b * 16);
-                const Bases16 yb = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + E - n + 1 + b * 16);
-                uint32_t d = xb ^ yb.bits;
-                d = (d | (d >> 1)) & 0x55555555u;
-                uint32_t inval = ~yb.valid & 0xffffu;
-                inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
-                inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
-                d |= inval;
-                const int lo = max(c - b * 16, 0), lim = min(16, n - b * 16);
-                if (lo > 0) d &= ~((1u << (2 * lo)) - 1u);
-                if (lim < 16) d &= (1u << (2 * lim)) - 1u;
-                if (d) clean = false;
+            for (int ch = c >> 6; ch * 64 < n && clean; ch++) {
+                uint32_t xb4[4], yb4[4], yv4[4];
+                fetch64_x(store, t.x_word, t.x_start + ch * 64, xb4);
+                fetch64(store, t.y_word, t.y_len, t.y_rev, win0 + E - n + 1 + ch * 64, yb4, yv4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int b = ch * 4 + j;
+                    if (b >= (c >> 4) && b * 16 < n) {
+                        uint32_t d = xb4[j] ^ yb4[j];
+                        d = (d | (d >> 1)) & 0x55555555u;
+                        uint32_t inval = ~yv4[j] & 0xffffu;
+                        inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
+                        inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
+                        d |= inval;
+                        const int lo = max(c - b * 16, 0), lim = min(16, n - b * 16);
+                        if (lo > 0) d &= ~((1u << (2 * lo)) - 1u);
+                        if (lim < 16) d &= (1u << (2 * lim)) - 1u;
+                        if (d) clean = false;
+                    }
+                }
             }
         }
         if (clean) {
@@ -2603,7 +2621,7 @@ __global__ __launch_bounds__(256) void k_repack(const uint32_t *__restrict__ gwi
 #define FSV_BND_SIDE 25
 struct BndArgs {
     const fsv_wtask *tasks; const fsv_wpath *paths; const uint32_t *n_tasks;     // the round's window tasks and their paths
-    const uint4 *ovl_c; const uint32_t *pair_base, *set_start; uint32_t n_sets;
+    const uint4 *ovl_c; const uint32_t *pair_base, *set_start; uint32_t n_sets; const uint32_t *pair_read;   // pair slot -> its query read
     const uint32_t *gwin_off, *lb; const uint16_t *cwin_len; const uint8_t *cov3; const uint32_t *read_dirty;
     const uint32_t *brel_off; uint32_t b_base;      // first-pass result of read r in the second-pass store: word b_base + brel_off[r]
     const uint8_t *thr_tab;
@@ -2620,10 +2638,7 @@ __global__ __launch_bounds__(256) void k_bnd_tasks(BndArgs A)
     const fsv_wtask t = A.tasks[ti];
     if (t.x_start % FSV_WINDOW != 0 || t.x_start == 0) return;    // only an overlap that covers the window's first base takes part
     const uint32_t p = t.ovl;
-    uint32_t lo = 0, hi = A.n_sets;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.pair_base[mid] <= p) lo = mid; else hi = mid; }
-    const uint32_t r0 = A.set_start[lo], ns = A.set_start[lo + 1] - r0;
-    const uint32_t r = r0 + (p - A.pair_base[lo]) / (ns - 1);
+    const uint32_t r = A.pair_read[p];
     if (!A.read_dirty[r]) return;     // every overlap matches the read base for base: every junction alignment has distance 0
     const uint32_t gw = A.gwin_off[r] + (uint32_t)(t.x_start / FSV_WINDOW);
     if (!A.cov3[gw]) return;
@@ -2640,15 +2655,26 @@ __global__ __launch_bounds__(256) void k_bnd_tasks(BndArgs A)
     // ending on that diagonal, K6 an all-match path): such an alignment only counts towards the junction's coverage
     const uint32_t xw2 = A.b_base + A.brel_off[r];
     if (y_start + blen <= t.y_len) {
-        bool same = true;
-        for (int b = 0; b < blen && same; b += 16) {
-            const uint32_t xb = fetch16_x(A.store2, xw2, cws + b);
-            const Bases16 yb = fetch16(A.store2, t.y_word, t.y_len, t.y_rev, y_start + b);
-            uint32_t d = xb ^ yb.bits;
-            const int lim = min(16, blen - b);
-            if (lim < 16) d &= (1u << (2 * lim)) - 1u;
-            same = d == 0u;
+        // (all six 64-base fetches of either read in flight: with an early exit per 16 bases an exact alignment -- the common case --
+        // paid 24 dependent round trips)
+        uint32_t acc = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            if (c * 64 < blen) {
+                uint32_t xb[4], yb[4], yv[4];
+                fetch64_x(A.store2, xw2, cws + c * 64, xb);
+                fetch64(A.store2, t.y_word, t.y_len, t.y_rev, y_start + c * 64, yb, yv);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int b = c * 64 + j * 16;
+                    if (b < blen) {
+                        const int lim = min(16, blen - b);
+                        acc |= (xb[j] ^ yb[j]) & (lim < 16 ? (1u << (2 * lim)) - 1u : 0xffffffffu);
+                    }
+                }
+            }
         }
+        const bool same = acc == 0u;
         if (same) { A.idx2[ti] = -2; atomicAdd(&A.bnd_flag[gw], 2u); return; }
     }
     const uint32_t slot = atomicAdd(A.n_tasks2, 1u);
