@@ -2637,17 +2637,19 @@ __global__ __launch_bounds__(256) void k_bnd_tasks(BndArgs A)
     A.idx2[ti] = -1;
     const fsv_wtask t = A.tasks[ti];
     if (t.x_start % FSV_WINDOW != 0 || t.x_start == 0) return;    // only an overlap that covers the window's first base takes part
+    // the tests are grouped so that the loads they need are in flight together: one test per load is one memory round trip per test
     const uint32_t p = t.ovl;
     const uint32_t r = A.pair_read[p];
-    if (!A.read_dirty[r]) return;     // every overlap matches the read base for base: every junction alignment has distance 0
-    const uint32_t gw = A.gwin_off[r] + (uint32_t)(t.x_start / FSV_WINDOW);
-    if (!A.cov3[gw]) return;
-    const int LB = (int)A.lb[gw];
-    if (LB == 0) return;
-    if (!(A.ovl_c[p].z >> 31)) return;
+    const uint4 oc = A.ovl_c[p];
     const uint4 h0 = *reinterpret_cast<const uint4 *>(A.paths + ti);
-    if ((h0.w & 0xffu) != 1u) return;
-    const int len_now = LB + (int)A.cwin_len[gw];
+    const uint32_t dirty = A.read_dirty[r], gwo = A.gwin_off[r];
+    // a clean read: every overlap matches it base for base, every junction alignment has distance 0
+    if (!(dirty && (oc.z >> 31) && (h0.w & 0xffu) == 1u)) return;
+    const uint32_t gw = gwo + (uint32_t)(t.x_start / FSV_WINDOW);
+    const uint32_t cov = A.cov3[gw], cwl = A.cwin_len[gw];
+    const int LB = (int)A.lb[gw];
+    if (!cov || LB == 0) return;
+    const int len_now = LB + (int)cwl;
     const int cws = max(0, LB - FSV_BND_HALF), cwe = min(len_now - 1, LB + FSV_BND_HALF - 1), blen = cwe - cws + 1;
     const int y_start = (int)h0.x - FSV_BND_HALF;
     if (y_start < 0 || blen < 1) return;
