@@ -1944,6 +1944,8 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     __shared__ uint32_t s_fl[FSV_WINDOW + 1];      // the same for mismatch runs: per column, 8 bits per base
     __shared__ uint16_t s_inslist[FSV_INSLIST];    // columns whose inserted strings disagree
     __shared__ uint32_t s_nins;
+    __shared__ uint16_t s_devlist[FSV_WINDOW + 1]; // columns some vote deviates at
+    __shared__ uint32_t s_ndev;
     static_assert(sizeof(DagLds) <= sizeof(uint32_t) * 64 * 27, "the DAG scratch lives in the path buffer between the tally and the decisions");
     DagLds &s_dag = *reinterpret_cast<DagLds *>(&s_path[0][0]);
     __shared__ uint32_t s_xraw[28];                // raw store words covering x[gs-16 .. gs+glen+16)
@@ -1970,7 +1972,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
     for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_evhead[i] = 0xffffu;
     for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_fl[i] = 0;
-    if (lane == 0) { s_evn = 0; s_cover = 0; s_anydev = 0; s_nins = 0; }
+    if (lane == 0) { s_evn = 0; s_cover = 0; s_anydev = 0; s_nins = 0; s_ndev = 0; }
     __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
 #define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
@@ -2091,14 +2093,27 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     const bool verbatim = s_cover < 3u || s_anydev == 0u;
     if (A.cov3 && lane == 0) A.cov3[gw] = s_cover >= 3u ? 1 : 0;
     if (s_evn > (uint32_t)EVC && lane == 0) atomicOr(&A.warn[r], (uint32_t)FSV_W_INS_EVENTS);
+    // Columns nobody deviates at (no vote in s_cnt: nine in ten even in the first round) keep the backbone's base: poa_decide then
+    // sees one edge with all the weight.  The others are listed and decided a lane each -- walked in place, lane = six consecutive
+    // columns, nearly every trip had some lane with a deviating column and the whole wave went through the decision six times.
     int arrived = before, farrived = fbefore;
     bool differs = false, site = false;
     for (int c = c0; c < c1; c++) {
         arrived += COV_LO(s_cov[c]);
         farrived += COV_HI(s_cov[c]);
+        s_out[c][0] = 1; s_out[c][1] = (uint8_t)XB(gs + c);
+        if (!verbatim && (s_cnt[c][0] | s_cnt[c][1] | s_cnt[c][2]) != 0u) {
+            s_cov[c] = (int32_t)(((uint32_t)arrived & 0xffffu) | ((uint32_t)farrived << 16));     // the lane owns its columns: the difference array is done with
+            s_devlist[atomicAdd(&s_ndev, 1u)] = (uint16_t)c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = lane; e < s_ndev; e += 64) {
+        const int c = (int)s_devlist[e];
+        arrived = (int)(int16_t)((uint32_t)s_cov[c] & 0xffffu); farrived = (int)(int16_t)((uint32_t)s_cov[c] >> 16);
         const uint32_t own = XB(gs + c);
         uint8_t nb = 0;
-        if (MODE == 1 && !verbatim) {
+        if (MODE == 1) {
             // split_sub_list (Correct.cpp:5804) on the same tallies, as in k_snp_sites
             int oa[4], occ1 = 0;
 #pragma unroll
@@ -2114,8 +2129,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
                 if (ok && (double)(occ0 + 1 + mx) / (double)(arrived + 1) >= 0.95 && (double)mx / (double)(arrived + 1 - (occ0 + 1)) >= 0.70) site = true;
             }
         }
-        if (verbatim) { s_out[c][1] = (uint8_t)own; nb = 1; }
-        else {
+        {
             // the node in front of column c (poa_decide); the homopolymer relief looks at the PREVIOUS backbone base
             const int q = gs + c - 1;
             const bool homo = c > 0 && ((q > 0 && XB(q - 1) == XB(q)) || (q + 1 < xlen && XB(q + 1) == XB(q)));
@@ -2138,7 +2152,6 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
             poa_decide(W, Ifl, dl, ni, mi, ikey, (int)own, homo, &s_out[c][0]);
             nb = s_out[c][0];
         }
-        s_out[c][0] = nb;
         if (nb != 1 || s_out[c][1] != (uint8_t)own) differs = true;
     }
     if (differs && A.changed) A.changed[r] = 1u;
@@ -2724,7 +2737,8 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
     __shared__ uint32_t s_evhead[FSV_WINDOW + 1];
     __shared__ uint16_t s_off[FSV_WINDOW + 2];      // where a column's output starts in the consensus
     __shared__ uint8_t s_own[FSV_WINDOW + 1];       // the column keeps a base (its own or another one)
-    __shared__ uint32_t s_evn, s_cover, s_terr, s_nins;
+    __shared__ uint32_t s_evn, s_cover, s_terr, s_nins, s_ndev;
+    __shared__ uint16_t s_devlist[2 * FSV_BND_HALF + 2];   // columns some vote deviates at (as in consensus_window)
     __shared__ uint32_t s_fl[FSV_WINDOW + 1];      // votes of the mismatch runs that follow an insertion: 8 bits per base
     __shared__ uint16_t s_inslist[FSV_INSLIST];
     static_assert(sizeof(DagLds) <= sizeof(uint32_t) * 64 * 27, "the DAG scratch lives in the path buffer between the tally and the decisions");
@@ -2750,7 +2764,7 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
         for (int i = lane; i < FSV_WINDOW + 2; i += 64) s_cov[i] = 0;
         for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_evhead[i] = 0xffffu;
         for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_fl[i] = 0;
-        if (lane == 0) { s_evn = 0; s_cover = 0; s_terr = 0; s_nins = 0; }
+        if (lane == 0) { s_evn = 0; s_cover = 0; s_terr = 0; s_nins = 0; s_ndev = 0; }
         __syncthreads();
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
 #define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
@@ -2844,10 +2858,21 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
         __syncthreads();
         uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]);
         bool differs = false;
-        int mine = 0;
+        // columns without a deviating vote keep the backbone's base; the others are listed and decided a lane each (consensus_window)
         for (int c = c0; c < c1; c++) {
             arrived += COV_LO(s_cov[c]);
             farrived += COV_HI(s_cov[c]);
+            s_out[c][0] = 1; s_out[c][1] = (uint8_t)XB(cws + c);
+            s_own[c] = 1;
+            if ((s_cnt[c][0] | s_cnt[c][1] | s_cnt[c][2]) != 0u) {
+                s_cov[c] = (int32_t)(((uint32_t)arrived & 0xffffu) | ((uint32_t)farrived << 16));
+                s_devlist[atomicAdd(&s_ndev, 1u)] = (uint16_t)c;
+            }
+        }
+        __syncthreads();
+        for (uint32_t e = lane; e < s_ndev; e += 64) {
+            const int c = (int)s_devlist[e];
+            arrived = (int)(int16_t)((uint32_t)s_cov[c] & 0xffffu); farrived = (int)(int16_t)((uint32_t)s_cov[c] >> 16);
             const int p = cws + c;
             const uint32_t own = XB(p);
             const int q = p - 1;
@@ -2869,11 +2894,12 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
                 }
             }
             const bool kept = poa_decide(W, Ifl, dl, ni, mi, ikey, (int)own, homo, &s_out[c][0]);
-            const uint8_t nb = s_out[c][0];
             s_own[c] = kept;
-            mine += nb;
-            if (nb != 1 || s_out[c][1] != (uint8_t)own) differs = true;
+            if (s_out[c][0] != 1 || s_out[c][1] != (uint8_t)own) differs = true;
         }
+        __syncthreads();
+        int mine = 0;
+        for (int c = c0; c < c1; c++) mine += s_out[c][0];
         s_scan[lane] = (uint32_t)mine;
         __syncthreads();
         if (__ballot(differs) == 0ull) continue;          // the new cigar is one run of matches
