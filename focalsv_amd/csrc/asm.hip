@@ -232,7 +232,7 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     }
     // algorithmic bytes of the launch are filled in when the batch ends (they need the counts this launch leaves on the device)
     W.chain_rec.push_back(W.kt.begin(ctx, KN_CHAIN, 0));
-    const uint32_t n_chunks = (B.n_upairs + FSV_CHAIN_CH - 1) / FSV_CHAIN_CH;
+    const uint32_t n_chunks = ((B.n_upairs + FSV_CHAIN_CH - 1) / FSV_CHAIN_CH + 7u) & ~7u;   // (xcd_block: a multiple of eight blocks)
     if (short_reads) hipLaunchKernelGGL(k_chain_chunks<true>, dim3(n_chunks), dim3(64), chain_lds_bytes(true, A.amax), ctx->stream, A, B.n_upairs);
     else hipLaunchKernelGGL(k_chain_chunks<false>, dim3(n_chunks), dim3(64), chain_lds_bytes(false, A.amax), ctx->stream, A, B.n_upairs);
     FSV_HIP(ctx, hipGetLastError());
@@ -392,7 +392,7 @@ extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_w
         FSV_HIP(ctx, hipMemsetAsync(d_paths.p, 0, (size_t)n_tasks * sizeof(fsv_wpath), ctx->stream));
         // the same launches as a correction round of fsv_assemble_batch (device-side list lengths, no host round trip in between)
         TRY(fsv_bpm_windows_dev_n(ctx, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, n_tasks, nullptr, (fsv_wres *)d_res.p, k_cap));
-        hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_ovl *)d_ovl.p,
+        hipLaunchKernelGGL(k_path_fast, dim3((fsv_grid_for(n_tasks, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_ovl *)d_ovl.p,
                            (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p, n_tasks, (fsv_wpath *)d_paths.p, (uint32_t *)d_list.p,
                            ct + CT_DP, (uint32_t *)d_wide.p, ct + CT_DP_WIDE, true, (const uint32_t *)nullptr, (uint32_t *)d_xwide.p, ct + CT_DP_XW);
         FSV_HIP(ctx, hipGetLastError());
@@ -447,7 +447,7 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
                       const uint32_t *n_tasks_dev, uint32_t *ct, int round, bool wide_bands, const fsv_asm_params &P, bool first_pass)
 {
     { const size_t rec_ = W.kt.begin(ctx, KN_PATH_FAST, 0); (first_pass ? W.fast_rec : W.fast2_rec).push_back(rec_); }
-    hipLaunchKernelGGL(k_path_fast, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
+    hipLaunchKernelGGL(k_path_fast, dim3((fsv_grid_for(task_cap, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
                        tasks, res, task_cap, paths,
                        (uint32_t *)W.dp_list.p, ct + CT_DP, (uint32_t *)W.dp_wide.p, ct + CT_DP_WIDE, false, n_tasks_dev,
                        (uint32_t *)W.dp_xwide.p, ct + CT_DP_XW);
@@ -559,7 +559,7 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
     A.brel_off = (const uint32_t *)W.brel_off.p; A.b_base = a_words; A.thr_tab = (const uint8_t *)W.thr_tab.p;
     A.tasks2 = (fsv_wtask *)W.tasks2.p; A.idx2 = (int32_t *)W.idx2.p; A.n_tasks2 = ct2 + CT_TASKS;
     A.bnd_flag = (uint32_t *)W.bnd_flag.p; A.bnd_list = (uint32_t *)W.bnd_list.p; A.n_bnd = ct2 + CT_B_LIST; A.store2 = store2;
-    hipLaunchKernelGGL(k_bnd_tasks, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_bnd_tasks, dim3((fsv_grid_for(task_cap, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, A);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
     W.bpm2_rec.push_back(W.kt.begin(ctx, KN_BPM, 0));
@@ -780,11 +780,11 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         // through that, out of what the final pass accepts as verified), and the reads that lost an overlap get their windows redone
         W.cons_rec.push_back(W.kt.begin(ctx, KN_CONSENSUS, (uint64_t)n_gwin * (96 + 448)));
         if (wide_bands) {
-            if (partition) hipLaunchKernelGGL((k_consensus<FSV_EV_CAP_WIDE, 1>), dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, SL);
-            else hipLaunchKernelGGL((k_consensus<FSV_EV_CAP_WIDE, 0>), dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, SL);
+            if (partition) hipLaunchKernelGGL((k_consensus<FSV_EV_CAP_WIDE, 1>), dim3((n_gwin + 7u) & ~7u), dim3(64), 0, ctx->stream, C, n_gwin, SL);
+            else hipLaunchKernelGGL((k_consensus<FSV_EV_CAP_WIDE, 0>), dim3((n_gwin + 7u) & ~7u), dim3(64), 0, ctx->stream, C, n_gwin, SL);
         } else {
-            if (partition) hipLaunchKernelGGL((k_consensus<FSV_EV_CAP, 1>), dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, SL);
-            else hipLaunchKernelGGL((k_consensus<FSV_EV_CAP, 0>), dim3(n_gwin), dim3(64), 0, ctx->stream, C, n_gwin, SL);
+            if (partition) hipLaunchKernelGGL((k_consensus<FSV_EV_CAP, 1>), dim3((n_gwin + 7u) & ~7u), dim3(64), 0, ctx->stream, C, n_gwin, SL);
+            else hipLaunchKernelGGL((k_consensus<FSV_EV_CAP, 0>), dim3((n_gwin + 7u) & ~7u), dim3(64), 0, ctx->stream, C, n_gwin, SL);
         }
         FSV_HIP(ctx, hipGetLastError());
         W.kt.end(ctx);

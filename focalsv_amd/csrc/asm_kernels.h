@@ -934,8 +934,9 @@ __global__ __launch_bounds__(64) void k_chain_chunks(ChainArgs A, uint32_t n_upa
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int lane = threadIdx.x;
-    const uint32_t first = blockIdx.x * FSV_CHAIN_CH;
-    if (first >= n_upairs) return;
+    uint32_t chunk;
+    if (!xcd_block((n_upairs + FSV_CHAIN_CH - 1) / FSV_CHAIN_CH, chunk)) return;
+    const uint32_t first = chunk * FSV_CHAIN_CH;
     const int np = (int)min((uint32_t)FSV_CHAIN_CH, n_upairs - first);
     uint4 ptv = make_uint4(0, 0, 0, 0);
     int lent_v = 0, nt_v = 0;
@@ -1064,8 +1065,10 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ dp_xwide = nullptr,
                                                    uint32_t *__restrict__ dp_count_xwide = nullptr)
 {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_dev) n_tasks = *n_dev;   // the grid covers the task bound; the count stays on the device (no host round trip)
+    uint32_t blk;
+    if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
+    const uint32_t tid = blk * blockDim.x + threadIdx.x;
     if (tid >= n_tasks) return;
     const fsv_wtask t = tasks[tid];
     const fsv_wres r = res[tid];
@@ -2184,7 +2187,8 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
 template <int EVC, int MODE>
 __global__ __launch_bounds__(64) void k_consensus(ConsArgs A, uint32_t n_gwin, SiteLists L)
 {
-    if (blockIdx.x < n_gwin) consensus_window<EVC, MODE>(A, blockIdx.x, L);
+    uint32_t gw;
+    if (xcd_block(n_gwin, gw)) consensus_window<EVC, MODE>(A, gw, L);
 }
 
 // the redo: a fixed grid walks the list k_hap_partition left
@@ -2645,8 +2649,11 @@ struct BndArgs {
 
 __global__ __launch_bounds__(256) void k_bnd_tasks(BndArgs A)
 {
-    const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ti >= *A.n_tasks) return;
+    const uint32_t n_tasks = *A.n_tasks;
+    uint32_t blk;
+    if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
+    const uint32_t ti = blk * blockDim.x + threadIdx.x;
+    if (ti >= n_tasks) return;
     A.idx2[ti] = -1;
     const fsv_wtask t = A.tasks[ti];
     if (t.x_start % FSV_WINDOW != 0 || t.x_start == 0) return;    // only an overlap that covers the window's first base takes part

@@ -113,6 +113,18 @@ __device__ __forceinline__ uint32_t fetch16_x(const uint32_t *__restrict__ store
     return sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
 }
 
+// blockIdx -> work item.  The hardware deals consecutive workgroups to the eight XCDs in turn; taken as they come, the blocks that
+// work on one read set -- consecutive items of a list -- land on all eight, and every XCD's 4 MB L2 has to hold the operands of all
+// the sets in flight (k_chain fetched its lists five times over).  Here XCD x walks the x-th contiguous eighth of the n_blocks
+// items.  The grid must cover 8 * ceil(n_blocks / 8) blocks; false: no item for this block.
+__device__ __forceinline__ bool xcd_block(uint32_t n_blocks, uint32_t &item)
+{
+    const uint32_t per = (n_blocks + 7u) >> 3, b = blockIdx.x;
+    if ((b >> 3) >= per) return false;
+    item = (b & 7u) * per + (b >> 3);
+    return item < n_blocks;
+}
+
 // ---- 64 bases at a time ---------------------------------------------------------------------------------------------------
 // Five consecutive words of a read from word a (any dword alignment: global_load_dwordx4 + global_load_dword); words outside
 // [0, nwords) read as 0.  One wide load where the 16-base fetches above issue eight narrow ones.

@@ -22,8 +22,10 @@ namespace {
 __global__ __launch_bounds__(256) void k5_bpm_kernel(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
                                                      uint32_t n_tasks, fsv_wres *__restrict__ res, const uint32_t *__restrict__ n_dev)
 {
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_dev) n_tasks = *n_dev;   // the grid covers the task bound; the count stays on the device
+    uint32_t blk;
+    if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
+    const uint32_t tid = blk * blockDim.x + threadIdx.x;
     if (tid >= n_tasks) return;
     const fsv_wtask t = tasks[tid];
     fsv_wres r;
@@ -99,7 +101,7 @@ int fsv_bpm_windows_dev_n(fsv_ctx *ctx, const uint32_t *store_dev, const fsv_wta
         hipLaunchKernelGGL(k5_bpm_wide_kernel, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store_dev, tasks_dev,
                            n_tasks, res_dev, n_dev, k_cap);
     else
-    hipLaunchKernelGGL(k5_bpm_kernel, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, store_dev, tasks_dev,
+    hipLaunchKernelGGL(k5_bpm_kernel, dim3((fsv_grid_for(n_tasks, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, store_dev, tasks_dev,
                        n_tasks, res_dev, n_dev);
     FSV_HIP(ctx, hipGetLastError());
     return FSV_OK;
