@@ -269,3 +269,55 @@ def test_repeat_rich_sets_equal_hifiasm(ctx, golden_dir):
         corrected = reads[k:k + len(sets[si])]
         k += len(sets[si])
         check_repeat_set(g, [c for c, cs in zip(contigs, cset) if cs == si], corrected, r.haps[0])
+
+
+def test_reads_of_65536_bases_and_more_match_oracle(ctx):
+    """a batch with a read of 65 536 bases or more leaves the compact k_chain layout (16-bit positions) for the long one, and its
+    long reads have more minimizers than the chain kernel keeps in registers (768): two sets of 66-90 kb reads over a 260 kb
+    stretch, one with a short-read set beside it in the same batch; corrected reads and contigs against oracle/asm.c.  The
+    sequence is rich in homopolymer runs so that no pair has more anchors than the chaining tile holds (1 024: a 35 kb overlap of
+    random sequence -- FSV_W_ANCHOR_TRUNC, which the test asserts is not raised)"""
+    rng = np.random.default_rng(77)
+    # homopolymer runs of 3.5 bases on average: a 75 kb read then has ~850 minimizers, a 60 kb overlap ~650 anchors
+    genome = np.repeat(rng.integers(0, 4, 70000).astype(np.uint8), 1 + rng.poisson(2.5, 70000))[:210000]
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def noisy(seq, r):
+        # 0.07 % deleted, 0.07 % with an inserted base in front, 0.07 % substituted
+        u = r.random(len(seq))
+        keep = u >= 0.0007
+        sub = (u >= 0.0014) & (u < 0.0021)
+        out = seq.copy()
+        out[sub] = (out[sub] + 1 + r.integers(0, 3, int(sub.sum()))) % 4
+        ins = np.flatnonzero((u >= 0.0007) & (u < 0.0014))
+        out = np.insert(out[keep], np.searchsorted(np.flatnonzero(keep), ins), r.integers(0, 4, len(ins)).astype(np.uint8))
+        return acgt[out].tobytes()
+
+    def long_set(seed, n):
+        r = np.random.default_rng(seed)
+        reads = []
+        for i in range(n):
+            ln = int(r.integers(66000, 80000))
+            st = int(r.integers(0, len(genome) - ln))
+            s = noisy(genome[st:st + ln], r)
+            reads.append(synth.revcomp(s) if r.random() < 0.5 else s)
+        return reads
+
+    short = synth.make_region(905, width=20000, depth_per_hap=12.0).reads[0]
+    sets = [long_set(1, 16), short, long_set(2, 12)]
+    assert max(len(x) for x in sets[0]) >= 65536
+    for rounds in (1, 3):
+        p = ctx.default_asm_params()
+        p.n_rounds = rounds
+        contigs, cset, status, reads, b = gpu_assemble(ctx, sets, p)
+        assert not any(int(x) & (_lib.W_ANCHOR_TRUNC | _lib.W_MZ_TRUNC) for x in status), list(status)
+        po = O.default_params()
+        po.n_rounds = rounds
+        k = 0
+        for si, s in enumerate(sets):
+            oc, ocorr = O.assemble(s, po)
+            for j in range(len(s)):
+                assert reads[k + j] == ocorr[j], (rounds, si, j, len(reads[k + j]), len(ocorr[j]))
+            k += len(s)
+            mine = [c for c, cs in zip(contigs, cset) if cs == si]
+            assert mine == oc, (rounds, si, [len(c) for c in mine], [len(c) for c in oc])
