@@ -50,10 +50,10 @@ struct Span {
 // per-round block of device counters (one 64-byte slot per correction round + one for the final pass, zeroed once per batch and
 // read back with the round's one synchronisation or at the end): u32 indices
 enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4, CT_COLS_HI = 5, CT_DP_WIDE = 6, CT_DP_SB = 7, CT_DP_GEN = 8, CT_DP_XW = 9,
-       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_DP_SB16 = 14, CT_SLOT = 16 };
+       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_DP_SB16 = 14, CT_WIDE = 15, CT_SLOT = 16 };
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -68,7 +68,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -224,6 +224,12 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     // 65 536 bases), so the tile no longer has to be cut to the batch's longest list to keep several pairs per CU
     A.upair_tab = (const uint4 *)W.upair_tab.p; A.pair_list = nullptr; A.n_list_dev = nullptr;
     A.amax = wide_anchors ? FSV_AMAX_WIDE : FSV_AMAX;
+    // a pair whose lists both exceed the tile is set aside and chained with the large tile afterwards (reads above ~25 kb)
+    A.wide_list = nullptr; A.n_wide = nullptr;
+    if (!wide_anchors) {
+        TRY(ensure(ctx, W.wide_list, (size_t)B.n_upairs * 4 + 16));
+        A.wide_list = (uint32_t *)W.wide_list.p; A.n_wide = ct + CT_WIDE;
+    }
     A.stamps = nullptr;
     if (getenv("FSV_CHAIN_STAMPS")) {   // diagnostic: where a k_chain wave spends its cycles (never in a measured run)
         TRY(ensure(ctx, W.tmp, 128));
@@ -236,6 +242,14 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     if (short_reads) hipLaunchKernelGGL(k_chain_chunks<true>, dim3(n_chunks), dim3(64), chain_lds_bytes(true, A.amax), ctx->stream, A, B.n_upairs);
     else hipLaunchKernelGGL(k_chain_chunks<false>, dim3(n_chunks), dim3(64), chain_lds_bytes(false, A.amax), ctx->stream, A, B.n_upairs);
     FSV_HIP(ctx, hipGetLastError());
+    if (A.wide_list) {
+        ChainArgs AW = A;
+        AW.amax = short_reads ? FSV_AMAX_WIDE : FSV_AMAX_WIDE_LONG; AW.stamps = nullptr;   // (the kernel walks AW.wide_list)
+        const uint32_t gridw = std::min<uint32_t>(B.n_upairs, 2u * (uint32_t)ctx->n_cu);
+        if (short_reads) hipLaunchKernelGGL(k_chain_wide_list<true>, dim3(gridw), dim3(64), chain_lds_bytes(true, AW.amax), ctx->stream, AW);
+        else hipLaunchKernelGGL(k_chain_wide_list<false>, dim3(gridw), dim3(64), chain_lds_bytes(false, AW.amax), ctx->stream, AW);
+        FSV_HIP(ctx, hipGetLastError());
+    }
     W.kt.end(ctx);
     if (A.stamps) {
         unsigned long long h[16];
@@ -881,11 +895,20 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             FSV_HIP(ctx, hipGetLastError());
             ChainArgs A2 = W.last_chain;
             A2.bw = P.bw_rechain; A2.emit_tasks = 0; A2.pair_list = (const uint32_t *)W.inexact_list.p; A2.n_list_dev = n_list_dev;
+            if (A2.wide_list) FSV_HIP(ctx, hipMemsetAsync(A2.n_wide, 0, 4, ctx->stream));   // (the final pass's own wide pairs are done)
             // timed like the other k_chain launches (a profiler counts it too)
             W.kt.begin(ctx, KN_CHAIN, 0);
             if (short_reads) hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A2.amax), ctx->stream, A2);
             else hipLaunchKernelGGL(k_chain<false>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(false, A2.amax), ctx->stream, A2);
             FSV_HIP(ctx, hipGetLastError());
+            if (A2.wide_list) {
+                ChainArgs AW = A2;
+                AW.amax = short_reads ? FSV_AMAX_WIDE : FSV_AMAX_WIDE_LONG; AW.pair_list = nullptr; AW.n_list_dev = nullptr;
+                const uint32_t gridw = std::min<uint32_t>(B.n_upairs, 2u * (uint32_t)ctx->n_cu);
+                if (short_reads) hipLaunchKernelGGL(k_chain_wide_list<true>, dim3(gridw), dim3(64), chain_lds_bytes(true, AW.amax), ctx->stream, AW);
+                else hipLaunchKernelGGL(k_chain_wide_list<false>, dim3(gridw), dim3(64), chain_lds_bytes(false, AW.amax), ctx->stream, AW);
+                FSV_HIP(ctx, hipGetLastError());
+            }
             W.kt.end(ctx);
             hipLaunchKernelGGL(k_accept_inexact, dim3(fsv_grid_for(2ull * B.n_upairs, 256)), dim3(256), 0, ctx->stream, (const uint4 *)W.upair_tab.p,
                                (const uint32_t *)W.inexact_list.p, 0u, (const fsv_ovl *)W.ovl.p, (const fsv_ovl *)W.ovl_prev.p,

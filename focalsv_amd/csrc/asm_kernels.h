@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #define FSV_AMAX       1024  // anchors per read pair held in LDS
+#define FSV_AMAX_WIDE_LONG 2560  // ... the same second pass in the long layout (24 B per anchor: 60 KB, a workgroup's LDS limit without opting in to more)
 #define FSV_AMAX_WIDE  4096  // ... for ONT-profile batches: k = 15 minimizers every ~8 bases, corrected reads share all of them (a 25 kb overlap: ~3 000)
 #define FSV_UQ_MAX     4096  // minimizers per read sorted in LDS
 #define FSV_PATH_CAP    416  // ops per window path: x_len (<= 375) + y-only ops (<= k <= 31)
@@ -369,6 +370,8 @@ struct ChainArgs {
     uint32_t n_sets;
     int32_t k_score, min_anchors, min_ovlp, bw, emit_tasks;
     unsigned long long *stamps;  // diagnostic (FSV_CHAIN_STAMPS=1): shader cycles per phase summed over the waves, else nullptr
+    uint32_t *wide_list, *n_wide; // pairs whose two lists both have more than amax entries (only they can have more than amax anchors) are
+                                  // set aside here and chained by k_chain_wide_list with the large tile; nullptr: chain every pair here
 };
 
 // The unordered pairs of every set, enumerated once per batch: block b of k_chain reads one 16-byte record instead of
@@ -918,9 +921,33 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A)
     const int lenq = A.read_len[rq], lent = A.read_len[rt];
     const int nq = (int)A.mz_cnt[rq], nt = (int)A.mz_cnt[rt];
     const fsv_mz *mq = A.mz + A.mz_off[rq] + nq, *mt = A.mz + A.mz_off[rt]; // q: position-sorted copy, t: hash-sorted
+    if (A.wide_list && min(nq, nt) > A.amax) {
+        if (threadIdx.x == 0) A.wide_list[atomicAdd(A.n_wide, 1u)] = A.pair_list ? A.pair_list[blockIdx.x] : blockIdx.x;
+        return;
+    }
     uint4 qa[FSV_CHAIN_QR];
     chain_load_query<SHORT>(qa, mq, nq);
     chain_pair<SHORT>(A, s_raw, pt, lenq, lent, nq, nt, mq, mt, qa);
+}
+
+// the pairs set aside by the kernels above (long reads: more than 1 024 minimizers in both lists), with the large tile; a small
+// fixed grid walks the list, which is empty for reads below ~25 kb
+template <bool SHORT>
+__global__ __launch_bounds__(64) void k_chain_wide_list(ChainArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const uint32_t n = *A.n_wide;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint4 pt = A.upair_tab[A.wide_list[i]];
+        const uint32_t rq = pt.x + (pt.y & 0xffffu), rt = pt.x + (pt.y >> 16);
+        const int lenq = A.read_len[rq], lent = A.read_len[rt];
+        const int nq = (int)A.mz_cnt[rq], nt = (int)A.mz_cnt[rt];
+        const fsv_mz *mq = A.mz + A.mz_off[rq] + nq, *mt = A.mz + A.mz_off[rt];
+        uint4 qa[FSV_CHAIN_QR];
+        chain_load_query<SHORT>(qa, mq, nq);
+        chain_pair<SHORT>(A, s_raw, pt, lenq, lent, nq, nt, mq, mt, qa);
+        __syncthreads();
+    }
 }
 
 // The full pass: one block per FSV_CHAIN_CH consecutive pairs of the pair table (row-major: the pairs of a chunk nearly always
@@ -966,6 +993,10 @@ __global__ __launch_bounds__(64) void k_chain_chunks(ChainArgs A, uint32_t n_upa
             lenq = __builtin_amdgcn_readfirstlane(A.read_len[rq]); nq = __builtin_amdgcn_readfirstlane((int)A.mz_cnt[rq]);
             offq = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.mz_off[rq]);
             chain_load_query<SHORT>(qa, A.mz + offq + nq, nq);   // the position-sorted copy
+        }
+        if (A.wide_list && min(nq, nt) > A.amax) {     // only such a pair can have more anchors than this tile holds
+            if (lane == 0) A.wide_list[atomicAdd(A.n_wide, 1u)] = first + (uint32_t)i;
+            continue;
         }
         const fsv_mz *mq = A.mz + offq + nq;
         chain_pair<SHORT>(A, s_raw, pt, lenq, lent, nq, nt, mq, A.mz + offt, qa);

@@ -293,18 +293,23 @@ def test_reads_of_65536_bases_and_more_match_oracle(ctx):
         out = np.insert(out[keep], np.searchsorted(np.flatnonzero(keep), ins), r.integers(0, 4, len(ins)).astype(np.uint8))
         return acgt[out].tobytes()
 
-    def long_set(seed, n):
+    def long_set(seed, n, g=None, lo=66000, hi=80000):
+        g = genome if g is None else g
         r = np.random.default_rng(seed)
         reads = []
         for i in range(n):
-            ln = int(r.integers(66000, 80000))
-            st = int(r.integers(0, len(genome) - ln))
-            s = noisy(genome[st:st + ln], r)
+            ln = int(r.integers(lo, hi))
+            st = int(r.integers(0, len(g) - ln))
+            s = noisy(g[st:st + ln], r)
             reads.append(synth.revcomp(s) if r.random() < 0.5 else s)
         return reads
 
+    # plain random sequence: a 60 kb overlap has ~1 700 anchors, more than the chaining tile of the main kernel holds -- such pairs
+    # are set aside and chained with the large tile (k_chain_wide_list: 2 560 anchors in the long layout, 4 096 in the compact one)
+    plain = rng.integers(0, 4, 230000).astype(np.uint8)
+
     short = synth.make_region(905, width=20000, depth_per_hap=12.0).reads[0]
-    sets = [long_set(1, 16), short, long_set(2, 12)]
+    sets = [long_set(1, 16), short, long_set(2, 12), long_set(3, 12, plain, 66000, 80000)]
     assert max(len(x) for x in sets[0]) >= 65536
     for rounds in (1, 3):
         p = ctx.default_asm_params()
