@@ -311,7 +311,10 @@ def test_reads_of_65536_bases_and_more_match_oracle(ctx):
     short = synth.make_region(905, width=20000, depth_per_hap=12.0).reads[0]
     sets = [long_set(1, 16), short, long_set(2, 12), long_set(3, 12, plain, 66000, 80000)]
     assert max(len(x) for x in sets[0]) >= 65536
-    for rounds in (1, 3):
+    # and a batch of 40-60 kb reads: the compact layout (every read below 65 536 bases) with pairs of more than 1 024 anchors
+    compact = [long_set(5, 12, plain, 40000, 60000), short]
+    assert max(len(x) for x in compact[0]) < 65536
+    for sets, rounds in ((sets, 1), (sets, 3), (compact, 3)):
         p = ctx.default_asm_params()
         p.n_rounds = rounds
         contigs, cset, status, reads, b = gpu_assemble(ctx, sets, p)
