@@ -70,7 +70,7 @@ class Alns(C.Structure):
 
 class AlnStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_pairs", "n_events", "dp_cells", "algo_bytes")] + \
-               [(n, C.c_double) for n in ("ms_seed", "ms_chain", "ms_events", "ms_dp", "ms_total")]
+               [(n, C.c_double) for n in ("ms_seed", "ms_chain", "ms_events", "ms_dp", "ms_total")] + [("n_boxes", C.c_uint64)]
 
 
 ALN_REC_DTYPE = np.dtype([("ref_start", "<i4"), ("ref_end", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"), ("n_cigar", "<u4"),
@@ -385,7 +385,7 @@ class Context:
             cseq = np.frombuffer(b"".join(contigs) + b"\0", dtype=np.uint8)
             total = int(coff[-1])
         cref = np.ascontiguousarray(contig_ref, dtype=np.uint32)
-        rec = np.zeros(max(1, 3 * n), dtype=ALN_REC_DTYPE)   # primary + up to two supplementary records per contig
+        rec = np.zeros(max(1, 5 * n), dtype=ALN_REC_DTYPE)   # FSV_ALN_MAX_REC records per contig
         cap = total // 8 + 4096 * max(1, n)
         cigar = np.empty(cap, dtype=np.uint32)
         status = np.zeros(max(1, n), dtype=np.int32)

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64) void k_sketch(const uint32_t *__restrict__ stor
 template <int UQ_MAX>
 __device__ __forceinline__ void uniq_read(const uint32_t r, fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
                                           uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed, uint32_t lo_cnt, uint32_t hi_cnt,
-                                          unsigned long long *__restrict__ total)
+                                          unsigned long long *__restrict__ total, const uint32_t max_occ = 1u)
 {
     __shared__ uint64_t s_hash[UQ_MAX];
     __shared__ uint64_t s_pay[UQ_MAX]; // pos | rev << 32 | span << 40
@@ -255,7 +255,13 @@ __device__ __forceinline__ void uniq_read(const uint32_t r, fsv_mz *__restrict__
     for (uint32_t j = 0; j < UQ_MAX / 256; j++) {
         const uint32_t i = lo + j;
         if (i < hi) {
-            const bool u = (i == 0 || s_hash[i - 1] != s_hash[i]) && (i + 1 >= n || s_hash[i + 1] != s_hash[i]);
+            bool u = (i == 0 || s_hash[i - 1] != s_hash[i]) && (i + 1 >= n || s_hash[i + 1] != s_hash[i]);
+            if (max_occ > 1u && !u) {   // the aligner's second seeding of an oversize event keeps hashes that occur up to max_occ times
+                uint32_t run = 1;
+                for (uint32_t d = 1; d <= max_occ && i >= d && s_hash[i - d] == s_hash[i]; d++) run++;
+                for (uint32_t d = 1; d <= max_occ && i + d < n && s_hash[i + d] == s_hash[i]; d++) run++;
+                u = run <= max_occ;
+            }
             if (u) { kh[cnt] = s_hash[i]; kp[cnt] = s_pay[i]; cnt++; }
         }
     }
@@ -304,9 +310,10 @@ __device__ __forceinline__ void uniq_read(const uint32_t r, fsv_mz *__restrict__
 template <int UQ_MAX>
 __global__ __launch_bounds__(256) void k_uniq(fsv_mz *__restrict__ mz, const uint32_t *__restrict__ mz_off, uint32_t *__restrict__ mz_cnt,
                                               uint32_t *__restrict__ warn, const uint32_t *__restrict__ only_changed = nullptr,
-                                              uint32_t lo_cnt = 0u, uint32_t hi_cnt = 0xffffffffu, unsigned long long *__restrict__ total = nullptr)
+                                              uint32_t lo_cnt = 0u, uint32_t hi_cnt = 0xffffffffu, unsigned long long *__restrict__ total = nullptr,
+                                              uint32_t max_occ = 1u)
 {
-    uniq_read<UQ_MAX>(blockIdx.x, mz, mz_off, mz_cnt, warn, only_changed, lo_cnt, hi_cnt, total);
+    uniq_read<UQ_MAX>(blockIdx.x, mz, mz_off, mz_cnt, warn, only_changed, lo_cnt, hi_cnt, total, max_occ);
 }
 
 // the same for a size class that is usually empty (lists above 1 024 entries in a HiFi batch): a few blocks walk all reads, so the

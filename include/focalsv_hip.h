@@ -44,6 +44,7 @@ extern "C" {
 #define FSV_EHIP     -4  /* HIP runtime error (fsv_last_error gives the text) */
 #define FSV_ECAP     -5  /* caller buffer too small */
 #define FSV_EUNSUP   -6  /* input outside what this build supports */
+#define FSV_EINTERNAL -7 /* an invariant of the library did not hold, or a C++ exception was caught at the boundary (fsv_last_error gives the text) */
 
 #define FSV_WINDOW          375 /* hifiasm WINDOW, Hash_Table.h:9 */
 #define FSV_K_FULL           15 /* hifiasm THRESHOLD, Hash_Table.h:13 */
@@ -272,12 +273,13 @@ int fsv_sketch_reads(fsv_ctx *ctx, const fsv_readsets *sets, int32_t w, int32_t 
  */
 typedef struct fsv_aln_params {
     int32_t k, w;               /* seeds: 19, 19; w grows with the sequence length (len/3000 + 1) */
-    int32_t min_anchors, lookback, max_gap;  /* 3, 64, 20000 */
+    int32_t min_anchors, lookback, max_gap;  /* 3, 64, 50000: one chain runs across any SV DipPAV calls (max_svlen, extract_contig_signature_CCS.py:411) */
     int32_t a, b, q, e, q2, e2; /* asm5: 1, 19, 39, 3, 81, 1 */
     int32_t pad;                /* identical bases added on each side of a DP event, 24 */
     int32_t max_mm_run;         /* equal-length inter-seed run with <= this many mismatches stays M, 4 */
     int32_t xdrop;              /* gap-free end extension, 100 */
-    int32_t max_cells;          /* largest DP event, 2^26 cells */
+    int32_t max_cells;          /* largest DP event, 2^26 cells; a larger one (both copies of a duplication between two unique seeds) is seeded
+                                   again on its own, and what is still larger inside it is closed from its corners: never refused */
 } fsv_aln_params;
 void fsv_aln_default_params(fsv_aln_params *p);
 
@@ -292,18 +294,20 @@ typedef struct fsv_aln_rec {
 } fsv_aln_rec;                    /* 40 bytes */
 
 typedef struct fsv_alns {
-    fsv_aln_rec *rec;       /* host, capacity rec_cap: 3 x n_contigs holds every case (FSV_ALN_MAX_REC records per contig) */
+    fsv_aln_rec *rec;       /* host, capacity rec_cap: 5 x n_contigs holds every case (FSV_ALN_MAX_REC records per contig) */
     uint32_t  rec_cap, n_rec;
     uint32_t *cigar;        /* host, BAM encoding len << 4 | op */
     uint64_t  cigar_cap, n_cigar;
     int32_t  *contig_status; /* host, n_contigs: 0 aligned, 1 no chain (unaligned), <0 FSV_E* for that contig */
 } fsv_alns;
 
-#define FSV_ALN_MAX_REC 3
+#define FSV_ALN_MAX_REC 5
 /* contig i is aligned to reference window contig_ref[i].  A contig yields its primary record and, when the primary chain leaves
- * part of the contig uncovered (an SV beyond max_gap), up to two supplementary records -- consecutive in `rec`, primary first,
- * soft clips for the parts the record does not align -- from which DipPAV's split-alignment rules call the SV
- * (extract_contig_signature_CCS.py:251-327).
+ * part of the contig uncovered (an SV beyond max_gap), up to two supplementary records on the same strand -- consecutive in
+ * `rec`, primary first, soft clips for the parts the record does not align -- from which DipPAV's split-alignment rules call the
+ * SV (extract_contig_signature_CCS.py:251-327).  An inverted piece of the contig comes back as one record of the other strand
+ * (rev differs), and the record it interrupts is cut in two around it: the split rule pairs records of one strand only (:286),
+ * so an inversion yields no INS / DEL call, as with minimap2's reverse-strand supplementary alignment.
  * contig_seq == NULL (contig_off ignored): align the n_contigs contigs of the last fsv_assemble_batch on this context straight
  * from device memory, in their output order -- the device-resident hand-off between the two boundaries. */
 int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint64_t *contig_off, uint32_t n_contigs,
@@ -313,6 +317,7 @@ int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint64_t *contig
 typedef struct fsv_aln_stats {
     uint64_t n_pairs, n_events, dp_cells, algo_bytes;
     double ms_seed, ms_chain, ms_events, ms_dp, ms_total;
+    uint64_t n_boxes;       /* events larger than max_cells that were seeded again */
 } fsv_aln_stats;
 int fsv_aln_last_stats(const fsv_ctx *ctx, fsv_aln_stats *out);
 

@@ -76,12 +76,12 @@ int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const o
                  char *corrected, uint64_t corrected_cap, uint64_t *corrected_off);
 typedef struct {
     int32_t k, w;             /* seeds: 19, 19 (minimap2 asm5); callers raise w to len/3000+1 for long windows */
-    int32_t min_anchors, lookback, max_gap;
+    int32_t min_anchors, lookback, max_gap;  /* max_gap 50 000: a chain runs across any SV DipPAV would call (max_svlen, extract_contig_signature_CCS.py:411) */
     int32_t a, b, q, e, q2, e2; /* asm5: 1, 19, 39, 3, 81, 1; q2 < 0 = single affine */
     int32_t pad;              /* identical bases added on each side of a DP event: 24 */
     int32_t max_mm_run;       /* an equal-length inter-seed run with at most this many mismatches stays 'M': 4 */
     int32_t xdrop;            /* gap-free end extension: 100 */
-    int32_t max_cells;        /* largest DP event: 2^26 cells */
+    int32_t max_cells;        /* largest DP event: 2^26 cells; a larger one is seeded again on its own (oracle/aln.c: sub_align) */
 } orc_aln_params;
 
 typedef struct {
@@ -99,10 +99,15 @@ int orc_aln_chain(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, 
 int orc_gap_max_shift(const char *s, int off, int len, int cap);
 int orc_align_contig(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
                      uint32_t *cigar, int cigar_cap);
-#define ORC_ALN_MAX_REC 3      /* records per contig: primary + supplementary chains */
+#define ORC_ALN_MAX_REC 5      /* records per contig: primary + supplementary chains of its strand, the part behind a cut, one chain of the other strand */
+#define ORC_ALN_MAJ_REC 3      /* chains on the contig's majority strand */
 #define ORC_ALN_SUP_MIN 200    /* chain score a supplementary chain needs */
+#define ORC_ALN_SUB_OCC 2      /* an event larger than max_cells is seeded again: minimizers occurring at most this often in each side */
+#define ORC_ALN_SUB_PER 1500   /* ... with a minimizer window of max(w, L / 1500 + 1) for a box whose longer side has L bases */
+#define ORC_ALN_AMAX 8192      /* anchors the chaining tile of the HIP path holds */
+int orc_occ_sorted(orc_mz *mz, int n, int max_occ);
 int orc_aln_chains(const orc_mz *mq, int nq, int lenq, const orc_mz *mt, int nt, const orc_aln_params *P, int *rev_out,
-                   int32_t *cq, int32_t *ct, int cap, int *chain_n, int max_rec);
+                   int32_t *cq, int32_t *ct, int cap, int *chain_n, uint8_t *chain_rev, int max_rec);
 int orc_align_contig_multi(const char *contig, int lenq, const char *ref, int lent, const orc_aln_params *P, orc_aln *out,
                            uint32_t *cigar, int cigar_cap, int max_rec);
 int orc_sketch(const char *s, int len, int w, int k, int hpc, orc_mz *out, int cap);

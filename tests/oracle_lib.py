@@ -174,7 +174,7 @@ def align_contig(contig: bytes, ref: bytes, params=None):
             "cigar": [(int(c) & 0xf, int(c) >> 4) for c in cg[: a.n_cigar]], "raw": cg[: a.n_cigar].copy()}
 
 
-def align_contig_multi(contig: bytes, ref: bytes, params=None, max_rec=3):
+def align_contig_multi(contig: bytes, ref: bytes, params=None, max_rec=5):
     """primary + supplementary records of one contig -> list of dicts as align_contig returns (empty: unaligned)"""
     p = params or aln_default_params()
     cap = 1 << 16

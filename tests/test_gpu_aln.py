@@ -82,36 +82,82 @@ def test_unalignable_contig_is_reported(ctx):
     assert int(rec[0]["ref_start"]) == 100 and int(rec[0]["ref_end"]) == 4000
 
 
+def _records_by_contig(rec, cigar, n):
+    by = [[] for _ in range(n)]
+    for r in rec:
+        cg = cigar[int(r["cigar_off"]): int(r["cigar_off"]) + int(r["n_cigar"])]
+        by[int(r["contig"])].append({"ref_start": int(r["ref_start"]), "ref_end": int(r["ref_end"]), "rev": int(r["rev"]), "mapq": int(r["mapq"]),
+                                     "q_start": int(r["q_start"]), "q_end": int(r["q_end"]),
+                                     "cigar": [(int(x) & 0xf, int(x) >> 4) for x in cg], "raw": cg})
+    return by
+
+
+def _same_records(got, want, what):
+    assert len(got) == len(want), (what, len(got), len(want))
+    for g, w in zip(got, want):
+        assert (g["ref_start"], g["ref_end"], g["rev"], g["q_start"], g["q_end"]) == (w["ref_start"], w["ref_end"], w["rev"], w["q_start"], w["q_end"]), what
+        assert list(g["raw"]) == list(w["raw"]), (what, O.cigar_str(g["raw"]), O.cigar_str(w["raw"]))
+
+
 def test_supplementary_records_for_svs_beyond_the_chaining_gap(ctx):
-    """a 30 kb deletion / insertion breaks the chain (max_gap 20 kb): the rest of the contig comes back as a supplementary
-    record, identical to the oracle's, and DipPAV's split-alignment rule turns the two records into the call"""
-    import numpy as np
-    from focalsv_amd.dippav import signatures as S
+    """a 30 kb deletion / insertion with max_gap at minimap2's 20 kb breaks the chain: the rest of the contig comes back as a
+    supplementary record, identical to the oracle's, and DipPAV's split-alignment rule turns the two records into the call.
+    With the default max_gap (50 kb: DipPAV's max_svlen) the same SVs sit in one record's CIGAR."""
+    from tests import aln_cases as A
     rng = np.random.default_rng(5)
-    A = np.frombuffer(b"ACGT", dtype=np.uint8)
-    ref = A[rng.integers(0, 4, 150000)].tobytes()
-    contigs = [ref[:40000] + ref[70000:], ref[:40000] + A[rng.integers(0, 4, 30000)].tobytes() + ref[40000:], ref[1000:90000]]
+    ref = A.rnd(rng, 150000)
+    contigs = [ref[:40000] + ref[70000:], ref[:40000] + A.rnd(rng, 30000) + ref[40000:], ref[1000:90000]]
+    p = ctx.default_aln_params()
+    p.max_gap = 20000
+    po = O.aln_default_params()
+    po.max_gap = 20000
+    rec, cigar, status = ctx.align_batch(contigs, [0, 0, 0], [ref], p)
+    assert list(status) == [0, 0, 0]
+    by = _records_by_contig(rec, cigar, 3)
+    assert [len(b) for b in by] == [2, 2, 1]
+    for i, c in enumerate(contigs):
+        _same_records(by[i], O.align_contig_multi(c, ref, po), i)
+    for i, want in ((0, ("DEL", 40000, 30000)), (1, ("INS", 40000, 30000))):
+        calls = A.split_calls(by[i])
+        assert len(calls) == 1 and calls[0][1] == want[0] and abs(calls[0][2] - want[1]) <= 2 and abs(calls[0][3] - want[2]) <= 2
     rec, cigar, status = ctx.align_batch(contigs, [0, 0, 0], [ref])
     assert list(status) == [0, 0, 0]
-    by = {}
-    for r in rec:
-        by.setdefault(int(r["contig"]), []).append(r)
-    assert [len(by[i]) for i in range(3)] == [2, 2, 1]
+    by = _records_by_contig(rec, cigar, 3)
+    assert [len(b) for b in by] == [1, 1, 1]
     for i, c in enumerate(contigs):
-        want = O.align_contig_multi(c, ref)
-        assert len(want) == len(by[i])
-        for r, w in zip(by[i], want):
-            cg = cigar[int(r["cigar_off"]): int(r["cigar_off"]) + int(r["n_cigar"])]
-            assert (int(r["ref_start"]), int(r["ref_end"]), int(r["rev"])) == (w["ref_start"], w["ref_end"], w["rev"])
-            assert list(cg) == list(w["raw"])
-    # the deletion through the host logic
-    segs = []
-    for r in by[0]:
-        cg = cigar[int(r["cigar_off"]): int(r["cigar_off"]) + int(r["n_cigar"])]
-        segs.append(S.AlignedSegment("chr21", int(r["ref_start"]), int(r["ref_end"]), [(int(x) & 0xf, int(x) >> 4) for x in cg], "contig_hp1_0", bool(r["rev"]), 60, None))
-    segs.sort(key=lambda x: x.pos)
-    dels, inss = S.extract_sig_from_split(segs[0], segs[1])
-    assert len(dels) == 1 and abs(dels[0][3] - 30000) <= 2 and abs(dels[0][2] - 40000) <= 2
+        _same_records(by[i], O.align_contig_multi(c, ref), i)
+    assert A.events(by[0][0]) == [("DEL", 40000, 30000)] and A.events(by[1][0]) == [("INS", 40000, 30000)]
+
+
+def test_duplications_beyond_max_cells(ctx):
+    """duplication-type INS / DEL of 6, 8, 12 and 30 kb (exact and 2 % diverged copies), a dispersed repeat
+    with variation inside a copy, a dispersed duplication, a tandem array of short units, a replacement -- each an event of more
+    than max_cells cells, which used to cost the whole contig (FSV_EUNSUP).  All in one call: status 0, records bit-identical
+    to the oracle's, every SV at its left-aligned position (+-1 bp) with its exact length, the contig's other SV still called."""
+    from tests import aln_cases as A
+    cases = A.duplication_cases() + A.other_cases()
+    rec, cigar, status = ctx.align_batch([c.hap for c in cases], list(range(len(cases))), [c.ref for c in cases])
+    assert (status == 0).all(), list(status)
+    assert ctx.aln_stats()["n_boxes"] >= 8      # the exact copies, the array, the replacement; diverged copies keep unique seeds
+    by = _records_by_contig(rec, cigar, len(cases))
+    for c, got in zip(cases, by):
+        A.check_case(c, got)
+        _same_records(got, O.align_contig_multi(c.hap, c.ref), c.name)
+
+
+def test_inversions_make_no_call(ctx):
+    """a 2 kb and a 5 kb inversion (contig on either strand): the inverted piece is a record of the other
+    strand, the record around it is cut in two, DipPAV's split rule makes nothing of records of different strands -- 0 calls
+    beside the contig's planted deletion; records bit-identical to the oracle's"""
+    from tests import aln_cases as A
+    cases = A.inversion_cases()
+    rec, cigar, status = ctx.align_batch([c.hap for c in cases], list(range(len(cases))), [c.ref for c in cases])
+    assert (status == 0).all(), list(status)
+    by = _records_by_contig(rec, cigar, len(cases))
+    for c, got in zip(cases, by):
+        A.check_case(c, got)
+        assert A.split_calls(got) == [], c.name
+        _same_records(got, O.align_contig_multi(c.hap, c.ref), c.name)
 
 
 def test_left_shift_regressions_and_tandem_regions(ctx):

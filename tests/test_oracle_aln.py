@@ -114,3 +114,41 @@ def test_gap_shift_rule():
     s = b"TTTTACACACACACACGGGG"
     assert O.lib().orc_gap_max_shift(s, 10, 2, 10) == 6    # a 2-base gap at 10 can move back to 4 (the first AC)
     assert O.lib().orc_gap_max_shift(s, 10, 2, 3) == 3
+
+
+def test_duplications_beyond_max_cells_are_aligned():
+    """a tandem duplication of 6 kb and more put both copies between two unique seeds -- an event of more than 2^26
+    cells, and the whole contig was refused.  Now the event's box is seeded again on its own (oracle/aln.c:sub_align): every case
+    comes back as one record with the SV at its left-aligned position and exact length, and the contig's other SV with it."""
+    from tests import aln_cases as A
+    for case in A.duplication_cases() + A.other_cases():
+        recs = O.align_contig_multi(case.hap, case.ref)
+        A.check_case(case, recs)
+
+
+def test_inversions_make_no_call():
+    """an inversion came back as one forward record with INS + DEL at the breakpoint.  Now the inverted piece is a
+    record of the other strand and the forward record is cut around it; DipPAV's split rule ignores pairs of different strands"""
+    from tests import aln_cases as A
+    for case in A.inversion_cases():
+        recs = O.align_contig_multi(case.hap, case.ref)
+        A.check_case(case, recs)
+        assert A.split_calls(recs) == [], case.name
+
+
+def test_split_records_beyond_max_gap():
+    """a 30 kb deletion / insertion with max_gap at minimap2's 20 kb: two records, and DipPAV's split rule makes the call;
+    with the default max_gap (50 kb) the same SV sits in one record's CIGAR"""
+    import numpy as np
+    from tests import aln_cases as A
+    rng = np.random.default_rng(5)
+    ref = A.rnd(rng, 150000)
+    for hap, want in ((ref[:40000] + ref[70000:], ("DEL", 40000, 30000)), (ref[:40000] + A.rnd(rng, 30000) + ref[40000:], ("INS", 40000, 30000))):
+        recs = O.align_contig_multi(hap, ref)
+        assert len(recs) == 1 and A.events(recs[0]) == [want]
+        p = O.aln_default_params()
+        p.max_gap = 20000
+        recs = O.align_contig_multi(hap, ref, p)
+        assert len(recs) == 2
+        calls = A.split_calls(recs)
+        assert len(calls) == 1 and calls[0][1] == want[0] and abs(calls[0][2] - want[1]) <= 2 and abs(calls[0][3] - want[2]) <= 2
