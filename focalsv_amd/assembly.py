@@ -14,6 +14,13 @@ from . import _lib, fasta
 from .readsets import pack_sets
 
 
+
+def _describe_status(st: int) -> str:
+    """the warning bits of a read set's status in words (bit 1 / 2: a read longer than the minimizer / anchor lists hold lost its
+    tail -- with the ONT / CLR parameter set that is a read above ~32 kb: include/focalsv_hip.h, fsv_asm_ont_params)"""
+    from .pipeline import describe_set_status
+    return describe_set_status(st)
+
 def setup_logging(step_name, out_dir):
     """same log layout as focalsv/utils.py:6-20"""
     log_dir = os.path.join(out_dir, "log")
@@ -129,7 +136,7 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
                     fw.write(">contig_%d\n" % n + "\n".join(t[i:i + 60] for i in range(0, len(t), 60)) + "\n")
             status[f] = int(st)
             if st:
-                logger.warning(f"{f}: assembly status {int(st)}")
+                logger.warning(f"{f}: assembly status {int(st)} ({_describe_status(int(st))})")
         combine_fas(regions_dir, logger, data_type)
         return status
     if fas:
@@ -158,7 +165,7 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
                 fasta.write_contig_fasta(outp, outp, contigs)
             status[f] = int(st)
             if st:
-                logger.warning(f"{f}: assembly status {int(st)}")
+                logger.warning(f"{f}: assembly status {int(st)} ({_describe_status(int(st))})")
     combine_fas(regions_dir, logger)
     return status
 

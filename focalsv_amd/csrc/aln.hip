@@ -1445,14 +1445,6 @@ static int align_batch_impl(fsv_ctx *ctx, const char *contig_seq, const uint64_t
     return FSV_OK;
 }
 
-// the C entry points never let a C++ exception through (a std::bad_alloc from a vector sized by caller data would otherwise
-// terminate a Python process that came in through ctypes)
-#define FSV_GUARD(ctx, call)                                                            \
-    try { return (call); }                                                              \
-    catch (const std::bad_alloc &) { return fsv_fail(ctx, FSV_ENOMEM, "out of host memory"); } \
-    catch (const std::exception &e) { if (ctx) (ctx)->last_error = std::string("exception: ") + e.what(); return FSV_EINTERNAL; } \
-    catch (...) { return fsv_fail(ctx, FSV_EINTERNAL, "unknown exception"); }
-
 extern "C" int fsv_nw(fsv_ctx *ctx, const char *target, int32_t tl, const char *query, int32_t ql, const fsv_aln_params *params, int32_t *score,
                       uint32_t *cigar, uint32_t cigar_cap, uint32_t *n_cigar)
 {

@@ -50,13 +50,15 @@ struct Span {
 // per-round block of device counters (one 64-byte slot per correction round + one for the final pass, zeroed once per batch and
 // read back with the round's one synchronisation or at the end): u32 indices
 enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4, CT_COLS_HI = 5, CT_DP_WIDE = 6, CT_DP_SB = 7, CT_DP_GEN = 8, CT_DP_XW = 9,
-       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_DP_SB16 = 14, CT_WIDE = 15, CT_SLOT = 16 };
+       CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_DP_SB16 = 14, CT_WIDE = 15,
+       CT_MZRAW_LO = 16, CT_MZRAW_HI = 17, CT_BASES_LO = 18, CT_BASES_HI = 19,   // k_uniq's other two sums: CT_MZ + 3 and + 4 as 64-bit words
+       CT_SLOT = 20 };
 
 struct AsmWs {
     DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
-    std::vector<size_t> chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
+    std::vector<size_t> sk_rec, uq_rec, chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -160,6 +162,14 @@ int make_geometry(fsv_ctx *ctx, const Batch &B, const std::vector<int32_t> &len,
     return FSV_OK;
 }
 
+// a workgroup may use more than 64 KB of dynamic LDS only after opting in (the ONT profile's 4 096-anchor tile in the long layout is
+// 96 KB: without this the launch was rejected and the whole batch came back FSV_EHIP -- ADVICE r02)
+template <class F> int lds_opt_in(fsv_ctx *ctx, F f, size_t bytes)
+{
+    if (bytes > 48u * 1024u) FSV_HIP(ctx, hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return FSV_OK;
+}
+
 // sketch + per-read index + chaining on the current store; fills ws.ovl (and ws.tasks when emit_tasks).  Nothing here waits
 // for the GPU: launches are sized from the read lengths the host already has, counts stay in the round's counter slot `ct`.
 int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, const uint32_t *store, const fsv_asm_params &P, int bw,
@@ -170,7 +180,7 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     TRY(ensure(ctx, W.mz_cnt, (size_t)B.n_reads * 4));
     TRY(ensure(ctx, W.ovl, (size_t)std::max(1u, B.n_pairs) * sizeof(fsv_ovl)));
     TRY(ensure(ctx, W.ovl_c, (size_t)std::max(1u, B.n_pairs) * sizeof(uint4)));
-    W.kt.begin(ctx, KN_SKETCH, (uint64_t)G.word_off[B.n_reads] * 4 + (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz));
+    W.sk_rec.push_back(W.kt.begin(ctx, KN_SKETCH, 0));    // bytes: filled in from the round's counters (minimizers produced, bases sketched)
     if (!(only_changed && (P.k & 1))) FSV_HIP(ctx, hipMemsetAsync(W.mz_cnt.p, 0, (size_t)B.n_reads * 4, ctx->stream));
     // (with only_changed the unchanged reads keep their count; the kernel zeroes the others itself)
     if (!(P.k & 1)) only_changed = nullptr; // the replay kernel (even k) always sketches every read
@@ -200,7 +210,7 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     // reads per CU), one for longer ones; each launch skips the reads of the other size class, so the host need not know the
     // longest list of the batch (round 1 read the counts back to choose)
     unsigned long long *mz_total = (unsigned long long *)(ct + CT_MZ_LO);
-    W.kt.begin(ctx, KN_UNIQ, (uint64_t)G.mz_off[B.n_reads] / 4 * sizeof(fsv_mz) * 2);
+    W.uq_rec.push_back(W.kt.begin(ctx, KN_UNIQ, 0));
     hipLaunchKernelGGL(k_uniq<1024>, dim3(B.n_reads), dim3(256), 0, ctx->stream, (fsv_mz *)W.mz.p, (const uint32_t *)W.mz_off.p,
                        (uint32_t *)W.mz_cnt.p, (uint32_t *)W.warn.p, only_changed, 0u, 1024u, mz_total);
     FSV_HIP(ctx, hipGetLastError());
@@ -239,15 +249,15 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     // algorithmic bytes of the launch are filled in when the batch ends (they need the counts this launch leaves on the device)
     W.chain_rec.push_back(W.kt.begin(ctx, KN_CHAIN, 0));
     const uint32_t n_chunks = ((B.n_upairs + FSV_CHAIN_CH - 1) / FSV_CHAIN_CH + 7u) & ~7u;   // (xcd_block: a multiple of eight blocks)
-    if (short_reads) hipLaunchKernelGGL(k_chain_chunks<true>, dim3(n_chunks), dim3(64), chain_lds_bytes(true, A.amax), ctx->stream, A, B.n_upairs);
-    else hipLaunchKernelGGL(k_chain_chunks<false>, dim3(n_chunks), dim3(64), chain_lds_bytes(false, A.amax), ctx->stream, A, B.n_upairs);
+    if (short_reads) { TRY(lds_opt_in(ctx, k_chain_chunks<true>, chain_lds_bytes(true, A.amax))); hipLaunchKernelGGL(k_chain_chunks<true>, dim3(n_chunks), dim3(64), chain_lds_bytes(true, A.amax), ctx->stream, A, B.n_upairs); }
+    else { TRY(lds_opt_in(ctx, k_chain_chunks<false>, chain_lds_bytes(false, A.amax))); hipLaunchKernelGGL(k_chain_chunks<false>, dim3(n_chunks), dim3(64), chain_lds_bytes(false, A.amax), ctx->stream, A, B.n_upairs); }
     FSV_HIP(ctx, hipGetLastError());
     if (A.wide_list) {
         ChainArgs AW = A;
         AW.amax = short_reads ? FSV_AMAX_WIDE : FSV_AMAX_WIDE_LONG; AW.stamps = nullptr;   // (the kernel walks AW.wide_list)
         const uint32_t gridw = std::min<uint32_t>(B.n_upairs, 2u * (uint32_t)ctx->n_cu);
-        if (short_reads) hipLaunchKernelGGL(k_chain_wide_list<true>, dim3(gridw), dim3(64), chain_lds_bytes(true, AW.amax), ctx->stream, AW);
-        else hipLaunchKernelGGL(k_chain_wide_list<false>, dim3(gridw), dim3(64), chain_lds_bytes(false, AW.amax), ctx->stream, AW);
+        if (short_reads) { TRY(lds_opt_in(ctx, k_chain_wide_list<true>, chain_lds_bytes(true, AW.amax))); hipLaunchKernelGGL(k_chain_wide_list<true>, dim3(gridw), dim3(64), chain_lds_bytes(true, AW.amax), ctx->stream, AW); }
+        else { TRY(lds_opt_in(ctx, k_chain_wide_list<false>, chain_lds_bytes(false, AW.amax))); hipLaunchKernelGGL(k_chain_wide_list<false>, dim3(gridw), dim3(64), chain_lds_bytes(false, AW.amax), ctx->stream, AW); }
         FSV_HIP(ctx, hipGetLastError());
     }
     W.kt.end(ctx);
@@ -373,7 +383,7 @@ extern "C" int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_
 
 // K5 + K6 on caller-supplied tasks: the same kernels fsv_assemble_batch drives, with every task treated as belonging to an
 // accepted overlap
-extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_words, const fsv_wtask *tasks, uint32_t n_tasks,
+static int fsv_bpm_paths_impl(fsv_ctx *ctx, const uint32_t *store, size_t store_words, const fsv_wtask *tasks, uint32_t n_tasks,
                              fsv_wres *res, fsv_wpath *paths)
 {
     if (!ctx || !store || (!tasks && n_tasks) || (!res && n_tasks) || (!paths && n_tasks)) return FSV_EINVAL;
@@ -610,7 +620,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     AsmWs &W = *ws_get(ctx);
     memset(&W.stats, 0, sizeof(W.stats));
     W.kt.reset();
-    W.chain_rec.clear(); W.bpm_rec.clear(); W.rescue_rec.clear(); W.fast_rec.clear(); W.dp_rec.clear(); W.cons_rec.clear();
+    W.sk_rec.clear(); W.uq_rec.clear(); W.chain_rec.clear(); W.bpm_rec.clear(); W.rescue_rec.clear(); W.fast_rec.clear(); W.dp_rec.clear(); W.cons_rec.clear();
     W.bnd_rec.clear(); W.bpm2_rec.clear(); W.fast2_rec.clear(); W.dp2_rec.clear(); W.bndc_rec.clear();
     const auto t_enter = std::chrono::steady_clock::now();
 
@@ -898,15 +908,15 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             if (A2.wide_list) FSV_HIP(ctx, hipMemsetAsync(A2.n_wide, 0, 4, ctx->stream));   // (the final pass's own wide pairs are done)
             // timed like the other k_chain launches (a profiler counts it too)
             W.kt.begin(ctx, KN_CHAIN, 0);
-            if (short_reads) hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A2.amax), ctx->stream, A2);
-            else hipLaunchKernelGGL(k_chain<false>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(false, A2.amax), ctx->stream, A2);
+            if (short_reads) { TRY(lds_opt_in(ctx, k_chain<true>, chain_lds_bytes(true, A2.amax))); hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A2.amax), ctx->stream, A2); }
+            else { TRY(lds_opt_in(ctx, k_chain<false>, chain_lds_bytes(false, A2.amax))); hipLaunchKernelGGL(k_chain<false>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(false, A2.amax), ctx->stream, A2); }
             FSV_HIP(ctx, hipGetLastError());
             if (A2.wide_list) {
                 ChainArgs AW = A2;
                 AW.amax = short_reads ? FSV_AMAX_WIDE : FSV_AMAX_WIDE_LONG; AW.pair_list = nullptr; AW.n_list_dev = nullptr;
                 const uint32_t gridw = std::min<uint32_t>(B.n_upairs, 2u * (uint32_t)ctx->n_cu);
-                if (short_reads) hipLaunchKernelGGL(k_chain_wide_list<true>, dim3(gridw), dim3(64), chain_lds_bytes(true, AW.amax), ctx->stream, AW);
-                else hipLaunchKernelGGL(k_chain_wide_list<false>, dim3(gridw), dim3(64), chain_lds_bytes(false, AW.amax), ctx->stream, AW);
+                if (short_reads) { TRY(lds_opt_in(ctx, k_chain_wide_list<true>, chain_lds_bytes(true, AW.amax))); hipLaunchKernelGGL(k_chain_wide_list<true>, dim3(gridw), dim3(64), chain_lds_bytes(true, AW.amax), ctx->stream, AW); }
+                else { TRY(lds_opt_in(ctx, k_chain_wide_list<false>, chain_lds_bytes(false, AW.amax))); hipLaunchKernelGGL(k_chain_wide_list<false>, dim3(gridw), dim3(64), chain_lds_bytes(false, AW.amax), ctx->stream, AW); }
                 FSV_HIP(ctx, hipGetLastError());
             }
             W.kt.end(ctx);
@@ -1042,6 +1052,15 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             if ((size_t)sl < W.bndc_rec.size()) W.kt.recs[W.bndc_rec[sl]].bytes = n2 * 128ull + (uint64_t)c2[CT_B_LIST] * (sizeof(BndPatch) + 2ull * FSV_BND_HALF);
         }
     }
+    // the sketch reads the packed bases of the reads it sketches and writes 16 B per minimizer it produces ("len/4
+    // in + 16 B / minimizer out"); k_uniq reads those and writes the unique ones twice (sorted by hash, sorted by position).
+    // Round 2 charged 16 B per slot of CAPACITY (one per base) -- seven times what the counters saw.
+    for (size_t i = 0; i < W.sk_rec.size() && i <= (size_t)P.n_rounds; i++) {
+        const uint32_t *c = h_ct.data() + i * CT_SLOT;
+        const uint64_t raw = (uint64_t)c[CT_MZRAW_LO] | (uint64_t)c[CT_MZRAW_HI] << 32, bases = (uint64_t)c[CT_BASES_LO] | (uint64_t)c[CT_BASES_HI] << 32;
+        W.kt.recs[W.sk_rec[i]].bytes = bases / 4 + raw * sizeof(fsv_mz);
+        if (i < W.uq_rec.size()) W.kt.recs[W.uq_rec[i]].bytes = raw * sizeof(fsv_mz) + mz_total[i] * 2 * sizeof(fsv_mz);
+    }
     for (size_t i = 0; i < W.chain_rec.size(); i++) {
         const uint32_t *c = h_ct.data() + i * CT_SLOT;
         W.kt.recs[W.chain_rec[i]].bytes = mz_total[i] * 32ull + (uint64_t)B.n_pairs * sizeof(fsv_ovl) + (i < (size_t)P.n_rounds ? (uint64_t)c[CT_TASKS] * sizeof(fsv_wtask) : 0ull);
@@ -1079,7 +1098,7 @@ static void set_cost(const fsv_readsets *sets, uint32_t s, uint64_t &tasks, uint
     pairs = ns > 1 ? ns * (ns - 1) : 0;
 }
 
-extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params *params, fsv_contigs *out)
+static int fsv_assemble_batch_impl(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params *params, fsv_contigs *out)
 {
     if (!ctx || !sets || !out || !sets->store_dev || !sets->word_off || !sets->read_len || !sets->set_start) return FSV_EINVAL;
     if (!out->seq || !out->off || !out->set || !out->n_reads || !out->set_status) return FSV_EINVAL;
@@ -1100,8 +1119,18 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     // beyond the budget (FSV_ASM_BUDGET_GB, default 40 % of the device's memory: ~200 B per window task (400 with the second consensus pass), ~200 B per read pair,
     // ~48 B per base) -- is cut into runs of consecutive sets that go through one after the other; the caller sees one call.
     // (Round 1 returned FSV_EUNSUP and left the splitting to the caller.)
+    // The default budget: 40 % of the device's memory, but never more than this context's share of what is FREE -- the free bytes
+    // plus what this context's own workspace already holds, divided among the contexts alive on the device (three lanes of one
+    // process used to be allowed 120 % between them, and a chromosome-sized batch failed in hipMalloc instead of being split).
     const char *env = getenv("FSV_ASM_BUDGET_GB");
-    const double budget = (env && atof(env) > 0 ? atof(env) : 0.4 * (double)ctx->hbm_bytes / 1e9) * 1e9;
+    double budget = 0.4 * (double)ctx->hbm_bytes;
+    {
+        size_t free_b = 0, total_b = 0, own = 0;
+        for (DevBuf *b : W.all()) own += b->cap;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            budget = std::min(budget, 0.8 * ((double)free_b + (double)own) / (double)std::max(1, fsv_live_contexts(ctx->device)));
+    }
+    if (env && atof(env) > 0) budget = atof(env) * 1e9;
     std::vector<uint32_t> cut{0};
     {
         uint64_t tk = 0, pr = 0, bs = 0;
@@ -1125,7 +1154,12 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
         std::vector<uint32_t> sub_start(s1 - s0 + 1);
         for (uint32_t s = s0; s <= s1; s++) sub_start[s - s0] = sets->set_start[s] - r0;
         fsv_readsets sub = *sets;
-        sub.word_off = sets->word_off + r0; sub.read_len = sets->read_len + r0; sub.set_start = sub_start.data();
+        // the chunk sees a store of its own: offsets relative to its first read (with the caller's absolute offsets a late chunk's
+        // second pass copied the whole store prefix in front of it, and offsets beyond 2^32 words made it fail -- ADVICE r02)
+        std::vector<uint64_t> sub_woff((size_t)(r1 - r0) + 1);
+        for (uint32_t r = r0; r <= r1; r++) sub_woff[r - r0] = sets->word_off[r] - sets->word_off[r0];
+        sub.store_dev = sets->store_dev + sets->word_off[r0];
+        sub.word_off = sub_woff.data(); sub.read_len = sets->read_len + r0; sub.set_start = sub_start.data();
         sub.n_reads = r1 - r0; sub.n_sets = s1 - s0; sub.set_flags = sets->set_flags ? sets->set_flags + s0 : nullptr;
         fsv_contigs part = *out;
         part.seq = out->seq + used; part.seq_cap = out->seq_cap - used; part.off = out->off + nc; part.set = out->set + nc; part.n_reads = out->n_reads + nc;
@@ -1170,7 +1204,7 @@ extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const 
     return FSV_OK;
 }
 
-extern "C" int fsv_asm_fetch_reads(fsv_ctx *ctx, char *seq, uint64_t seq_cap, uint64_t *off, uint32_t n_reads)
+static int fsv_asm_fetch_reads_impl(fsv_ctx *ctx, char *seq, uint64_t seq_cap, uint64_t *off, uint32_t n_reads)
 {
     if (!ctx || !ctx->asm_ws || !seq || !off) return FSV_EINVAL;
     AsmWs &W = *(AsmWs *)ctx->asm_ws;
@@ -1194,7 +1228,7 @@ extern "C" int fsv_asm_fetch_reads(fsv_ctx *ctx, char *seq, uint64_t seq_cap, ui
     return rc;
 }
 
-extern "C" int fsv_sketch_reads(fsv_ctx *ctx, const fsv_readsets *sets, int32_t w, int32_t k, int32_t hpc, int32_t variant, fsv_mz *out_mz,
+static int fsv_sketch_reads_impl(fsv_ctx *ctx, const fsv_readsets *sets, int32_t w, int32_t k, int32_t hpc, int32_t variant, fsv_mz *out_mz,
                                 uint64_t out_cap, uint64_t *out_off)
 {
     if (!ctx || !sets || !sets->store_dev || !sets->word_off || !sets->read_len || !out_mz || !out_off) return FSV_EINVAL;
@@ -1258,4 +1292,27 @@ extern "C" int fsv_sketch_reads(fsv_ctx *ctx, const fsv_readsets *sets, int32_t 
     for (uint32_t r = 0; r < B.n_reads; r++)
         std::sort(out_mz + out_off[r], out_mz + out_off[r + 1], [](const fsv_mz &a, const fsv_mz &b) { return a.pos < b.pos; });
     return FSV_OK;
+}
+
+// ---- the guarded C entry points (FSV_GUARD: no C++ exception crosses the boundary)
+extern "C" int fsv_assemble_batch(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_params *params, fsv_contigs *out)
+{
+    FSV_GUARD(ctx, fsv_assemble_batch_impl(ctx, sets, params, out));
+}
+
+extern "C" int fsv_bpm_paths(fsv_ctx *ctx, const uint32_t *store, size_t store_words, const fsv_wtask *tasks, uint32_t n_tasks,
+                             fsv_wres *res, fsv_wpath *paths)
+{
+    FSV_GUARD(ctx, fsv_bpm_paths_impl(ctx, store, store_words, tasks, n_tasks, res, paths));
+}
+
+extern "C" int fsv_asm_fetch_reads(fsv_ctx *ctx, char *seq, uint64_t seq_cap, uint64_t *off, uint32_t n_reads)
+{
+    FSV_GUARD(ctx, fsv_asm_fetch_reads_impl(ctx, seq, seq_cap, off, n_reads));
+}
+
+extern "C" int fsv_sketch_reads(fsv_ctx *ctx, const fsv_readsets *sets, int32_t w, int32_t k, int32_t hpc, int32_t variant, fsv_mz *out_mz,
+                                uint64_t out_cap, uint64_t *out_off)
+{
+    FSV_GUARD(ctx, fsv_sketch_reads_impl(ctx, sets, w, k, hpc, variant, out_mz, out_cap, out_off));
 }

@@ -226,6 +226,7 @@ __device__ __forceinline__ void uniq_read(const uint32_t r, fsv_mz *__restrict__
     { const uint32_t raw = mz_cnt[r]; if (raw <= lo_cnt || raw > hi_cnt) return; }
     fsv_mz *a = mz + mz_off[r];
     uint32_t n = min(mz_cnt[r], mz_off[r + 1] - mz_off[r]); // k_sketch counts past the cap when it truncates
+    const uint32_t n_raw = n;
     if (n > UQ_MAX) { if (tid == 0) atomicOr(&warn[r], (uint32_t)FSV_W_MZ_TRUNC); n = UQ_MAX; }
     uint32_t np = 1;
     while (np < n) np <<= 1;
@@ -271,7 +272,11 @@ __device__ __forceinline__ void uniq_read(const uint32_t r, fsv_mz *__restrict__
         uint32_t acc = 0;
         for (int i = 0; i < 256; i++) { uint32_t c = s_scan[i]; s_scan[i] = acc; acc += c; }
         mz_cnt[r] = acc;
-        if (total) atomicAdd(total, (unsigned long long)acc);   // statistics: unique minimizers of the launch
+        if (total) {   // statistics of the launch: unique minimizers; minimizers the sketch produced; bases of the reads it sketched
+            atomicAdd(total, (unsigned long long)acc);
+            atomicAdd(total + 3, (unsigned long long)n_raw);                                     // CT_MZRAW (asm.hip)
+            atomicAdd(total + 4, (unsigned long long)(mz_off[r + 1] - mz_off[r] - 64u));         // CT_BASES: a slot holds len + 64 entries
+        }
     }
     __syncthreads();
     const uint32_t m = mz_cnt[r];
@@ -1103,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ dp_xwide = nullptr,
                                                    uint32_t *__restrict__ dp_count_xwide = nullptr)
 {
-    if (n_dev) n_tasks = *n_dev;   // the grid covers the task bound; the count stays on the device (no host round trip)
+    if (n_dev) n_tasks = min(*n_dev, n_tasks);   // the grid covers the task bound; the count stays on the device (no host round trip), clamped to the bound
     uint32_t blk;
     if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
     const uint32_t tid = blk * blockDim.x + threadIdx.x;
@@ -2687,7 +2692,7 @@ struct BndArgs {
 
 __global__ __launch_bounds__(256) void k_bnd_tasks(BndArgs A)
 {
-    const uint32_t n_tasks = *A.n_tasks;
+    const uint32_t n_tasks = min(*A.n_tasks, gridDim.x * blockDim.x);   // the grid covers the task bound
     uint32_t blk;
     if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
     const uint32_t ti = blk * blockDim.x + threadIdx.x;

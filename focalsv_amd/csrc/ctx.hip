@@ -1,7 +1,12 @@
 // ctx.hip -- context, error strings, raw memory helpers and the K0 host packer.
 #include "fsv_internal.h"
 #include <string.h>
+#include <atomic>
 #include <new>
+
+// contexts alive per device: a context sizes its workspace budget from the device's free memory divided among them
+static std::atomic<int> g_live_ctx[64];
+int fsv_live_contexts(int device) { return device >= 0 && device < 64 ? g_live_ctx[device].load() : 1; }
 
 extern "C" {
 
@@ -17,6 +22,7 @@ const char *fsv_strerror(int code)
     case FSV_EHIP: return "HIP runtime error";
     case FSV_ECAP: return "caller buffer too small";
     case FSV_EUNSUP: return "unsupported input";
+    case FSV_EINTERNAL: return "internal error (an invariant did not hold, or a C++ exception was caught at the boundary)";
     default: return "unknown error";
     }
 }
@@ -43,6 +49,7 @@ int fsv_ctx_create(int device, fsv_ctx **out)
         return FSV_EHIP;
     }
     c->own_stream = true;
+    if (device < 64) g_live_ctx[device]++;
     *out = c;
     return FSV_OK;
 }
@@ -59,6 +66,7 @@ void fsv_ctx_destroy(fsv_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
+    if (ctx->device >= 0 && ctx->device < 64) g_live_ctx[ctx->device]--;
     delete ctx;
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include "focalsv_hip.h"
@@ -53,6 +55,16 @@ __device__ __forceinline__ uint32_t fsv_base_at(const uint32_t *__restrict__ sto
     uint32_t b = fsv_base_fwd(store, word_off, q);
     return rev ? (3u - b) : b;
 }
+
+int fsv_live_contexts(int device);   // ctx.hip: contexts alive on a device
+
+// the C entry points never let a C++ exception through (a std::bad_alloc from a vector sized by caller data, a std::system_error
+// from a thread that could not start, would otherwise terminate a Python process that came in through ctypes)
+#define FSV_GUARD(ctx, call)                                                            \
+    try { return (call); }                                                              \
+    catch (const std::bad_alloc &) { return fsv_fail(ctx, FSV_ENOMEM, "out of host memory"); } \
+    catch (const std::exception &e) { if (ctx) (ctx)->last_error = std::string("exception: ") + e.what(); return FSV_EINTERNAL; } \
+    catch (...) { return fsv_fail(ctx, FSV_EINTERNAL, "unknown exception"); }
 
 static inline unsigned fsv_grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 

@@ -22,7 +22,7 @@ namespace {
 __global__ __launch_bounds__(256) void k5_bpm_kernel(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
                                                      uint32_t n_tasks, fsv_wres *__restrict__ res, const uint32_t *__restrict__ n_dev)
 {
-    if (n_dev) n_tasks = *n_dev;   // the grid covers the task bound; the count stays on the device
+    if (n_dev) n_tasks = min(*n_dev, n_tasks);   // the grid covers the task bound; the count stays on the device (and is clamped to the bound: k_chain leaves it above the bound on overflow)
     uint32_t blk;
     if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
     const uint32_t tid = blk * blockDim.x + threadIdx.x;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k5_bpm_wide_kernel(const uint32_t *__rest
                                                           uint32_t n_tasks, fsv_wres *__restrict__ res, const uint32_t *__restrict__ n_dev, int k_cap)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_dev) n_tasks = *n_dev;
+    if (n_dev) n_tasks = min(*n_dev, n_tasks);
     if (tid >= n_tasks) return;
     const fsv_wtask t = tasks[tid];
     fsv_wres r;

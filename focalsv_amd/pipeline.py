@@ -8,6 +8,7 @@ collective while computing); `gather_vcf` is the one exchange step -- the analog
 (focalsv/focalsv.py:66-70) -- an all-gather of per-rank VCF bytes (RCCL on GPUs, gloo in the CPU tests).
 """
 import logging
+import os
 import threading
 import time
 from dataclasses import dataclass, field
@@ -399,13 +400,40 @@ def run_stream(ctxs: Sequence[_lib.Context], batches, on_result=None, static: bo
     # A lane thread spends its time inside library calls (GIL released) and needs the GIL for microseconds between them, while the
     # host-half and read-side threads run pure Python.  With CPython's default 5 ms switch interval every such hand-over can cost the
     # lane up to 5 ms of GPU idle time -- three or four per batch; a short interval makes the Python threads yield promptly.
-    import sys
-    old_interval = sys.getswitchinterval()
-    sys.setswitchinterval(2e-4)
+    # The interval is process-wide: it is set by the first run_stream that enters and restored by the last one that leaves, so
+    # overlapping calls (one per chromosome on different threads) cannot restore it in the wrong order; FSV_SWITCH_INTERVAL=0
+    # leaves the interpreter's own value alone.
+    _switch_interval_enter()
     try:
         return _run_stream(ctxs, batches, on_result, static, stagger, host_workers, keep_results, lanes, **kw)
     finally:
-        sys.setswitchinterval(old_interval)
+        _switch_interval_leave()
+
+
+_switch_lock = threading.Lock()
+_switch_users = 0
+_switch_saved = None
+
+
+def _switch_interval_enter():
+    global _switch_users, _switch_saved
+    import sys
+    want = float(os.environ.get("FSV_SWITCH_INTERVAL", "2e-4"))
+    with _switch_lock:
+        if _switch_users == 0 and want > 0:
+            _switch_saved = sys.getswitchinterval()
+            sys.setswitchinterval(want)
+        _switch_users += 1
+
+
+def _switch_interval_leave():
+    global _switch_users, _switch_saved
+    import sys
+    with _switch_lock:
+        _switch_users -= 1
+        if _switch_users == 0 and _switch_saved is not None:
+            sys.setswitchinterval(_switch_saved)
+            _switch_saved = None
 
 
 def _run_stream(ctxs, batches, on_result, static, stagger, host_workers, keep_results, lanes, **kw):

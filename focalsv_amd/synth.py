@@ -186,6 +186,8 @@ def make_region(i: int, width: int = 50_000, profile: str = "hifi", depth_per_ha
         if tandem is not None:
             # VNTR contraction: delete whole repeat units inside the block (gap placement is ambiguous there)
             units = max(1, min(dlen // tandem[1], 1500 // tandem[1]))
+            while units * tandem[1] < 30:      # never below the 30 bp the reference calls (extract_contig_signature_CCS.py:351): one unit of 26-29 bases was
+                units += 1
             dlen = units * tandem[1]
             dpos = tandem[0] + tandem[1] * int(rng.integers(1, max(2, (2000 - dlen) // tandem[1] - 1)))
         if abs(ipos - dpos) >= edge and abs(ipos - (dpos + dlen)) >= edge:

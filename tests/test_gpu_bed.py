@@ -176,3 +176,62 @@ def test_a_batch_beyond_the_budget_is_split_by_sets(monkeypatch):
     assert one.raw_lines == many.raw_lines and one.lines == many.lines and len(one.lines) > 20
     assert list(one.set_status) == list(many.set_status)
     assert many.asm_stats["n_windows"] == one.asm_stats["n_windows"]
+
+
+def test_whole_genome_bed_sample_through_the_region_queue():
+    """BASELINE.json configs[3] on a sample: every 13th line of the whole-genome auto-mode BED (2 000 of 26 834, the 1 146 440 bp
+    line included) through `bench.py --workload bed` -- RegionQueue, three lanes, read stores uploaded per batch, one VCF gather.
+    Every planted SV back at +-1 bp with exact length and genotype, nothing else called, no region failed.  (The run over all
+    26 834 lines is committed under profiles/; it needs minutes of host-side read synthesis.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "bed", "--bed", "genome", "--bed-limit", "2000"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    doc = json.loads(p.stdout.strip().splitlines()[-1])
+    assert doc["n_gpus"] == 1 and doc["ranks"][0]["regions"] == 2000 and doc["regions_failed"] == 0
+    assert "1176440" in doc["config"]["workload"]          # the widest line + its margins is in the sample
+    sv = doc["sv_vs_truth"]
+    assert sv["truth"] >= 4000 and sv["tp"] == sv["truth"] == sv["gt_ok"] and sv["fp"] == 0 and sv["fn"] == 0, sv
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    json.dump(doc, open(os.path.join(root, "gpurun_out", "bed_genome2000_n1.json"), "w"), indent=1)
+
+
+def _nccl_gather_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    lines = {0: ["chr21\t500\ta\tA\tAT\t20\tPASS\tSVLEN=1;SVTYPE=INS\tGT\t0/1\n", "chr2\t9\tb\tAT\tA\t20\tPASS\tSVLEN=-1;SVTYPE=DEL\tGT\t1/1\n"],
+             1: ["chr21\t20\tc\tA\tAT\t20\tPASS\tSVLEN=1;SVTYPE=INS\tGT\t0/1\n"]}.get(rank, [])
+    out = pipeline.gather_vcf(lines, device=torch.device("cuda", rank))
+    empty = pipeline.gather_vcf([] if rank else ["chrX\t1\td\tA\tAT\t20\tPASS\tSVLEN=1;SVTYPE=INS\tGT\t0/1\n"], device=torch.device("cuda", rank))
+    q.put((rank, out, empty))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_vcf_over_rccl_with_two_gpus():
+    """the one exchange step of the multi-GPU path on its real backend: two ranks, one GPU each, `nccl` (= RCCL over xGMI).
+    Needs two visible GPUs: skipped on the one-GPU box (the gloo rehearsal of the same function is tests/test_distributed.py)."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL between two ranks); this box has %d" % torch.cuda.device_count())
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_nccl_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {r: (o, e) for r, o, e in (q.get(timeout=300) for _ in range(2))}
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    assert [l.split('\t')[2] for l in res[0][0]] == ["b", "c", "a"]  # chr2 before chr21, then by position
+    assert [l.split('\t')[2] for l in res[0][1]] == ["d"]
