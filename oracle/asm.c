@@ -1146,16 +1146,22 @@ void orc_asm_default_params(orc_asm_params *P)
     P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->partition = 1;
     P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1; P->ins_dag = 1;
+    P->min_anchors_final = 1; P->min_ovlp_final = 1; P->graph_layout = 1;
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),
  * and inexact ones that the last correction round had verified for the same ordered pair and strand with about the same
  * coordinates (update_overlaps: both ends of either read within 10 % of the longer span).  Pairs without an exact overlap are
  * re-chained with hifiasm's final bandwidth (0.001) to get gapped coordinates.  Returns the hits in ov[]. */
-static int final_overlaps(const readset *R, const orc_asm_params *P, const orc_ovl *prev, int n_prev, orc_ovl **out)
+static int final_overlaps(const readset *R, const orc_asm_params *P0, const orc_ovl *prev, int n_prev, orc_ovl **out)
 {
     orc_mz **uq; int *nuq, n_ov, i, m = 0;
     orc_ovl *ov; int32_t *cq, *ct;
+    orc_asm_params Pf = *P0;
+    const orc_asm_params *P = &Pf;
+    /* hifiasm's final pass keeps every pair that shares a minimizer on a strand, whatever the length of the overlap */
+    Pf.min_anchors = P0->min_anchors_final > 0 ? P0->min_anchors_final : P0->min_anchors;
+    Pf.min_ovlp = P0->min_ovlp_final > 0 ? P0->min_ovlp_final : P0->min_ovlp;
     sketch_set(R, P, P->w_later > 0 ? P->w_later : P->w, &uq, &nuq);
     collect_overlaps(R, P, P->bw_final, uq, nuq, &ov, &cq, &ct, &n_ov);
     for (i = 0; i < n_ov; i++) {
@@ -1309,7 +1315,11 @@ int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const o
     piece_len = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 1));
     piece_rev = (uint8_t *)malloc((size_t)n_reads + 1);
     contig_first = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_reads + 2));
-    nc = orc_layout(R.len, n_reads, hits, n_hit, P->min_contig_reads, piece_read, piece_rev, piece_len, contig_first, n_reads, contig_cap < n_reads ? contig_cap : n_reads);
+    if (P->graph_layout)
+        nc = orc_layout_graph((const char *const *)R.seq, R.len, n_reads, hits, n_hit, P->min_contig_reads, piece_read, piece_rev, piece_len, contig_first,
+                              n_reads, contig_cap < n_reads ? contig_cap : n_reads);
+    else
+        nc = orc_layout(R.len, n_reads, hits, n_hit, P->min_contig_reads, piece_read, piece_rev, piece_len, contig_first, n_reads, contig_cap < n_reads ? contig_cap : n_reads);
     for (c = 0; c < nc; c++) {
         contig_off[c] = used;
         for (i = contig_first[c]; i < contig_first[c + 1]; i++) {

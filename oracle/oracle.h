@@ -38,6 +38,10 @@ typedef struct {
     int32_t w_later;          /* minimizer window from the second correction round on (0 = w throughout, as hifiasm) */
     int32_t second_round;     /* 1: the junctions between grid windows get a second consensus (process_boundary, Correct.cpp:4453) */
     int32_t ins_dag;          /* 1: inserted strings that disagree go through hifiasm's DAG (build_DAGCon); 0: the most frequent string (ONT profile) */
+    int32_t min_anchors_final;/* shortest chain of the final overlap pass: 1 -- hifiasm keeps every (target, strand) group that shares a minimizer
+                                 (calculate_overlap_region_by_chaining, Hash_Table.cpp:684-745: no minimum) */
+    int32_t min_ovlp_final;   /* shortest final overlap: 1 (the graph drops what is below 50 bases: ma_hit_cut) */
+    int32_t graph_layout;     /* 1: the layout as hifiasm's string graph + unitig polishing (oracle/layout.c); 0: best-buddy chains (ONT profile) */
 } orc_asm_params;
 
 typedef struct {
@@ -70,6 +74,8 @@ int orc_unique_sorted(orc_mz *mz, int n);
 int orc_chain_pair(const orc_mz *q, int nq, int lenq, const orc_mz *t, int nt, int lent, const orc_asm_params *P,
                    int bw_per_mille, orc_ovl *o, int32_t *chain_qe, int32_t *chain_te, int chain_cap);
 void orc_asm_default_params(orc_asm_params *P);
+int orc_layout_graph(const char *const *seq, const int *len, int n, const orc_ovl *hit, int n_hit, int min_reads, int32_t *piece_read,
+                     uint8_t *piece_rev, int32_t *piece_len, int32_t *contig_first, int piece_cap, int contig_cap);
 /* whole path for one read set; see oracle/asm.c */
 int orc_assemble(const char *seqs, const uint64_t *seq_off, int n_reads, const orc_asm_params *P,
                  char *contigs, uint64_t contigs_cap, uint64_t *contig_off, int contig_cap, int *n_contigs,

@@ -89,7 +89,8 @@ def sketch(seq: str, w=51, k=51, hpc=1):
 
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "partition",
-                                         "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "second_round", "ins_dag")]
+                                         "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "second_round", "ins_dag",
+                                         "min_anchors_final", "min_ovlp_final", "graph_layout")]
 
 
 def default_params():
@@ -106,6 +107,7 @@ def ont_params():
     p.partition = 0
     p.second_round = 0
     p.ins_dag = 0
+    p.min_anchors_final, p.min_ovlp_final, p.graph_layout = 3, 500, 0     # the ONT profile keeps the layout it was tuned with
     return p
 
 
