@@ -27,7 +27,8 @@ assert WPATH_DTYPE.itemsize == 128
 
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final",
-                                         "min_contig_reads", "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "partition", "second_round", "ins_dag")]
+                                         "min_contig_reads", "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "partition", "second_round", "ins_dag",
+                                         "min_anchors_final", "min_ovlp_final", "graph_layout")]
 
 
 class ReadSets(C.Structure):

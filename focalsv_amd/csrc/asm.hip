@@ -5,6 +5,7 @@
 // kernels of asm_kernels.h; the host only sizes buffers between stages and walks the (tiny, <= a few
 // hundred nodes per set) overlap graph, which is host code in hifiasm as well (Overlaps.cpp).
 #include "asm_kernels.h"
+#include "layout.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -353,6 +354,7 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
     p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0; p->partition = 1; p->second_round = 1; p->ins_dag = 1;
+    p->min_anchors_final = 1; p->min_ovlp_final = 1; p->graph_layout = 1;
 }
 
 extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
@@ -368,6 +370,7 @@ extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
     p->second_round = 0;                        // the junction vote: what the ONT outcome was validated with (and a third less work)
     p->ins_dag = 0;                             // at 10 % error nearly every column has inserted strings that disagree: the most frequent one, per lane
     p->min_contig_reads = 2;                    // reads of 10-30 kb tile a 50 kb window with three or four uncontained reads: hifiasm's tip rule (4) would drop them
+    p->min_anchors_final = 0; p->min_ovlp_final = 0; p->graph_layout = 0;   // the layout this profile was validated with
 }
 
 extern "C" int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap)
@@ -878,7 +881,11 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     const int w_final = P.w_later > 0 ? P.w_later : P.w;
     // (the final pass keeps the lists of unchanged reads only when the last round sketched with the same window)
     const bool keep_lists = P.n_rounds > 0 && (P.n_rounds > 1 || w_final == P.w);
-    TRY(overlap_stage(ctx, W, B, G, store, P, P.bw_final, false, 0, ctf, short_reads, wide_bands && w_final == P.w, w_final, keep_lists ? (const uint32_t *)W.changed.p : nullptr));
+    // hifiasm's final pass keeps every pair that shares a minimizer on a strand, however short the overlap (the graph sorts them out)
+    fsv_asm_params Pf = P;
+    if (P.min_anchors_final > 0) Pf.min_anchors = P.min_anchors_final;
+    if (P.min_ovlp_final > 0) Pf.min_ovlp = P.min_ovlp_final;
+    TRY(overlap_stage(ctx, W, B, G, store, Pf, P.bw_final, false, 0, ctf, short_reads, wide_bands && w_final == P.w, w_final, keep_lists ? (const uint32_t *)W.changed.p : nullptr));
     trace("overlaps");
     const fsv_hit *hraw = nullptr;
     std::vector<uint32_t> hit_first(B.n_sets + 1, 0);
@@ -958,6 +965,19 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     }
     trace("exact+gather");
 
+    // the unitig polishing compares reads base for base where they are joined by an inexact overlap (low coverage only): the
+    // corrected reads then come to the host too, 2 bits a base (24 MB for 256 regions)
+    std::vector<uint32_t> h_store;
+    if (P.graph_layout && hraw) {
+        bool any_inexact = false;
+        for (uint32_t i = 0; i < hit_first[B.n_sets] && !any_inexact; i++) any_inexact = !(hraw[i].slot >> 31);
+        if (any_inexact) {
+            h_store.resize((size_t)G.word_off[B.n_reads] + 1);
+            FSV_HIP(ctx, hipMemcpyAsync(h_store.data(), store, (size_t)G.word_off[B.n_reads] * 4, hipMemcpyDeviceToHost, ctx->stream));
+            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    const uint8_t *set_flags = sets->set_flags;
     // layout per set (host), then stitch on the device
     std::vector<fsv_piece> pieces;
     uint64_t used = 0;
@@ -974,6 +994,27 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
                 const uint32_t r0 = B.set_start[s], ns = B.set_start[s + 1] - r0;
                 if (ns == 0) continue;
                 const uint32_t nh_s = hit_first[s + 1] - hit_first[s];
+                const bool unphased = set_flags && (set_flags[s] & FSV_SET_UNPHASED);
+                if (P.graph_layout && !unphased) {
+                    // the layout as hifiasm makes it (layout.h)
+                    fsv_layout::ReadBases rb; rb.words = h_store.empty() ? nullptr : h_store.data(); rb.word_off = G.word_off.data() + r0; rb.len = len.data() + r0;
+                    fsv_layout::Graph g(len.data() + r0, (int)ns, rb);
+                    std::vector<fsv_layout::Hit> hs(nh_s);
+                    for (uint32_t i = 0; i < nh_s; i++) {
+                        const fsv_hit &h = hraw[hit_first[s] + i];
+                        const int tl = len[r0 + h.t];
+                        fsv_layout::Hit &x = hs[i];
+                        x.qn = (int32_t)h.q; x.tn = (int32_t)h.t; x.qs = h.x_s; x.qe = h.x_e + 1; x.rev = (uint8_t)h.rev; x.el = (uint8_t)(h.slot >> 31); x.del = 0;
+                        if (h.rev) { x.ts = tl - h.y_e - 1; x.te = tl - h.y_s; } else { x.ts = h.y_s; x.te = h.y_e + 1; }
+                    }
+                    g.set_hits(std::move(hs));
+                    g.build();
+                    std::vector<std::vector<fsv_layout::PieceOut>> cs;
+                    g.unitigs(P.min_contig_reads, cs);
+                    for (auto &c : cs) { std::vector<Piece> pc; for (auto &e : c) pc.push_back(Piece{e.read, e.rev, e.len}); lay[s].contigs.push_back(std::move(pc)); }
+                    lay[s].fallback = cs.empty();
+                    continue;
+                }
                 layout_set(len.data() + r0, ns, hraw + hit_first[s], nh_s, P.min_contig_reads, lay[s].contigs, lay[s].fallback);
             }
         };

@@ -3032,7 +3032,7 @@ __global__ __launch_bounds__(64) void k_bnd_apply(const uint32_t *__restrict__ g
 // The comparison issues four 16-base fetches per lane before it looks at any of them (the early exit costs a memory
 // round trip per test, and most valid overlaps of the final pass are exact).
 // An exact overlap as the host layout reads it (32 B; q, t are read indices inside the set).
-struct fsv_hit { uint32_t q, t; int32_t x_s, x_e, y_s, y_e; uint32_t rev, slot; };
+struct fsv_hit { uint32_t q, t; int32_t x_s, x_e, y_s, y_e; uint32_t rev, slot; };   // slot: the overlap slot; bit 31 set = exact
 
 __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
                                               const int32_t *__restrict__ read_len, const uint32_t *__restrict__ read_set,
@@ -3080,7 +3080,7 @@ __global__ __launch_bounds__(64) void k_exact(const uint32_t *__restrict__ store
     if (lane < 2) {
         const uint32_t slot = lane ? pt.w : pt.z;
         if (lane) o = ovl[slot];
-        fsv_hit h; h.q = o.q; h.t = o.t; h.x_s = o.x_s; h.x_e = o.x_e; h.y_s = o.y_s; h.y_e = o.y_e; h.rev = o.rev; h.slot = slot;
+        fsv_hit h; h.q = o.q; h.t = o.t; h.x_s = o.x_s; h.x_e = o.x_e; h.y_s = o.y_s; h.y_e = o.y_e; h.rev = o.rev; h.slot = slot | 0x80000000u;   // bit 31: an exact overlap (hifiasm's el)
         hits[pair_base[s] + at + lane] = h;
     }
 }

@@ -168,6 +168,12 @@ typedef struct fsv_asm_params {
                                * it -- a quarter faster, same reads after three rounds on all but one of 7 800 golden reads (ONT profile: 0) */
     int32_t ins_dag;          /* 1 (default): inserted strings that disagree go through hifiasm's DAG of inserted strings (build_DAGCon, Correct.cpp:3893);
                                * 0: the most frequent string is inserted (ONT profile) */
+    int32_t min_anchors_final;/* shortest chain of the final overlap pass: 1 -- hifiasm keeps every (target, strand) group that shares a minimizer
+                               * (calculate_overlap_region_by_chaining, Hash_Table.cpp:684-745: no minimum); 0 = min_anchors */
+    int32_t min_ovlp_final;   /* shortest final overlap: 1 (the graph drops what is below 50 bases, ma_hit_cut, Overlaps.cpp:1785); 0 = min_ovlp */
+    int32_t graph_layout;     /* 1 (default): the layout as hifiasm-0.14 makes it -- chimeric-read detection, containment in read order, string graph with
+                               * transitive reduction and tip cutting, unitig polishing (Overlaps.cpp:1698, 1031, 2152, 4531, 4666, 7759, 8480, 8893) --
+                               * for every set that is not flagged FSV_SET_UNPHASED; 0: best-buddy chains (ONT profile, unphased sets) */
 } fsv_asm_params;
 void fsv_asm_default_params(fsv_asm_params *p);
 /* ONT-profile reads (BASELINE configs[4]: ~10 % error): k = 15, w = 15 without homopolymer compression (a 30 kb read then has ~3 750 minimizers: below the 4 096 a list holds), chain indel budget 0.15 / 0.05,
