@@ -454,6 +454,41 @@ static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ov
                 next = u->y_beg + u->end_site - u->extra_begin + 1;
             }
         }
+        /* rescue, left-extension pass (Correct.cpp:2745-2905): a matched window whose left neighbour is unmatched gets its path first
+         * -- its real start on y -- and the unmatched windows to its left are tried again, each placed so that it ends right in
+         * front of the window to its right, with the doubled threshold and its path at once */
+        if (P->left_rescue) for (j = 1; j < o->n_win; j++) {
+            orc_win *w = &W[o->first_win + j];
+            int k2, total_y_end;
+            if (w->err < 0 || W[o->first_win + j - 1].err >= 0) continue;
+            if (!w->pad[0]) { window_path(x, y, ylen, o->rev, w, ybuf, cols, tmp, rl, ro); w->pad[0] = 1; }
+            if (w->err < 0) continue;
+            total_y_end = w->ry_start - 1;
+            for (k2 = j - 1; k2 >= 0 && W[o->first_win + k2].err < 0; k2--) {
+                orc_win *u = &W[o->first_win + k2], trial = *u;
+                trial.k = (uint8_t)orc_double_thr_p(P, u->k, u->x_len);
+                if (total_y_end <= 0) break;
+                trial.y_start = total_y_end - trial.x_len + 1;
+                if (!window_verify(x, y, ylen, o->rev, &trial, ybuf, P->k_cap)) break;
+                if ((trial.x_len + 2 * trial.k - trial.extra_begin - trial.extra_end) + trial.k < trial.x_len) break;
+                if (trial.err < 0) break;
+                window_path(x, y, ylen, o->rev, &trial, ybuf, cols, tmp, rl, ro);
+                if (trial.err < 0) break;
+                trial.rescued = 1; trial.pad[0] = 1;
+                *u = trial;
+                o->align_len += u->x_len;
+                total_y_end = u->ry_start - 1;
+            }
+        }
+        if (getenv("ORC_DEBUG_WIN")) {
+            int dq = -1, dp = -1;
+            sscanf(getenv("ORC_DEBUG_WIN"), "%d,%d", &dq, &dp);
+            if ((int)o->q == dq && o->x_s <= dp && dp <= o->x_e) {
+                fprintf(stderr, "OVL q %u t %u rev %d x [%d,%d] y [%d,%d] nwin %d:", o->q, o->t, o->rev, o->x_s, o->x_e, o->y_s, o->y_e, o->n_win);
+                for (j = 0; j < o->n_win; j++) fprintf(stderr, " %d%s", W[o->first_win + j].err, W[o->first_win + j].rescued ? "r" : "");
+                fprintf(stderr, "  (win of pos: %d)\n", dp / ORC_WINDOW - o->x_s / ORC_WINDOW);
+            }
+        }
         /* accept: 0.9 coverage filter, then error rate <= 0.03 with unmatched windows charged in full */
         o->is_match = 0;
         for (j = 0; j < o->n_win; j++) {
@@ -466,7 +501,7 @@ static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ov
         if (!o->is_match) continue;
         for (j = 0; j < o->n_win; j++) {
             orc_win *w = &W[o->first_win + j];
-            if (w->err >= 0) window_path(x, y, ylen, o->rev, w, ybuf, cols, tmp, rl, ro);
+            if (w->err >= 0 && !w->pad[0]) window_path(x, y, ylen, o->rev, w, ybuf, cols, tmp, rl, ro);
         }
     }
     (void)wi;
@@ -1147,6 +1182,7 @@ void orc_asm_default_params(orc_asm_params *P)
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->partition = 1;
     P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1; P->ins_dag = 1;
     P->min_anchors_final = 1; P->min_ovlp_final = 1; P->graph_layout = 1;
+    P->left_rescue = 0;   /* restated here, not yet in the HIP path: off so that the two stay bit-identical (it changes none of the golden sets) */
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),

@@ -42,6 +42,7 @@ typedef struct {
                                  (calculate_overlap_region_by_chaining, Hash_Table.cpp:684-745: no minimum) */
     int32_t min_ovlp_final;   /* shortest final overlap: 1 (the graph drops what is below 50 bases: ma_hit_cut) */
     int32_t graph_layout;     /* 1: the layout as hifiasm's string graph + unitig polishing (oracle/layout.c); 0: best-buddy chains (ONT profile) */
+    int32_t left_rescue;      /* 1: the rescue pass also walks left from a matched window (recalcate_window_advance, Correct.cpp:2745-2905) */
 } orc_asm_params;
 
 typedef struct {

@@ -157,9 +157,10 @@ def _round_sets(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
 
 
 # After the FIRST round one read of each of these two sets still differs from hifiasm's (after the second round all 88 sets are
-# identical): a read's last base (74); a window hifiasm corrects with a third alignment that its left-extension rescue pass
-# (recalcate_window_advance, Correct.cpp:2745-2905: not restated, it needs the path of the window to its right) supplies (77).
-# Listed so that a fix shows.
+# identical): a read's last base (74: 581/1, read 77); one inserted base in a window six overlaps cover at 8x (77: 590/2, read 19, column
+# 14 055 -- round 3 checked: every window of all six overlaps is matched, so this is a vote, not the left-extension rescue pass round 2
+# suspected; that pass, recalcate_window_advance Correct.cpp:2745-2905, is restated in oracle/asm.c behind orc_asm_params.left_rescue
+# and changes neither set).  Listed so that a fix shows.
 KNOWN_ROUND1_DEVIATIONS = {74, 77}
 
 
