@@ -130,6 +130,7 @@ def load():
         "fsv_bpm_paths": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp]),
         "fsv_asm_default_params": (None, [C.POINTER(AsmParams)]),
         "fsv_asm_ont_params": (None, [C.POINTER(AsmParams)]),
+        "fsv_asm_clr_params": (None, [C.POINTER(AsmParams)]),
         "fsv_assemble_batch_bound": (C.c_int, [C.POINTER(ReadSets), u64p, u32p]),
         "fsv_assemble_batch": (C.c_int, [vp, C.POINTER(ReadSets), C.POINTER(AsmParams), C.POINTER(Contigs)]),
         "fsv_asm_last_stats": (C.c_int, [vp, C.POINTER(AsmStats)]),
@@ -298,6 +299,12 @@ class Context:
         """the error model for ONT-profile reads (fsv_asm_ont_params)"""
         p = AsmParams()
         self._lib.fsv_asm_ont_params(C.byref(p))
+        return p
+
+    def clr_asm_params(self):
+        """the error model for PacBio CLR reads (fsv_asm_clr_params)"""
+        p = AsmParams()
+        self._lib.fsv_asm_clr_params(C.byref(p))
         return p
 
     def upload(self, arr):

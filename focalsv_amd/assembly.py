@@ -116,14 +116,14 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
     if fas and data_type != 0:
         # CLR / ONT: the reference runs Flye on every PS*.fa (run_assembly.py:46-100, output <X>_flye/assembly.fasta; ONT falls back to
         # Shasta, post_assembly.py:43-76).  Here the same assembler as for HiFi runs with the error model opened up
-        # (fsv_asm_ont_params: wide-band K5 / K6) and leaves its contigs where combine_fas_clr / _ont look for Flye's.
+        # (fsv_asm_clr_params / fsv_asm_ont_params: wide-band K5 / K6) and leaves its contigs where combine_fas_clr / _ont look for Flye's.
         # Checkpoint as the reference's: a set whose assembly.fasta exists is skipped (run_assembly.py:65).
         fas = [f for f in fas if not os.path.exists(os.path.join(f[:-3] + "_flye", "assembly.fasta"))] if skip_existing else fas
         sets = [fasta.read_reads(f) for f in fas]
         own = ctx is None
         ctx = ctx or _lib.Context(device)
         try:
-            per_set = assemble_sets(ctx, sets, logger, params=ctx.ont_asm_params())
+            per_set = assemble_sets(ctx, sets, logger, params=ctx.clr_asm_params() if data_type == 1 else ctx.ont_asm_params())
         finally:
             if own:
                 ctx.close()

@@ -373,6 +373,15 @@ extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
     p->min_anchors_final = 0; p->min_ovlp_final = 0; p->graph_layout = 0;   // the layout this profile was validated with
 }
 
+// CLR reads (the reference: `flye --pacbio-raw`, run_assembly.py:46-72): ~12 % error, insertions before deletions before
+// substitutions, reads of 10-25 kb.  Two such reads differ by about a quarter of a window, which the ONT profile's thresholds (k = 93 of
+// 375 columns, overlaps up to 30 % error, 15-mer seeds without homopolymer compression) already hold: the same values, under a name of
+// their own so that the two data types can part ways.  Planted truth on the synthetic CLR profile: tests/test_gpu_ont.py.
+extern "C" void fsv_asm_clr_params(fsv_asm_params *p)
+{
+    fsv_asm_ont_params(p);
+}
+
 extern "C" int fsv_assemble_batch_bound(const fsv_readsets *sets, uint64_t *seq_cap, uint32_t *contig_cap)
 {
     if (!sets || !sets->read_len) return FSV_EINVAL;

@@ -2031,16 +2031,23 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
         const uint32_t ti = oc.y + (uint32_t)j;
         const fsv_wpath *P = A.paths + ti;
         const uint4 h0 = *reinterpret_cast<const uint4 *>(P);                      // ry_start, ry_end, path_len|err, state|rev|pad
-        atomicAdd(&s_cover, 1u);       // get_available_interval (Correct.cpp:113): every accepted overlap that overlaps the window counts, matched there or not
-        if ((h0.w & 0xffu) != 1u) continue;
         const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16); // y_word, y_len
-        // a path at distance 0 is all matches (every window from the second round on, a fifth of them in the first): its 104 op
-        // bytes are not even fetched, it only adds its coverage interval
-        const bool clean_path = (int16_t)(h0.z >> 16) == 0;
-        if (!clean_path) {
+        // In a read somebody deviates from (the only reads that get here) most paths carry deviations, so the 104 op bytes are
+        // requested together with the header: waiting for the header first to learn whether the path is clean cost a second
+        // memory round trip per overlap on the window's critical path
+        uint2 pv[13];
+        {
             const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
 #pragma unroll
-            for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
+            for (int i = 0; i < 13; i++) pv[i] = src[i];
+        }
+        atomicAdd(&s_cover, 1u);       // get_available_interval (Correct.cpp:113): every accepted overlap that overlaps the window counts, matched there or not
+        if ((h0.w & 0xffu) != 1u) continue;
+        // a path at distance 0 is all matches: it only adds its coverage interval
+        const bool clean_path = (int16_t)(h0.z >> 16) == 0;
+        if (!clean_path) {
+#pragma unroll
+            for (int i = 0; i < 13; i++) { s_path[lane][2 * i] = pv[i].x; s_path[lane][2 * i + 1] = pv[i].y; }
         }
         bool dev_here = false;
         const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);

@@ -179,6 +179,10 @@ void fsv_asm_default_params(fsv_asm_params *p);
 /* ONT-profile reads (BASELINE configs[4]: ~10 % error): k = 15, w = 15 without homopolymer compression (a 30 kb read then has ~3 750 minimizers: below the 4 096 a list holds), chain indel budget 0.15 / 0.05,
  * windows up to 25 % apart (k = 93: wide-band K5 / K6), overlaps up to 30 % error.  Parity unpinned: the reference has Flye here. */
 void fsv_asm_ont_params(fsv_asm_params *p);
+/* CLR reads (~12 % error, insertion-rich; the reference: flye --pacbio-raw, run_assembly.py:46-72): the ONT profile's values under a name of
+ * their own.  Parity unpinned (no Flye in the tree or the image); planted truth in tests/test_gpu_ont.py.  Reads above ~32 kb lose the anchors
+ * beyond their first 4 096 minimizers in either profile (set status bits 1 / 2 say so). */
+void fsv_asm_clr_params(fsv_asm_params *p);
 
 typedef struct fsv_mz {       /* ha_mz1_t, htab.h:8-13 */
     uint64_t hash;

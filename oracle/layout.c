@@ -12,7 +12,7 @@
  *   polish_unitig                :8480-8560          (a read joined by an inexact overlap is skipped when its neighbours overlap exactly)
  *   polish_unitig_advance        :8893-8960, get_consensus_rate :8800-8890 (the same from the reads' base-level agreement)
  *   ma_ug_seq                    :8962-9034          (contig = the reads' prefixes)
- * Traced with the reference's own code (tools/trace_graph.md): on read sets of this kind none of clean_graph's other steps
+ * Traced with the reference's own code (oracle/ref_graph_trace.cpp -> oracle/_ref/hifiasm_trace): on read sets of this kind none of clean_graph's other steps
  * (Overlaps.cpp:27087-27350: the four cleaning rounds, bubble popping, the rescue passes) changes the graph, so they are not
  * restated; the complex branch of detect_chimeric_reads (a read whose left and right overlaps meet in fewer than 0.2 % of its
  * length AND some spanning overlap fails a window check there) is taken as "not chimeric": final overlaps are exact or were

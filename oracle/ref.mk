@@ -19,7 +19,7 @@ HA16_OBJ := $(patsubst $(HA16)/%.cpp,$(OUT)/ha16/%.o,$(HA16_SRC)) $(OUT)/ha16/ks
 all: ha14 ha16 harness
 ha14: $(OUT)/hifiasm-0.14
 ha16: $(OUT)/hifiasm-0.16.1
-harness: $(OUT)/ha14_kernels
+harness: $(OUT)/ha14_kernels $(OUT)/hifiasm_trace
 
 $(OUT)/ha14/%.o: $(HA14)/%.cpp
 	@mkdir -p $(@D)
@@ -44,3 +44,8 @@ $(OUT)/hifiasm-0.16.1: $(HA16_OBJ) $(OUT)/ha16/main.o
 # routines; links against the other reference objects.
 $(OUT)/ha14_kernels: oracle/ref_harness.cpp $(filter-out $(OUT)/ha14/Correct.o,$(HA14_OBJ))
 	g++ $(CXXFLAGS) -I$(HA14) -DREF_CORRECT_CPP='"$(HA14)/Correct.cpp"' $^ -o $@ $(LIBS)
+
+# diagnosis: the reference binary with a trace of its graph steps (oracle/ref_graph_trace.cpp includes the reference's Overlaps.cpp
+# as a translation unit and replays clean_graph's call sequence with a dump after each step)
+$(OUT)/hifiasm_trace: oracle/ref_graph_trace.cpp $(filter-out $(OUT)/ha14/Overlaps.o,$(HA14_OBJ)) $(OUT)/ha14/main.o
+	g++ -O1 -msse4.2 -mpopcnt -w -I$(HA14) -DREF_OVERLAPS_CPP='"$(HA14)/Overlaps.cpp"' $^ -o $@ $(LIBS)

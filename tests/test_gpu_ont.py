@@ -102,3 +102,29 @@ def test_insertion_dag_under_stress_equals_the_oracle():
                 k += len(s)
     finally:
         ctx.close()
+
+
+def test_clr_profile_planted_truth():
+    """PacBio CLR-like reads (synth profile "clr": 12 % error, insertions : deletions : substitutions = 55 : 33 : 12, reads of 10-25 kb;
+    the reference runs `flye --pacbio-raw` on them, run_assembly.py:46-72) through the hot path with fsv_asm_clr_params and DipPAV's CLR
+    rules: one contig per read set within 0.2 % of its haplotype's length, the planted SVs back with type, genotype and SVLEN (2 %)
+    within 20 bp, three in four at the exact left-aligned position.  PARITY UNPINNED (no Flye here), as the ONT row."""
+    regions = [synth.make_region(i, width=50000, profile="clr", start=i * 60000) for i in range(12)]
+    with _lib.Context(0) as ctx:
+        b = pipeline.upload_regions(ctx, [pipeline.region_from_synth(r) for r in regions])
+        try:
+            res = pipeline.run_hot_path(ctx, b, asm_params=ctx.clr_asm_params(), data_type='CLR')
+        finally:
+            b.free(ctx)
+    assert (res.set_status == 0).all() and (res.contig_status == 0).all()
+    per = {}
+    for ri, hp, c in res.contigs:
+        per.setdefault((ri, hp), []).append(len(c))
+    for ri, r in enumerate(regions):
+        for h in (0, 1):
+            assert len(per[(ri, h + 1)]) == 1 and abs(per[(ri, h + 1)][0] - len(r.haps[h])) <= len(r.haps[h]) // 500
+    calls = pipeline.parse_calls(res.lines)
+    truth = [(r.chrom, t.svtype, r.start + t.pos_left, t.length, t.gt) for r in regions for t in r.truth]
+    tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=20, len_tol=0.02, left_shift_ok=2000)
+    assert tp >= len(truth) - 1 and fp <= 1 and gt_ok >= tp - 1, (tp, fp, fn, gt_ok, len(truth))
+    assert pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.0)[0] >= len(truth) * 3 // 4
