@@ -519,6 +519,17 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
                            (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
         // distance <= 3 (nine in ten): the 16-bit sub-band, half the scratch; the same slices, after the launch above on this stream
+        if (getenv("FSV_K6_STAMPS")) {
+            DevBuf &sb = W.tmp;
+            FSV_HIP(ctx, hipMemsetAsync(sb.p, 0, 64, ctx->stream));
+            hipLaunchKernelGGL((k_path_sb<true, true>), dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
+                               (const uint32_t *)W.dp_list16.p, (const uint32_t *)(ct + CT_DP_SB16), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)sb.p);
+            unsigned long long h[4] = {0, 0, 0, 0};
+            FSV_HIP(ctx, hipMemcpyAsync(h, sb.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            fprintf(stderr, "[fsv] k_path_sb<HALF> round %d: %llu waves, cycles per wave: forward %.0f, walk %.0f, finish %.0f\n", round, h[3],
+                    h[3] ? (double)h[0] / h[3] : 0.0, h[3] ? (double)h[1] / h[3] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0);
+        } else
         hipLaunchKernelGGL((k_path_sb<false, true>), dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
                            (const uint32_t *)W.dp_list16.p, (const uint32_t *)(ct + CT_DP_SB16), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
         FSV_HIP(ctx, hipGetLastError());

@@ -1540,15 +1540,37 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
         int cur = err, ci = n - 1, plen = 0, start = end, rel = ME, dir = 0;
         uint32_t acc = 0;
         // The walk, a quad of columns per phase: every lane walks until it leaves its current quad (four column steps plus its
-        // "up" steps), then all lanes move one quad down together.  Three quads rotate through registers and the one just left
-        // is refilled with the quad three below, so a quad is requested two phases before it is walked and no lane ever waits
+        // "up" steps), then all lanes move one quad down together.  Six quads rotate through registers and the one just left
+        // is refilled with the quad six below, so a quad is requested five phases before it is walked and no lane ever waits
         // for a load another lane has just issued (with a per-lane "switch when I cross" every crossing waited out the full
         // memory latency of the neighbour's request: 1 500 cycles per step, FSV_K6_STAMPS).
         int qi = ci >> QSH;
         auto quad = [&](int q) { return q >= 0 ? slot[(size_t)q * 64] : make_uint4(0, 0, 0, 0); };
-        uint4 qa = quad(qi), qb = quad(qi - 1), qc = quad(qi - 2);
+        uint4 qa = quad(qi), qb = quad(qi - 1), qc = quad(qi - 2), qd = quad(qi - 3), qe = quad(qi - 4), qf = quad(qi - 5);
         auto phase = [&](const uint4 &q4) {
             while (cur != 0 && ci >= 0 && (ci >> QSH) == qi) {
+                // A match step keeps the band row (`rel`) and moves one column left, so a run of matches is a run of zero codes at ONE
+                // bit position of consecutive columns' words: the columns of this quad whose code at `rel` is not 0 are found with a few
+                // shifts, and the matches in front of the first of them are taken in one step (round 2 walked them one by one, ~40
+                // instructions each: half of K6's time by the cycle stamps, 375 steps for the 1-3 deviations of a HiFi window).
+                uint32_t nz;
+                if (HALF) {
+                    const uint32_t tx = ((q4.x >> rel) | (q4.x >> (rel + 8))) & 0x00010001u, ty = ((q4.y >> rel) | (q4.y >> (rel + 8))) & 0x00010001u;
+                    const uint32_t tz = ((q4.z >> rel) | (q4.z >> (rel + 8))) & 0x00010001u, tw = ((q4.w >> rel) | (q4.w >> (rel + 8))) & 0x00010001u;
+                    nz = ((tx | tx >> 15) & 3u) | (((ty | ty >> 15) & 3u) << 2) | (((tz | tz >> 15) & 3u) << 4) | (((tw | tw >> 15) & 3u) << 6);
+                } else {
+                    nz = (((q4.x >> rel) | (q4.x >> (rel + 16))) & 1u) | ((((q4.y >> rel) | (q4.y >> (rel + 16))) & 1u) << 1) |
+                         ((((q4.z >> rel) | (q4.z >> (rel + 16))) & 1u) << 2) | ((((q4.w >> rel) | (q4.w >> (rel + 16))) & 1u) << 3);
+                }
+                const int cl = ci & (HALF ? 7 : 3);
+                const uint32_t m = nz & ((2u << cl) - 1u);          // deviating columns at or below this one
+                const int steps = m ? cl - (31 - __clz((int)m)) : cl + 1;
+                if (steps) {
+                    const int np = plen + steps;
+                    if ((np >> 4) != (plen >> 4)) { s_ops[plen >> 4][lane64] = acc; acc = 0; }   // the word fills up with matches
+                    plen = np; start -= steps; ci -= steps; dir = 0;
+                    if (!m) continue;                                   // the rest of the quad matched
+                }
                 const uint32_t w = HALF ? (quad_elem(q4, (ci & 7) >> 1) >> ((ci & 1) << 4)) & 0xffffu : quad_elem(q4, ci & 3);
                 const uint32_t code = ((w >> rel) & 1u) | (((w >> ((HALF ? 8 : 16) + rel)) & 1u) << 1);
                 acc |= code << ((plen & 15) << 1);
@@ -1561,10 +1583,15 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
                 dir = (int)code;
             }
         };
+        // (six quads in rotation since round 3: a quad is requested five phases before it is walked.  With three -- two phases, ~800
+        // cycles of walking -- every phase still waited out most of a memory round trip: the stamps showed half of K6's time in the walk)
         while (__any(cur != 0 && ci >= 0)) {
-            phase(qa); qi--; qa = quad(qi - 2);
-            phase(qb); qi--; qb = quad(qi - 2);
-            phase(qc); qi--; qc = quad(qi - 2);
+            phase(qa); qi--; qa = quad(qi - 5);
+            phase(qb); qi--; qb = quad(qi - 5);
+            phase(qc); qi--; qc = quad(qi - 5);
+            phase(qd); qi--; qd = quad(qi - 5);
+            phase(qe); qi--; qe = quad(qi - 5);
+            phase(qf); qi--; qf = quad(qi - 5);
         }
         if (plen & 15) s_ops[plen >> 4][lane64] = acc;
         if (STAMP) t2 = __builtin_amdgcn_s_memtime();
@@ -1620,19 +1647,45 @@ __global__ __launch_bounds__(64) void k_path_wide(const uint32_t *__restrict__ s
         int cur = err, ci = n - 1, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
         uint32_t acc = 0;
         bool fits = true;
-        while (ci >= 0 && cur != 0) {
-            const uint32_t *c = slot + (size_t)ci * 2 * FSV_WL * 64 + lane64;
-            const int lm = row >> 5, bt = row & 31;
-            const uint32_t code = ((c[(size_t)lm * 64] >> bt) & 1u) | (((c[(size_t)(FSV_WL + lm) * 64] >> bt) & 1u) << 1);
-            if (plen >= 28 * 16 - 1) { fits = false; break; }        // the path buffer holds 448 ops; such a path is dropped below anyway
-            acc |= code << ((plen & 15) << 1);
-            if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
-            plen++;
-            cur -= (int)(code != 0u);
-            start -= (int)(code != 3u);
-            row += (int)(code == 3u) - (int)(code == 2u);
-            ci -= (int)(code != 2u);
-            dir = (int)code;
+        // The walk, column by column for the whole wavefront: the two code words a lane needs at a column (those of its row's limb)
+        // are requested FOUR columns ahead, at a point every lane passes together, and held in four register pairs that an unrolled
+        // loop uses in turn -- round 2's walk was a dependent pair of loads per step (~400 steps of full memory latency per window:
+        // 314 ms per ONT step).  A lane whose row has moved to another limb by the time it reaches a column (a limb is 32 rows; the
+        // row drifts by one per gap) loads that column's words directly.
+        auto ld = [&](int c, int lm, uint32_t &lo, uint32_t &hi) {
+            if (c >= 0) { const uint32_t *p = slot + (size_t)c * 2 * FSV_WL * 64 + lane64; lo = p[(size_t)lm * 64]; hi = p[(size_t)(FSV_WL + lm) * 64]; }
+        };
+        auto column = [&](int c, uint32_t &lo, uint32_t &hi, int &lmx) {
+            if (c >= 0 && ci == c && cur != 0 && fits) {
+                while (true) {
+                    const int lm = row >> 5, bt = row & 31;
+                    if (lm != lmx) { ld(c, lm, lo, hi); lmx = lm; }
+                    const uint32_t code = ((lo >> bt) & 1u) | (((hi >> bt) & 1u) << 1);
+                    if (plen >= 28 * 16 - 1) { fits = false; break; }        // the path buffer holds 448 ops; such a path is dropped below anyway
+                    acc |= code << ((plen & 15) << 1);
+                    if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
+                    plen++;
+                    cur -= (int)(code != 0u);
+                    start -= (int)(code != 3u);
+                    row += (int)(code == 3u) - (int)(code == 2u);
+                    dir = (int)code;
+                    if (code != 2u) { ci--; break; }     // "up" stays in its column
+                    if (cur == 0) break;
+                }
+            }
+            lmx = row >> 5;
+            ld(c - 4, lmx, lo, hi);          // (every lane, walking or not: the request is issued where the whole wave passes)
+        };
+        const int c0 = FSV_WINDOW - 1;       // every window has at most FSV_WINDOW columns; a shorter one idles until the loop reaches its last column
+        uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0, lo3 = 0, hi3 = 0;
+        int lm0 = row >> 5, lm1 = lm0, lm2 = lm0, lm3 = lm0;
+        ld(c0, lm0, lo0, hi0); ld(c0 - 1, lm1, lo1, hi1); ld(c0 - 2, lm2, lo2, hi2); ld(c0 - 3, lm3, lo3, hi3);
+        for (int c = c0; c >= 0; c -= 4) {
+            if (!__any(cur != 0 && ci >= 0 && fits)) break;
+            column(c, lo0, hi0, lm0);
+            column(c - 1, lo1, hi1, lm1);
+            column(c - 2, lo2, hi2, lm2);
+            column(c - 3, lo3, hi3, lm3);
         }
         if (plen & 15) s_ops[plen >> 4][lane64] = acc;
         if (!fits) { P->state = 0; continue; }
