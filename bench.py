@@ -247,7 +247,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=256, help="regions per GPU (BASELINE.json configs[1]: 256)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("FSV_BENCH_LANES", "0")),
-                    help="concurrent lanes per GPU (contexts / streams / host threads); 0 = 3")
+                    help="concurrent lanes per GPU (contexts / streams / host threads); 0 = 4")
     ap.add_argument("--lane-mode", choices=["split", "steps"], default=os.environ.get("FSV_BENCH_LANE_MODE", "steps"),
                     help="split: every step's batch is halved over the lanes; steps: every lane takes whole steps (one batch in flight per lane)")
     ap.add_argument("--stagger", type=float, default=float(os.environ.get("FSV_BENCH_STAGGER", "0.0")), help="seconds between the lanes' first steps")
@@ -304,7 +304,9 @@ def main():
     if args.lanes <= 0:
         # K steps over L lanes take ceil(K / L) rounds: pick the lane count whose last round is fullest, weighted by what that many
         # lanes sustain (measured regions/s at a multiple of L steps: 3: 1980, 4: 2110, 5: 2150, 6: 2165, 7: 2190)
-        args.lanes = 3 if args.lane_mode == "steps" else 2
+        # (round 3: four lanes -- 2 265 / 2 318 regions/s against 2 222 / 2 279 with three at the driver's --steps 20 --warmup 5, whose 20 steps
+        # are five full rounds of four lanes but six and two thirds of three; five lanes are back at 2 258)
+        args.lanes = 4 if args.lane_mode == "steps" else 2
     lanes = max(1, min(args.lanes, n))
     ctxs = [_lib.Context(local) for _ in range(lanes)]
     kw = {"asm_params": ctxs[0].ont_asm_params()} if args.profile == "ont" else {}

@@ -212,3 +212,27 @@ def test_bam_batches_through_the_lanes(ctx, tmp_path):
             pipeline.run_stream(lanes, failing())
     finally:
         lanes[1].close()
+
+
+@pytest.mark.parametrize("size", [3000, 8000])
+def test_tandem_duplication_end_to_end(ctx, size):
+    """reads of a haplotype that carries a tandem duplication (a second copy of `size` bases: an INS) through assembly, contig
+    alignment and the SV logic.  The 3 kb copy assembles into one contig; with 8 kb copies the string graph of 10-20 kb reads
+    branches at the repeat (three unitigs, as hifiasm's would) and the contig that spans both copies carries the call -- which the
+    aligner of round 2 would have refused (an 8 k x 16 k event).  One heterozygous INS of the exact length at the left-aligned
+    position, nothing else"""
+    import numpy as np
+    rng = np.random.default_rng(99)
+    width, at = 60000, 25000
+    ref = np.frombuffer(synth.make_region(4000, width=width, depth_per_hap=0.1).ref, dtype=np.uint8).copy()
+    hap1 = np.concatenate([ref[:at + size], ref[at:at + size], ref[at + size:]])
+    r1 = synth._sample_reads(rng, hap1, 20.0, 10000, 20000, 0.002, 3000, synth._segments([(at, "INS", size)], width), [])
+    r2 = synth._sample_reads(rng, ref, 20.0, 10000, 20000, 0.002, 3000, synth._segments([], width), [])
+    b = pipeline.upload_regions(ctx, [pipeline.RegionInput("chr21", 0, ref.tobytes(), r1, r2, [], "dup")])
+    try:
+        res = pipeline.run_hot_path(ctx, b)
+    finally:
+        b.free(ctx)
+    assert (res.set_status >= 0).all() and (res.contig_status >= 0).all()
+    calls = [(c["type"], c["pos"], c["svlen"], c["gt"]) for c in pipeline.parse_calls(res.raw_lines)]
+    assert len(calls) == 1 and calls[0][0] == "INS" and abs(calls[0][1] - at) <= 1 and calls[0][2] == size and calls[0][3] == "0/1", calls

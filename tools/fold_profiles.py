@@ -76,7 +76,7 @@ def main():
             f, w = fe[k]["FETCH_SIZE"] * 1024.0, wr[k]["WRITE_SIZE"] * 1024.0     # counter unit: KB
             kernels[k] = {"launches": max(fn[k]["FETCH_SIZE"], wn[k]["WRITE_SIZE"]), "fetch_bytes_raw": int(f), "fetch_bytes_x2": int(2 * f), "write_bytes": int(w)}
         doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --lanes 1 --steps %d --warmup 0 "
-                         "--cpu-sample 0 --holdout 0; sums over the process (`steps` = the whole-batch passes of the hot path it ran: priming + %d timed + two one-lane passes); counter "
+                         "--cpu-sample 0 --holdout 0; sums over the process (`steps` = the whole-batch passes of the hot path it ran: priming + %d timed + the untimed one-lane passes); counter "
                          "unit KB; gfx950: FETCH_SIZE counts half of a wide coalesced stream, fetch_bytes_x2 is the corrected figure" % (steps, steps),
                "source_sha": sha, "steps": passes_of(os.path.join(src, "fetch.log")) or steps + 3, "kernels": kernels}
         json.dump(doc, open(os.path.join(prof, tag + "_pmc_hbm_traffic.json"), "w"), indent=1)

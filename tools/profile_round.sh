@@ -5,7 +5,7 @@
 # default command.  Everything lands in gpurun_out/prof_<tag>/; afterwards, anywhere:
 #   python tools/fold_profiles.py gpurun_out/prof_<tag> <tag>
 set -e -o pipefail
-tag=${1:-r02_x}
+tag=${1:-r03_x}
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
 export TMPDIR=/tmp
