@@ -1067,7 +1067,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     if (!pieces.empty()) {
         TRY(upload(ctx, W.pieces, pieces));
         TRY(ensure(ctx, W.contig_out, used + 16));
-        W.kt.begin(ctx, KN_STITCH, used * 2);
+        W.kt.begin(ctx, KN_STITCH, used + used / 4);    // 2-bit bases in, ASCII out
         hipLaunchKernelGGL(k_stitch, dim3((uint32_t)pieces.size()), dim3(256), 0, ctx->stream, store, (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const fsv_piece *)W.pieces.p, (char *)W.contig_out.p);
         FSV_HIP(ctx, hipGetLastError());
@@ -1189,7 +1189,7 @@ static int fsv_assemble_batch_impl(fsv_ctx *ctx, const fsv_readsets *sets, const
         size_t free_b = 0, total_b = 0, own = 0;
         for (DevBuf *b : W.all()) own += b->cap;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            budget = std::min(budget, 0.8 * ((double)free_b + (double)own) / (double)std::max(1, fsv_live_contexts(ctx->device)));
+            budget = std::min(budget, 0.9 * ((double)free_b + (double)own) / (double)std::max(1, fsv_live_contexts(ctx->device)));
     }
     if (env && atof(env) > 0) budget = atof(env) * 1e9;
     std::vector<uint32_t> cut{0};
