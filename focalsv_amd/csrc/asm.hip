@@ -1180,16 +1180,17 @@ static int fsv_assemble_batch_impl(fsv_ctx *ctx, const fsv_readsets *sets, const
     // beyond the budget (FSV_ASM_BUDGET_GB, default 40 % of the device's memory: ~200 B per window task (400 with the second consensus pass), ~200 B per read pair,
     // ~48 B per base) -- is cut into runs of consecutive sets that go through one after the other; the caller sees one call.
     // (Round 1 returned FSV_EUNSUP and left the splitting to the caller.)
-    // The default budget: 40 % of the device's memory, but never more than this context's share of what is FREE -- the free bytes
-    // plus what this context's own workspace already holds, divided among the contexts alive on the device (three lanes of one
-    // process used to be allowed 120 % between them, and a chromosome-sized batch failed in hipMalloc instead of being split).
+    // The default budget: 40 % of the device's memory, but never more than what this context can still get -- its own workspace plus
+    // its share of the FREE bytes (divided among the contexts alive on the device; the budgets of all of them then add up to at
+    // most 90 % of what is free plus what they hold).  Three lanes of one process used to be allowed 120 % of the device between them,
+    // and a chromosome-sized batch failed in hipMalloc instead of being split.
     const char *env = getenv("FSV_ASM_BUDGET_GB");
     double budget = 0.4 * (double)ctx->hbm_bytes;
     {
         size_t free_b = 0, total_b = 0, own = 0;
         for (DevBuf *b : W.all()) own += b->cap;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            budget = std::min(budget, 0.9 * ((double)free_b + (double)own) / (double)std::max(1, fsv_live_contexts(ctx->device)));
+            budget = std::min(budget, 0.9 * ((double)free_b / (double)std::max(1, fsv_live_contexts(ctx->device)) + (double)own));
     }
     if (env && atof(env) > 0) budget = atof(env) * 1e9;
     std::vector<uint32_t> cut{0};
