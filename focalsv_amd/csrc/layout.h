@@ -64,10 +64,19 @@ public:
     // hits grouped by query, each group sorted by target (the order hifiasm pushes them in)
     void set_hits(std::vector<Hit> &&h)
     {
-        h_ = std::move(h);
-        std::stable_sort(h_.begin(), h_.end(), [](const Hit &a, const Hit &b) { return a.qn != b.qn ? a.qn < b.qn : a.tn < b.tn; });
-        for (const Hit &x : h_) src_first_[x.qn + 1]++;
+        // counting sort by query, then each query's few dozen hits by target (a pair has one hit: no ties)
+        for (const Hit &x : h) src_first_[x.qn + 1]++;
         for (int i = 0; i < n_; i++) src_first_[i + 1] += src_first_[i];
+        h_.resize(h.size());
+        std::vector<int> at(src_first_.begin(), src_first_.end() - 1);
+        for (const Hit &x : h) h_[at[x.qn]++] = x;
+        for (int q = 0; q < n_; q++)
+            for (int i = src_first_[q] + 1; i < src_first_[q + 1]; i++) {
+                const Hit t = h_[i];
+                int j = i;
+                for (; j > src_first_[q] && h_[j - 1].tn > t.tn; j--) h_[j] = h_[j - 1];
+                h_[j] = t;
+            }
     }
 
     void build()
@@ -140,7 +149,12 @@ private:
     Arc *arc_a(uint32_t v) { return arc_.data() + a_first_[v]; }
     const Arc *arc_a(uint32_t v) const { return arc_.data() + a_first_[v]; }
 
-    Hit *find_hit(int qn, int tn) { for (int i = src_first_[qn]; i < src_first_[qn + 1]; i++) if (h_[i].tn == tn) return &h_[i]; return nullptr; }
+    Hit *find_hit(int qn, int tn)      // a query's hits are sorted by target
+    {
+        int lo = src_first_[qn], hi = src_first_[qn + 1];
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (h_[mid].tn < tn) lo = mid + 1; else hi = mid; }
+        return lo < src_first_[qn + 1] && h_[lo].tn == tn ? &h_[lo] : nullptr;
+    }
     void delete_single_edge(int qn, int tn) { if (Hit *t = find_hit(qn, tn)) t->del = 1; }
     void delete_all_edges(int qn)
     {
