@@ -411,7 +411,7 @@ def main():
         sha = source_sha()
         pmc_name, pmc = newest_profile("_pmc_hbm_traffic.json")
         sq_name, sq = newest_profile("_pmc_sq.json")
-        alias = {"k_sketch": ["k_sketch_fast", "k_sketch"], "k5_bpm": ["k5_bpm_kernel"], "k_path_dp": ["k_path_sb", "k_path_dp", "k_path_indel1"],
+        alias = {"k_sketch": ["k_sketch_fast", "k_sketch"], "k5_bpm": ["k5_bpm_kernel"], "k_path_dp": ["k_path_fr", "k_path_sb", "k_path_dp"],
                  "k_uniq": ["k_uniq", "k_uniq_walk"], "k_chain": ["k_chain", "k_chain_chunks"], "k_consensus": ["k_consensus", "k_consensus_redo", "k_read_dirty"],
                  "k_bnd_tasks": ["k_bnd_tasks", "k_newlen"], "k_bnd_consensus": ["k_bnd_consensus", "k_bnd_apply"]}
 

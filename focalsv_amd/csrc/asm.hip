@@ -53,10 +53,11 @@ struct Span {
 enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4, CT_COLS_HI = 5, CT_DP_WIDE = 6, CT_DP_SB = 7, CT_DP_GEN = 8, CT_DP_XW = 9,
        CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_DP_SB16 = 14, CT_WIDE = 15,
        CT_MZRAW_LO = 16, CT_MZRAW_HI = 17, CT_BASES_LO = 18, CT_BASES_HI = 19,   // k_uniq's other two sums: CT_MZ + 3 and + 4 as 64-bit words
-       CT_SLOT = 20 };
+       CT_DP_FR3 = 20,       // k_path_fr's lists by distance: CT_DP_SB16 (1), CT_DP (2), CT_DP_FR3 (3)
+       CT_SLOT = 22 };      // even: the 64-bit sums stay aligned in every slot
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> sk_rec, uq_rec, chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -71,7 +72,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -407,8 +408,8 @@ static int fsv_bpm_paths_impl(fsv_ctx *ctx, const uint32_t *store, size_t store_
     }
     const int k_cap = kmax > FSV_K_MAX ? kmax : FSV_K_MAX;     // a threshold above 31 anywhere: K5 of the whole list through the wide kernel
     FSV_HIP(ctx, hipSetDevice(ctx->device));
-    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_list2, d_list3, d_list16, d_wide, d_xwide, d_cnt, d_cols, d_cols_sb, d_cols_wide;
-    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_list2, &d_list3, &d_list16, &d_wide, &d_xwide, &d_cnt, &d_cols, &d_cols_sb, &d_cols_wide}) if (b->p) (void)hipFree(b->p); };
+    DevBuf d_store, d_tasks, d_res, d_paths, d_ovl, d_list, d_list2, d_list3, d_list16, d_list_e3, d_wide, d_xwide, d_cnt, d_cols, d_cols_sb, d_cols_wide;
+    auto cleanup = [&]() { for (DevBuf *b : {&d_store, &d_tasks, &d_res, &d_paths, &d_ovl, &d_list, &d_list2, &d_list3, &d_list16, &d_list_e3, &d_wide, &d_xwide, &d_cnt, &d_cols, &d_cols_sb, &d_cols_wide}) if (b->p) (void)hipFree(b->p); };
     int rc = FSV_OK;
     auto run = [&]() -> int {
         std::vector<fsv_wtask> t(tasks, tasks + n_tasks);
@@ -421,28 +422,29 @@ static int fsv_bpm_paths_impl(fsv_ctx *ctx, const uint32_t *store, size_t store_
         TRY(upload(ctx, d_ovl, std::vector<fsv_ovl>{o}));
         TRY(ensure(ctx, d_res, (size_t)n_tasks * sizeof(fsv_wres)));
         TRY(ensure(ctx, d_paths, (size_t)n_tasks * sizeof(fsv_wpath)));
-        for (DevBuf *b : {&d_list, &d_list2, &d_list3, &d_list16, &d_wide, &d_xwide}) TRY(ensure(ctx, *b, (size_t)n_tasks * 4));
+        for (DevBuf *b : {&d_list, &d_list2, &d_list3, &d_list16, &d_list_e3, &d_wide, &d_xwide}) TRY(ensure(ctx, *b, (size_t)n_tasks * 4));
         TRY(ensure(ctx, d_cnt, CT_SLOT * 4));
         uint32_t *ct = (uint32_t *)d_cnt.p;
         FSV_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, CT_SLOT * 4, ctx->stream));
         FSV_HIP(ctx, hipMemsetAsync(d_paths.p, 0, (size_t)n_tasks * sizeof(fsv_wpath), ctx->stream));
         // the same launches as a correction round of fsv_assemble_batch (device-side list lengths, no host round trip in between)
         TRY(fsv_bpm_windows_dev_n(ctx, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, n_tasks, nullptr, (fsv_wres *)d_res.p, k_cap));
+        const PathLists lists{{(uint32_t *)d_list16.p, (uint32_t *)d_list.p, (uint32_t *)d_list_e3.p, (uint32_t *)d_list2.p, (uint32_t *)d_list3.p, (uint32_t *)d_wide.p, (uint32_t *)d_xwide.p},
+                              {ct + CT_DP_SB16, ct + CT_DP, ct + CT_DP_FR3, ct + CT_DP_SB, ct + CT_DP_GEN, ct + CT_DP_WIDE, ct + CT_DP_XW}};
         hipLaunchKernelGGL(k_path_fast, dim3((fsv_grid_for(n_tasks, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_ovl *)d_ovl.p,
-                           (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p, n_tasks, (fsv_wpath *)d_paths.p, (uint32_t *)d_list.p,
-                           ct + CT_DP, (uint32_t *)d_wide.p, ct + CT_DP_WIDE, true, (const uint32_t *)nullptr, (uint32_t *)d_xwide.p, ct + CT_DP_XW);
-        FSV_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(n_tasks, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p,
-                           (const fsv_wres *)d_res.p, (const uint32_t *)d_list.p, 0u, (fsv_wpath *)d_paths.p, (uint32_t *)d_list2.p, ct + CT_DP_SB,
-                           (const uint32_t *)(ct + CT_DP), (uint32_t *)d_list3.p, ct + CT_DP_GEN, (uint32_t *)d_list16.p, ct + CT_DP_SB16);
+                           (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p, n_tasks, (fsv_wpath *)d_paths.p, lists, true, (const uint32_t *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
         const uint32_t grid = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 8u * (uint32_t)ctx->n_cu);
         TRY(ensure(ctx, d_cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
-        hipLaunchKernelGGL((k_path_sb<false, false>), dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+        hipLaunchKernelGGL(k_path_sb<false>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
                            (const uint32_t *)d_list2.p, (const uint32_t *)(ct + CT_DP_SB), (fsv_wpath *)d_paths.p, (uint4 *)d_cols_sb.p, (unsigned long long *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((k_path_sb<false, true>), dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
-                           (const uint32_t *)d_list16.p, (const uint32_t *)(ct + CT_DP_SB16), (fsv_wpath *)d_paths.p, (uint4 *)d_cols_sb.p, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_path_fr<1>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+                           (const uint32_t *)d_list16.p, (const uint32_t *)(ct + CT_DP_SB16), (fsv_wpath *)d_paths.p);
+        hipLaunchKernelGGL(k_path_fr<2>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+                           (const uint32_t *)d_list.p, (const uint32_t *)(ct + CT_DP), (fsv_wpath *)d_paths.p);
+        hipLaunchKernelGGL(k_path_fr<3>, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t *)d_store.p, (const fsv_wtask *)d_tasks.p, (const fsv_wres *)d_res.p,
+                           (const uint32_t *)d_list_e3.p, (const uint32_t *)(ct + CT_DP_FR3), (fsv_wpath *)d_paths.p);
         FSV_HIP(ctx, hipGetLastError());
         const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(n_tasks, 64), 2u * (uint32_t)ctx->n_cu);
         TRY(ensure(ctx, d_cols, (size_t)gridg * 64 * (FSV_WINDOW + 2) * 3 * 8));
@@ -483,19 +485,15 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
                       const uint32_t *n_tasks_dev, uint32_t *ct, int round, bool wide_bands, const fsv_asm_params &P, bool first_pass)
 {
     { const size_t rec_ = W.kt.begin(ctx, KN_PATH_FAST, 0); (first_pass ? W.fast_rec : W.fast2_rec).push_back(rec_); }
+    const PathLists lists{{(uint32_t *)W.dp_list16.p, (uint32_t *)W.dp_list.p, (uint32_t *)W.dp_list_e3.p, (uint32_t *)W.dp_list2.p, (uint32_t *)W.dp_list3.p, (uint32_t *)W.dp_wide.p, (uint32_t *)W.dp_xwide.p},
+                          {ct + CT_DP_SB16, ct + CT_DP, ct + CT_DP_FR3, ct + CT_DP_SB, ct + CT_DP_GEN, ct + CT_DP_WIDE, ct + CT_DP_XW}};
     hipLaunchKernelGGL(k_path_fast, dim3((fsv_grid_for(task_cap, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
-                       tasks, res, task_cap, paths,
-                       (uint32_t *)W.dp_list.p, ct + CT_DP, (uint32_t *)W.dp_wide.p, ct + CT_DP_WIDE, false, n_tasks_dev,
-                       (uint32_t *)W.dp_xwide.p, ct + CT_DP_XW);
+                       tasks, res, task_cap, paths, lists, false, n_tasks_dev);
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
-    // single-indel windows are settled without the DP (k_path_indel1); what is left goes to the sub-band kernel
-    // (distance <= FSV_SB_MAXERR) or to the general one
+    // what the fast paths left: distance <= 3 is walked without the DP matrix (k_path_fr), <= FSV_SB_MAXERR by the sub-band kernel,
+    // the rest by the general one
     { const size_t rec_ = W.kt.begin(ctx, KN_PATH_DP, 0); (first_pass ? W.dp_rec : W.dp2_rec).push_back(rec_); }
-    hipLaunchKernelGGL(k_path_indel1, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, store, tasks,
-                       res, (const uint32_t *)W.dp_list.p, 0u, paths, (uint32_t *)W.dp_list2.p, ct + CT_DP_SB,
-                       (const uint32_t *)(ct + CT_DP), (uint32_t *)W.dp_list3.p, ct + CT_DP_GEN, (uint32_t *)W.dp_list16.p, ct + CT_DP_SB16);
-    FSV_HIP(ctx, hipGetLastError());
     // persistent grids: as many blocks as the device holds at once, each striding through its list, so the column scratch
     // is a fixed few hundred MB whatever the number of windows
     {
@@ -515,24 +513,41 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
             fprintf(stderr, "[fsv] k_path_sb round %d: %llu waves, cycles per wave: forward %.0f, walk %.0f, finish %.0f (grid %u)\n", round, h[3],
                     h[3] ? (double)h[0] / h[3] : 0.0, h[3] ? (double)h[1] / h[3] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0, grid);
         } else
-        hipLaunchKernelGGL((k_path_sb<false, false>), dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
+        hipLaunchKernelGGL(k_path_sb<false>, dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
                            (const uint32_t *)W.dp_list2.p, (const uint32_t *)(ct + CT_DP_SB), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
-        // distance <= 3 (nine in ten): the 16-bit sub-band, half the scratch; the same slices, after the launch above on this stream
-        if (getenv("FSV_K6_STAMPS")) {
-            DevBuf &sb = W.tmp;
-            FSV_HIP(ctx, hipMemsetAsync(sb.p, 0, 64, ctx->stream));
-            hipLaunchKernelGGL((k_path_sb<true, true>), dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
-                               (const uint32_t *)W.dp_list16.p, (const uint32_t *)(ct + CT_DP_SB16), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)sb.p);
-            unsigned long long h[4] = {0, 0, 0, 0};
-            FSV_HIP(ctx, hipMemcpyAsync(h, sb.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            fprintf(stderr, "[fsv] k_path_sb<HALF> round %d: %llu waves, cycles per wave: forward %.0f, walk %.0f, finish %.0f\n", round, h[3],
-                    h[3] ? (double)h[0] / h[3] : 0.0, h[3] ? (double)h[1] / h[3] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0);
-        } else
-        hipLaunchKernelGGL((k_path_sb<false, true>), dim3(grid), dim3(64), 0, ctx->stream, store, tasks, res,
-                           (const uint32_t *)W.dp_list16.p, (const uint32_t *)(ct + CT_DP_SB16), paths, (uint4 *)W.cols_sb.p, (unsigned long long *)nullptr);
-        FSV_HIP(ctx, hipGetLastError());
+        // distance <= 3 (nine in ten): walked without the matrix, a launch per distance
+        {
+            const bool stamps = getenv("FSV_K6_STAMPS") != nullptr;    // diagnostic, never in a measured run
+            auto fr = [&](auto kern, int e, const DevBuf &list, uint32_t *cnt) -> int {
+                int pf = 0;
+                FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, kern, 64, 0));
+                const uint32_t gridf = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, pf) * (uint32_t)ctx->n_cu);
+                if (stamps) { TRY(ensure(ctx, W.tmp, 64)); FSV_HIP(ctx, hipMemsetAsync(W.tmp.p, 0, 64, ctx->stream)); }
+                hipLaunchKernelGGL(kern, dim3(gridf), dim3(64), 0, ctx->stream, store, tasks, res, (const uint32_t *)list.p, (const uint32_t *)cnt, paths,
+                                   (unsigned long long *)(stamps ? W.tmp.p : nullptr));
+                FSV_HIP(ctx, hipGetLastError());
+                if (stamps) {
+                    unsigned long long h[4] = {0, 0, 0, 0};
+                    uint32_t nl = 0;
+                    FSV_HIP(ctx, hipMemcpyAsync(h, W.tmp.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+                    FSV_HIP(ctx, hipMemcpyAsync(&nl, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    fprintf(stderr, "[fsv] k_path_fr<%d> round %d: %u windows, %llu waves (%d per CU), cycles per wave: table %.0f, walk %.0f, finish %.0f\n", e, round, nl, h[3], pf,
+                            h[3] ? (double)h[0] / h[3] : 0.0, h[3] ? (double)h[1] / h[3] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0);
+                }
+                return FSV_OK;
+            };
+            if (stamps) {
+                TRY(fr(k_path_fr<1, true>, 1, W.dp_list16, ct + CT_DP_SB16));
+                TRY(fr(k_path_fr<2, true>, 2, W.dp_list, ct + CT_DP));
+                TRY(fr(k_path_fr<3, true>, 3, W.dp_list_e3, ct + CT_DP_FR3));
+            } else {
+                TRY(fr(k_path_fr<1>, 1, W.dp_list16, ct + CT_DP_SB16));
+                TRY(fr(k_path_fr<2>, 2, W.dp_list, ct + CT_DP));
+                TRY(fr(k_path_fr<3>, 3, W.dp_list_e3, ct + CT_DP_FR3));
+            }
+        }
         // the general kernel's lists are short (rescue windows, distances above 7): two blocks per CU are plenty
         const uint32_t gridg = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 2u * (uint32_t)ctx->n_cu), stride = gridg * 64;
         TRY(ensure(ctx, W.cols, (size_t)stride * (FSV_WINDOW + 2) * 3 * sizeof(uint64_t)));
@@ -736,6 +751,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         TRY(ensure(ctx, W.res, (size_t)task_cap * sizeof(fsv_wres)));
         TRY(ensure(ctx, W.paths, (size_t)task_cap * sizeof(fsv_wpath)));
         TRY(ensure(ctx, W.dp_list, (size_t)task_cap * 4));
+        TRY(ensure(ctx, W.dp_list_e3, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_list2, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_list3, (size_t)task_cap * 4));
         TRY(ensure(ctx, W.dp_list16, (size_t)task_cap * 4));
@@ -1087,29 +1103,29 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         if (sl == P.n_rounds) { W.stats.n_inexact_candidates = c[CT_INEXACT]; break; }
         W.stats.n_windows += c[CT_TASKS];
         W.stats.dp_columns += (uint64_t)c[CT_COLS_LO] | (uint64_t)c[CT_COLS_HI] << 32;      // rescue re-runs (k_rescue_accept)
-        W.stats.n_path_dp += (uint64_t)c[CT_DP_SB] + c[CT_DP_SB16] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW];
-        W.stats.n_path_indel1 += (uint64_t)c[CT_DP] - c[CT_DP_SB] - c[CT_DP_SB16] - c[CT_DP_GEN];
+        W.stats.n_path_dp += (uint64_t)c[CT_DP_SB] + c[CT_DP_SB16] + c[CT_DP] + c[CT_DP_FR3] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW];
+        W.stats.n_path_fr += (uint64_t)c[CT_DP_SB16] + c[CT_DP] + c[CT_DP_FR3];
         // algorithmic bytes of the round's launches, now that the counts are known: a window task is
         // 94 + 102 B of 2-bit operands + 16 B of result; a K6 window leaves a 128 B path record instead;
         // k_chain reads every unique-minimizer list once (two sorted copies, 16 B entries) and writes the overlap slots and
         // the 32 B task records; the consensus reads the path records and writes its corrected windows
-        const uint64_t nt = c[CT_TASKS];
+        const uint64_t nt = c[CT_TASKS], n_dp = (uint64_t)c[CT_DP_SB] + c[CT_DP_SB16] + c[CT_DP] + c[CT_DP_FR3] + c[CT_DP_GEN] + c[CT_DP_WIDE] + c[CT_DP_XW];
         if ((size_t)sl < W.bpm_rec.size()) W.kt.recs[W.bpm_rec[sl]].bytes = nt * 212ull;
         if ((size_t)sl < W.rescue_rec.size()) W.kt.recs[W.rescue_rec[sl]].bytes += nt * 16ull;
-        if ((size_t)sl < W.fast_rec.size()) W.kt.recs[W.fast_rec[sl]].bytes = nt * (16ull + 196ull) + (nt - c[CT_DP] - c[CT_DP_WIDE] - c[CT_DP_XW]) * 128ull;
-        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = ((uint64_t)c[CT_DP] + c[CT_DP_WIDE] + c[CT_DP_XW]) * (196ull + 128ull);   // k_path_indel1's windows included
+        if ((size_t)sl < W.fast_rec.size()) W.kt.recs[W.fast_rec[sl]].bytes = nt * (16ull + 196ull) + (nt - n_dp) * 128ull;
+        if ((size_t)sl < W.dp_rec.size()) W.kt.recs[W.dp_rec[sl]].bytes = n_dp * (196ull + 128ull);
         if ((size_t)sl < W.cons_rec.size()) W.kt.recs[W.cons_rec[sl]].bytes += nt * 128ull;
         // the round's second consensus pass (its counters sit n_rounds + 1 rows further): the junction tasks are window tasks like
         // the first pass's; k_bnd_tasks reads every first-pass task and path record and writes the junction tasks; the junctions'
         // consensus reads their path records and writes a patch per junction
         if ((size_t)sl < W.bnd_rec.size()) {
             const uint32_t *c2 = h_ct.data() + (size_t)(P.n_rounds + 1 + sl) * CT_SLOT;
-            const uint64_t n2 = c2[CT_TASKS], n3 = c2[CT_B_RETRY];
+            const uint64_t n2 = c2[CT_TASKS], n3 = c2[CT_B_RETRY], n_dp2 = (uint64_t)c2[CT_DP_SB] + c2[CT_DP_SB16] + c2[CT_DP] + c2[CT_DP_FR3] + c2[CT_DP_GEN] + c2[CT_DP_WIDE] + c2[CT_DP_XW];
             n_windows2 += n2 + n3;
             W.kt.recs[W.bnd_rec[sl]].bytes = nt * (sizeof(fsv_wtask) + 128ull) + n2 * sizeof(fsv_wtask);
             if ((size_t)sl < W.bpm2_rec.size()) W.kt.recs[W.bpm2_rec[sl]].bytes = (n2 + n3) * 212ull;
-            if ((size_t)sl < W.fast2_rec.size()) W.kt.recs[W.fast2_rec[sl]].bytes = n2 * (16ull + 196ull) + (n2 - c2[CT_DP] - c2[CT_DP_WIDE] - c2[CT_DP_XW]) * 128ull;
-            if ((size_t)sl < W.dp2_rec.size()) W.kt.recs[W.dp2_rec[sl]].bytes = ((uint64_t)c2[CT_DP] + c2[CT_DP_WIDE] + c2[CT_DP_XW]) * (196ull + 128ull);
+            if ((size_t)sl < W.fast2_rec.size()) W.kt.recs[W.fast2_rec[sl]].bytes = n2 * (16ull + 196ull) + (n2 - n_dp2) * 128ull;
+            if ((size_t)sl < W.dp2_rec.size()) W.kt.recs[W.dp2_rec[sl]].bytes = n_dp2 * (196ull + 128ull);
             if ((size_t)sl < W.bndc_rec.size()) W.kt.recs[W.bndc_rec[sl]].bytes = n2 * 128ull + (uint64_t)c2[CT_B_LIST] * (sizeof(BndPatch) + 2ull * FSV_BND_HALF);
         }
     }
@@ -1248,7 +1264,7 @@ static int fsv_assemble_batch_impl(fsv_ctx *ctx, const fsv_readsets *sets, const
         const fsv_asm_stats &st = W.stats;
         total.n_pairs += st.n_pairs; total.n_overlaps += st.n_overlaps; total.n_windows += st.n_windows; total.n_windows_matched += st.n_windows_matched;
         total.n_paths += st.n_paths; total.n_path_dp += st.n_path_dp; total.dp_columns += st.dp_columns; total.algo_bytes += st.algo_bytes;
-        total.n_exact_overlaps += st.n_exact_overlaps; total.n_inexact_candidates += st.n_inexact_candidates; total.n_path_indel1 += st.n_path_indel1;
+        total.n_exact_overlaps += st.n_exact_overlaps; total.n_inexact_candidates += st.n_inexact_candidates; total.n_path_fr += st.n_path_fr;
         total.ms_sketch += st.ms_sketch; total.ms_chain += st.ms_chain; total.ms_verify += st.ms_verify; total.ms_path += st.ms_path;
         total.ms_consensus += st.ms_consensus; total.ms_final += st.ms_final; total.ms_total += st.ms_total;
         total.n_kernels = st.n_kernels;

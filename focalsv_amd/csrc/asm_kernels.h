@@ -25,7 +25,7 @@
 #define FSV_INS_MAXLEN   12
 #define FSV_SB_MAXERR    7   // k_path_sb: distances it holds in one word per column (2 x 7 + 1 rows x 2 bits)
 #define FSV_SB_QUADS ((FSV_WINDOW + 3) / 4)
-#define FSV_SB16_MAXERR  3   // k_path_sb<., true>: distances whose sub-band (2 x 3 + 1 rows x 2 bits) fits 16 bits a column
+#define FSV_FR_MAXERR    3   // k_path_fr: distances it walks without the DP matrix
 #define FSV_EV_CAP_WIDE 2048 // ... for ONT-profile batches (wide bands): ~25 inserted-base events per overlap and window
 #define FSV_EV_CAP     256   // insertion events per grid window (HiFi at 30x: ~8; more sets the read's warning bit 8 and drops the excess)
 
@@ -1100,13 +1100,13 @@ __device__ __forceinline__ uint32_t task_ybase(const uint32_t *__restrict__ stor
 }
 
 // Fast paths of Reserve_Banded_BPM_PATH (Levenshtein_distance.h:516-531): err == 0, or a gap-free placement with
-// exactly err mismatches (try_cigar).  Everything else is queued for the DP kernel.
+// exactly err mismatches (try_cigar).  Everything else is queued for one of the walk kernels.
+struct PathLists {      // task lists and their device-side lengths: 0-2 k_path_fr<1..3>, 3 k_path_sb, 4 k_path_dp<32>, 5 k_path_dp<64>, 6 k_path_wide
+    uint32_t *list[7], *cnt[7];
+};
 __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ store, const fsv_ovl *__restrict__ ovl,
                                                    const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res, uint32_t n_tasks,
-                                                   fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list, uint32_t *__restrict__ dp_count,
-                                                   uint32_t *__restrict__ dp_wide, uint32_t *__restrict__ dp_count_wide, bool write_clean_ops,
-                                                   const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ dp_xwide = nullptr,
-                                                   uint32_t *__restrict__ dp_count_xwide = nullptr)
+                                                   fsv_wpath *__restrict__ paths, PathLists L, bool write_clean_ops, const uint32_t *__restrict__ n_dev)
 {
     if (n_dev) n_tasks = min(*n_dev, n_tasks);   // the grid covers the task bound; the count stays on the device (no host round trip), clamped to the bound
     uint32_t blk;
@@ -1153,14 +1153,28 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
         }
         ok = (mm == r.err);
     }
-    if (!ok) {
-        // queued for the DP kernels: narrow bands (k <= 15: the recurrence fits 32-bit words) and wide ones (the doubled
-        // thresholds of the rescue pass) in lists of their own, so that each launch is homogeneous
-        P->state = 2;
-        if (t.k <= 15) dp_list[atomicAdd(dp_count, 1u)] = tid;
-        else if (t.k <= FSV_K_MAX) dp_wide[atomicAdd(dp_count_wide, 1u)] = tid;
-        else dp_xwide[atomicAdd(dp_count_xwide, 1u)] = tid;     // bands above 63 rows (k_path_wide)
-        return;
+    // Not settled here: queued for one of the walk kernels, each list homogeneous -- first-pass bands (k <= 15) by distance: the walk
+    // without the matrix up to 3 (nine in ten; a list per distance), the sub-band matrix up to 7, the general kernel beyond; the doubled thresholds of the
+    // rescue pass (k <= 31); bands above 63 rows (k_path_wide).  One atomic instruction per wave: a class's first lane reserves its slots.
+    {
+        const int cls = ok ? -1 : t.k <= 15 ? (r.err <= FSV_FR_MAXERR ? r.err - 1 : r.err <= FSV_SB_MAXERR ? 3 : 4) : t.k <= FSV_K_MAX ? 5 : 6;
+        if (__any(cls >= 0)) {
+            const int lane = (int)(threadIdx.x & 63u);
+            unsigned long long mine = 0ull;
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                const unsigned long long m = __ballot(cls == c);
+                if (cls == c) mine = m;
+            }
+            const int leader = mine ? __ffsll((long long)mine) - 1 : lane;      // the class's first lane reserves for all of them
+            uint32_t base = 0, *cnt = L.cnt[0], *list = L.list[0];
+#pragma unroll
+            for (int c = 1; c < 7; c++) { cnt = cls == c ? L.cnt[c] : cnt; list = cls == c ? L.list[c] : list; }
+            if (cls >= 0 && lane == leader) base = atomicAdd(cnt, (uint32_t)__popcll(mine));
+            const uint32_t at = __shfl(base, leader, 64) + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+            if (cls >= 0) { P->state = 2; list[at] = tid; }
+        }
+        if (!ok) return;
     }
     // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops (3) and
     // moves the y interval inwards -- the alignment end first, then its start; there are no gaps to shift.
@@ -1178,125 +1192,6 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     uint2 *dst = reinterpret_cast<uint2 *>(P->ops); // ops sit at byte 24 of the record: 8-byte aligned
 #pragma unroll
     for (int i = 0; i < 13; i++) dst[i] = make_uint2(ops32[2 * i], ops32[2 * i + 1]);
-}
-
-// Windows at distance 1 that are not a single mismatch are a single inserted or deleted base: about a third of the windows that
-// reach the DP in the first correction round.  For them the reference's walk back (Levenshtein_distance.h:757-888) can be
-// predicted without the DP matrix.  It climbs the end diagonal over matches (distance stays 1) and leaves it at the first cell,
-// coming from the end, whose upper or left neighbour has distance 0 -- "up" is tested first.  A cell has distance 0 exactly
-// when the x prefix in front of it matches on its diagonal, so with pmU / pmL = the number of leading x bases that match on the
-// diagonal above / below the end diagonal, "up" is open at columns c <= pmU and "left" at c <= pmL + 1 (band edges permitting),
-// and the walk takes the larger of the two, "up" on a tie.  generate_cigar then left-shifts that one gap while the bases it
-// passes pair up.  Anything unexpected (no admissible column, a mismatch behind the gap) is left to the DP kernel.
-__device__ __forceinline__ int path_prefix_match(const uint32_t *__restrict__ store, const fsv_wtask &t, int win0, int off, int n)
-{
-    // number of leading i with x[i] == ywin[off + i]; columns outside read y never match
-    // 64 bases a trip (the exit test once per fetch: a long matching prefix -- the usual case -- is 6 round trips, not 24)
-    for (int c = 0; c * 64 < n; c++) {
-        uint32_t xb4[4], yb4[4], yv4[4];
-        fetch64_x(store, t.x_word, t.x_start + c * 64, xb4);
-        fetch64(store, t.y_word, t.y_len, t.y_rev, win0 + off + c * 64, yb4, yv4);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int b = c * 4 + j;
-            if (b * 16 < n) {
-                uint32_t d = xb4[j] ^ yb4[j];
-                d = (d | (d >> 1)) & 0x55555555u;
-                uint32_t inval = ~yv4[j] & 0xffffu;
-                inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
-                inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
-                d |= inval;
-                const int lim = min(16, n - b * 16);
-                if (lim < 16) d &= (1u << (2 * lim)) - 1u;
-                if (d) return b * 16 + (__ffs((int)d) - 1) / 2;
-            }
-        }
-    }
-    return n;
-}
-
-__global__ __launch_bounds__(256) void k_path_indel1(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
-                                                     const fsv_wres *__restrict__ res, const uint32_t *__restrict__ dp_list, uint32_t n_list,
-                                                     fsv_wpath *__restrict__ paths, uint32_t *__restrict__ dp_list2, uint32_t *__restrict__ n_list2,
-                                                     const uint32_t *__restrict__ n_list_dev, uint32_t *__restrict__ dp_list3, uint32_t *__restrict__ n_list3,
-                                                     uint32_t *__restrict__ dp_list16 = nullptr, uint32_t *__restrict__ n_list16 = nullptr)
-{
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_list_dev) n_list = *n_list_dev;    // the grid covers the largest the list can be; its length stays on the device
-    if (idx >= n_list) return;
-    const uint32_t tid = dp_list[idx];
-    const fsv_wtask t = tasks[tid];
-    const fsv_wres r = res[tid];
-    bool done = false;
-    if (r.err == 1 && t.k >= 1) {
-        const int n = t.x_len, k = t.k, band = 2 * k + 1, E = r.end_site, win0 = t.y_start - k;
-        const int row = band - (n + 2 * k - E);
-        const bool can_up = row != 0, can_left = row != band - 1;
-        const int c_up = can_up ? min(n, path_prefix_match(store, t, win0, E - n, n)) : 0;
-        const int c_left = can_left ? min(n, path_prefix_match(store, t, win0, E - n + 2, n) + 1) : 0;
-        const int c = max(c_up, c_left);
-        const uint32_t gap = c_up >= c_left ? 2u : 3u;
-        // behind the gap the end diagonal must be all matches: x[c .. n) against ywin[E - n + 1 + i]
-        bool clean = c >= 1;
-        if (clean) {
-            for (int ch = c >> 6; ch * 64 < n && clean; ch++) {
-                uint32_t xb4[4], yb4[4], yv4[4];
-                fetch64_x(store, t.x_word, t.x_start + ch * 64, xb4);
-                fetch64(store, t.y_word, t.y_len, t.y_rev, win0 + E - n + 1 + ch * 64, yb4, yv4);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int b = ch * 4 + j;
-                    if (b >= (c >> 4) && b * 16 < n) {
-                        uint32_t d = xb4[j] ^ yb4[j];
-                        d = (d | (d >> 1)) & 0x55555555u;
-                        uint32_t inval = ~yv4[j] & 0xffffu;
-                        inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
-                        inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
-                        d |= inval;
-                        const int lo = max(c - b * 16, 0), lim = min(16, n - b * 16);
-                        if (lo > 0) d &= ~((1u << (2 * lo)) - 1u);
-                        if (lim < 16) d &= (1u << (2 * lim)) - 1u;
-                        if (d) clean = false;
-                    }
-                }
-            }
-        }
-        if (clean) {
-            // the walk: n - c matches, the gap, then c (up) or c - 1 (left) matches; start site as the reference computes it
-            const int g = n - c, rest = gap == 2u ? c : c - 1, plen = n + (gap == 2u ? 1 : 0);
-            int start = E - g - (gap == 2u ? 1 : 0);
-            if (rest > 0) start -= rest;
-            if (rest > 0 || gap != 3u) start++;
-            // generate_cigar: no mismatches to trim; the gap (index g counted from the end) moves towards the start while the bases pair up
-            const int before = plen - 1 - g;     // ops in front of the gap, all matches: x and y consumed there
-            int x2 = before, y2 = before, s = 0;
-            if (gap == 3u) y2--; else x2--;
-            for (int pi = g + 1; pi < plen && x2 >= 0 && y2 >= 0; pi++, x2--, y2--) {
-                if (fsv_base_fwd(store, t.x_word, t.x_start + x2) != task_ybase(store, t, start + y2)) break;
-                s++;
-            }
-            const int f = before - s;            // field of the gap in start-to-end order
-            fsv_wpath *P = paths + tid;
-            uint2 *dst = reinterpret_cast<uint2 *>(P->ops);
-#pragma unroll
-            for (int i = 0; i < 13; i++) {
-                uint2 v = make_uint2(0u, 0u);
-                if ((f >> 5) == i) { if ((f >> 4) & 1) v.y = gap << ((f & 15) << 1); else v.x = gap << ((f & 15) << 1); }
-                dst[i] = v;
-            }
-            P->ry_start = t.y_start - t.k + start;
-            P->ry_end = t.y_start - t.k + E;
-            P->path_len = (int16_t)plen; P->err = 1; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
-            done = true;
-        }
-    }
-    // what is left: distance <= FSV_SB_MAXERR goes to the sub-band kernel, the few beyond it to the general one
-    // (distance <= FSV_SB16_MAXERR: the sub-band of 7 rows fits 16 bits a column: k_path_sb<., true>, half the scratch)
-    if (!done) {
-        if (dp_list16 && r.err <= FSV_SB16_MAXERR) dp_list16[atomicAdd(n_list16, 1u)] = tid;
-        else if (r.err <= FSV_SB_MAXERR) dp_list2[atomicAdd(n_list2, 1u)] = tid;
-        else dp_list3[atomicAdd(n_list3, 1u)] = tid;
-    }
 }
 
 // base access through one cached 16-base word (forward position >> 4 is the key)
@@ -1463,7 +1358,7 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
 #undef COL
 }
 
-// ---- K6 for first-pass windows: k <= 15, distance <= FSV_SB_MAXERR ---------------------------------------------------------
+// ---- K6 for first-pass windows: k <= 15, distance 4 .. FSV_SB_MAXERR (3 and below: k_path_fr further down) ----------------
 // What the walk back (Levenshtein_distance.h:757-888) asks of a DP cell is which way it leaves it -- 0 diagonal over a match,
 // 1 diagonal over a mismatch, 2 up, 3 left; ties: diagonal, then up, then left -- and that is known while the column is
 // computed: a cell whose D0 bit is clear is a mismatch (the diagonal is one cheaper than the cell, nothing beats it);
@@ -1475,8 +1370,6 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
 // four at a time ([block][column quad][lane] as uint4: 1 KB per wave store); the walk reads them back a quad ahead of where it
 // stands, so no step waits on memory -- round 1's walk was a chain of ~375 dependent loads per window (62 % of its wave cycles
 // parked in s_waitcnt, profiles/r01_i_pmc_sq_summary.txt).  Scratch traffic: 1.5 KB per window, written once, read once.
-// HALF: distance <= 3 -- seven rows, 7 + 7 code bits in a 16-bit word, eight columns to a uint4 (half the scratch bytes)
-template <bool HALF>
 struct SubbandSink {
     uint4 *slot;             // this lane's uint4 of quad 0; quad q sits 64 x q further
     uint32_t sr, sl, lmask;  // band word -> sub-band: (w >> sr) << sl; rows that may step left
@@ -1485,30 +1378,17 @@ struct SubbandSink {
     {
         const uint32_t u = vp << 1, l = hp & lmask;
         const uint32_t w1 = d0 & (u | l), w0 = ~d0 | (l & ~u);
-        if (HALF) {
-            const uint32_t h = (((w0 >> sr) << sl) & 0x7fu) | ((((w1 >> sr) << sl) & 0x7fu) << 8);
-            const int e = j & 7;     // blk is a multiple of 16
-            const uint32_t v = (e & 1) ? h << 16 : h;
-            if ((e >> 1) == 0) a0 = (e & 1) ? (a0 | v) : v; else if ((e >> 1) == 1) a1 = (e & 1) ? (a1 | v) : v;
-            else if ((e >> 1) == 2) a2 = (e & 1) ? (a2 | v) : v; else a3 = (e & 1) ? (a3 | v) : v;
-            if (e == 7) slot[(size_t)((blk + j) >> 3) * 64] = make_uint4(a0, a1, a2, a3);
-        } else {
-            const uint32_t word = (((w0 >> sr) << sl) & 0xffffu) | (((w1 >> sr) << sl) << 16);
-            if ((j & 3) == 0) a0 = word; else if ((j & 3) == 1) a1 = word; else if ((j & 3) == 2) a2 = word; else a3 = word;
-            if ((j & 3) == 3) slot[(size_t)((blk + j) >> 2) * 64] = make_uint4(a0, a1, a2, a3);
-        }
+        const uint32_t word = (((w0 >> sr) << sl) & 0xffffu) | (((w1 >> sr) << sl) << 16);
+        if ((j & 3) == 0) a0 = word; else if ((j & 3) == 1) a1 = word; else if ((j & 3) == 2) a2 = word; else a3 = word;
+        if ((j & 3) == 3) slot[(size_t)((blk + j) >> 2) * 64] = make_uint4(a0, a1, a2, a3);
     }
-    __device__ __forceinline__ void flush(int n)
-    {
-        if (HALF) { if (n & 7) slot[(size_t)(n >> 3) * 64] = make_uint4(a0, a1, a2, a3); }
-        else if (n & 3) slot[(size_t)(n >> 2) * 64] = make_uint4(a0, a1, a2, a3);
-    }
+    __device__ __forceinline__ void flush(int n) { if (n & 3) slot[(size_t)(n >> 2) * 64] = make_uint4(a0, a1, a2, a3); }
 };
 
 __device__ __forceinline__ uint32_t quad_elem(const uint4 &q, int e) { return e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w; }
 
 // STAMP: diagnostic build only (FSV_K6_STAMPS=1): shader-clock cycles of the three phases summed per wave into `stamps`
-template <bool STAMP, bool HALF = false>
+template <bool STAMP>
 __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res,
                                                 const uint32_t *__restrict__ dp_list, const uint32_t *__restrict__ n_dev,
                                                 fsv_wpath *__restrict__ paths, uint4 *__restrict__ cols, unsigned long long *__restrict__ stamps)
@@ -1525,9 +1405,9 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
         fsv_wpath *P = paths + tid;
         const int n = t.x_len, k = t.k, band = 2 * k + 1;
         const int end = r0.end_site, err = r0.err;
-        constexpr int ME = HALF ? FSV_SB16_MAXERR : FSV_SB_MAXERR, QSH = HALF ? 3 : 2;
+        constexpr int ME = FSV_SB_MAXERR, QSH = 2;
         const int row0 = band - (n + 2 * k - end), lo = row0 - ME;
-        SubbandSink<HALF> sink;
+        SubbandSink sink;
         sink.slot = slot; sink.sr = (uint32_t)max(lo, 0); sink.sl = (uint32_t)max(-lo, 0);
         sink.lmask = band == 1 ? 1u : (1u << (band - 1)) - 1u;
         sink.a0 = sink.a1 = sink.a2 = sink.a3 = 0;
@@ -1554,15 +1434,9 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
                 // shifts, and the matches in front of the first of them are taken in one step (round 2 walked them one by one, ~40
                 // instructions each: half of K6's time by the cycle stamps, 375 steps for the 1-3 deviations of a HiFi window).
                 uint32_t nz;
-                if (HALF) {
-                    const uint32_t tx = ((q4.x >> rel) | (q4.x >> (rel + 8))) & 0x00010001u, ty = ((q4.y >> rel) | (q4.y >> (rel + 8))) & 0x00010001u;
-                    const uint32_t tz = ((q4.z >> rel) | (q4.z >> (rel + 8))) & 0x00010001u, tw = ((q4.w >> rel) | (q4.w >> (rel + 8))) & 0x00010001u;
-                    nz = ((tx | tx >> 15) & 3u) | (((ty | ty >> 15) & 3u) << 2) | (((tz | tz >> 15) & 3u) << 4) | (((tw | tw >> 15) & 3u) << 6);
-                } else {
-                    nz = (((q4.x >> rel) | (q4.x >> (rel + 16))) & 1u) | ((((q4.y >> rel) | (q4.y >> (rel + 16))) & 1u) << 1) |
-                         ((((q4.z >> rel) | (q4.z >> (rel + 16))) & 1u) << 2) | ((((q4.w >> rel) | (q4.w >> (rel + 16))) & 1u) << 3);
-                }
-                const int cl = ci & (HALF ? 7 : 3);
+                nz = (((q4.x >> rel) | (q4.x >> (rel + 16))) & 1u) | ((((q4.y >> rel) | (q4.y >> (rel + 16))) & 1u) << 1) |
+                     ((((q4.z >> rel) | (q4.z >> (rel + 16))) & 1u) << 2) | ((((q4.w >> rel) | (q4.w >> (rel + 16))) & 1u) << 3);
+                const int cl = ci & 3;
                 const uint32_t m = nz & ((2u << cl) - 1u);          // deviating columns at or below this one
                 const int steps = m ? cl - (31 - __clz((int)m)) : cl + 1;
                 if (steps) {
@@ -1571,8 +1445,8 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
                     plen = np; start -= steps; ci -= steps; dir = 0;
                     if (!m) continue;                                   // the rest of the quad matched
                 }
-                const uint32_t w = HALF ? (quad_elem(q4, (ci & 7) >> 1) >> ((ci & 1) << 4)) & 0xffffu : quad_elem(q4, ci & 3);
-                const uint32_t code = ((w >> rel) & 1u) | (((w >> ((HALF ? 8 : 16) + rel)) & 1u) << 1);
+                const uint32_t w = quad_elem(q4, ci & 3);
+                const uint32_t code = ((w >> rel) & 1u) | (((w >> (16 + rel)) & 1u) << 1);
                 acc |= code << ((plen & 15) << 1);
                 if ((plen & 15) == 15) { s_ops[plen >> 4][lane64] = acc; acc = 0; }
                 plen++;
@@ -1599,6 +1473,159 @@ __global__ __launch_bounds__(64) void k_path_sb(const uint32_t *__restrict__ sto
         if (STAMP) { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); t_fwd += t1 - t0; t_walk += t2 - t1; t_fin += t3 - t2; }
     }
     if (STAMP && lane64 == 0) { atomicAdd(&stamps[0], t_fwd); atomicAdd(&stamps[1], t_walk); atomicAdd(&stamps[2], t_fin); atomicAdd(&stamps[3], 1ull); }
+}
+
+// ---- K6 without the matrix: distance <= FSV_FR_MAXERR ------------------------------------------------------------------------
+// The walk back (Levenshtein_distance.h:757-888) asks three things of the cell (column c, band row r) it stands on, whose
+// distance `cur` it knows: is the diagonal neighbour (c-1, r) one cheaper (a mismatch), else is the upper one (c, r-1), else the
+// left one (c-1, r+1); none of them: a match, one column down the same row.  A band row is a diagonal of the alignment
+// matrix and the distance never falls along a diagonal, so "cell (c, r) is within s errors" is c <= F[s][r], the furthest
+// column row r reaches with s errors -- Landau-Vishkin's table, started from the free start of the DP (every band row at
+// column -1 with distance 0) and clipped to the band:
+//     F[0][r] = last column of the run of matches from column 0 on row r
+//     F[s][r] = the run of matches behind max(F[s-1][r] + 1, F[s-1][r-1], F[s-1][r+1] + 1)      (mismatch, up, left)
+// The walk starts on the end row with the window's distance e (K5 gave both) and spends an error with every move off a match,
+// so the cell it stands on with `cur` left is at most e - cur rows from the end row and the three neighbours it tests sit on
+// level cur - 1 at most e - cur + 1 rows away: a triangle of (2e+1) + (2e-1) + .. + 3 table entries (15 for e = 3), each a
+// word-wise comparison of packed bases, instead of 375 columns of the recurrence and their 750-byte scratch.  Between two
+// errors the walk is one subtraction: it matches down its row to the first column where a neighbour opens.
+// tests/test_gpu_k6.py holds this kernel to the oracle's matrix walk.
+// first column in [cs, cs + 64) (none at or past n) whose x base differs from the y base at strand position ypos + column, as an offset from cs
+__device__ __forceinline__ int diag_mismatch16(uint32_t xb, uint32_t yb, uint32_t yvalid)
+{
+    uint32_t d = xb ^ yb;
+    d = (d | (d >> 1)) & 0x55555555u;
+    uint32_t inval = ~yvalid & 0xffffu;     // columns outside read y never match
+    inval = (inval | (inval << 8)) & 0x00ff00ffu; inval = (inval | (inval << 4)) & 0x0f0f0f0fu;
+    inval = (inval | (inval << 2)) & 0x33333333u; inval = (inval | (inval << 1)) & 0x55555555u;
+    d |= inval;
+    return d ? (__ffs((int)d) - 1) >> 1 : 16;
+}
+__device__ __forceinline__ int diag_probe64(const uint32_t *__restrict__ store, const fsv_wtask &t, int ypos, int cs, int n)
+{
+    uint32_t xb4[4], yb4[4], yv4[4];
+    fetch64_x(store, t.x_word, t.x_start + cs, xb4);
+    fetch64(store, t.y_word, t.y_len, t.y_rev, ypos + cs, yb4, yv4);
+    int m = 64;
+#pragma unroll
+    for (int q = 3; q >= 0; q--) { const int f = diag_mismatch16(xb4[q], yb4[q], yv4[q]); if (f < 16) m = q * 16 + f; }
+    return min(m, n - cs);
+}
+
+// E = the windows' distance (one list per distance: a wave's lanes then have the same number of table entries to fill)
+// STAMP: diagnostic build only (FSV_K6_STAMPS=1): shader-clock cycles of table / walk / finish summed per wave into `stamps`
+template <int E, bool STAMP = false>
+__global__ __launch_bounds__(64) void k_path_fr(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res,
+                                                const uint32_t *__restrict__ dp_list, const uint32_t *__restrict__ n_dev, fsv_wpath *__restrict__ paths,
+                                                unsigned long long *__restrict__ stamps = nullptr)
+{
+    unsigned long long t_tab = 0, t_walk = 0, t_fin = 0, t0 = 0, t1 = 0, t2 = 0;
+    __shared__ uint32_t s_ops[28][64];     // per lane: the path, 2 bits per op, end-to-start (path_finish works on it)
+    constexpr int NJ = 2 * E + 1;
+    const int lane64 = threadIdx.x;
+    const uint32_t n_list = *n_dev;
+    for (uint32_t li = blockIdx.x * 64 + threadIdx.x; li < n_list; li += gridDim.x * 64) {
+        if (STAMP) t0 = __builtin_amdgcn_s_memtime();
+        const uint32_t tid = dp_list[li];
+        const fsv_wtask t = tasks[tid];
+        const fsv_wres r0 = res[tid];
+        fsv_wpath *P = paths + tid;
+        const int n = t.x_len, k = t.k, band = 2 * k + 1;
+        const int end = r0.end_site;
+        const int row0 = band - (n + 2 * k - end), win0 = t.y_start - k;
+        // Q[s][j + E] = F[s][row0 + j] + 1: the first column of the row that is NOT within s errors; -1 = no such row (outside the
+        // band or the triangle): F = -2 is below every column the walk can ask about
+        int Q[E][NJ];
+        // the rows in `run` lengthen their runs of matches, 64 columns a trip, every lane working on its lowest running row: the
+        // wave makes as many trips as its busiest lane has chunks to compare (row after row it made the sum of the rows' longest)
+        auto extend = [&](int (&q)[NJ], uint32_t run) {
+            while (__any(run != 0u)) {
+                if (run) {
+                    const int jj = __ffs((int)run) - 1;
+                    int c = 0;
+#pragma unroll
+                    for (int i = 0; i < NJ; i++) c = i == jj ? q[i] : c;
+                    const int m = diag_probe64(store, t, win0 + row0 + jj - E, c, n);
+                    c += m;
+#pragma unroll
+                    for (int i = 0; i < NJ; i++) q[i] = i == jj ? c : q[i];
+                    if (m < 64 || c >= n) run &= run - 1u;
+                }
+            }
+        };
+        {
+            // level 0, first 64 columns: every row starts at column 0 and the rows' y bases overlap -- one fetch for all of them
+            uint32_t xb4[4], yb[5], yv[5];
+            fetch64_x(store, t.x_word, t.x_start, xb4);
+            {
+                uint32_t b4[4], v4[4];
+                fetch64(store, t.y_word, t.y_len, t.y_rev, win0 + row0 - E, b4, v4);
+                const Bases16 b5 = fetch16(store, t.y_word, t.y_len, t.y_rev, win0 + row0 - E + 64);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { yb[q] = b4[q]; yv[q] = v4[q] & 0xffffu; }
+                yb[4] = b5.bits; yv[4] = b5.valid & 0xffffu;
+            }
+            uint32_t run = 0;
+#pragma unroll
+            for (int jj = 0; jj < NJ; jj++) {
+                const int row = row0 + jj - E;
+                int m = -1;
+                if (row >= 0 && row < band) {
+                    m = 64;
+#pragma unroll
+                    for (int q = 3; q >= 0; q--) {
+                        const int f = diag_mismatch16(xb4[q], __builtin_amdgcn_alignbit(yb[q + 1], yb[q], 2 * jj), ((yv[q] | yv[q + 1] << 16) >> jj) & 0xffffu);
+                        if (f < 16) m = q * 16 + f;
+                    }
+                    m = min(m, n);
+                    if (m == 64 && n > 64) run |= 1u << jj;
+                }
+                Q[0][jj] = m;
+            }
+            extend(Q[0], run);
+        }
+#pragma unroll
+        for (int s = 1; s < E; s++) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int jj = 0; jj < NJ; jj++) {
+                const int row = row0 + jj - E;
+                int c = -1;
+                if (abs(jj - E) <= E - s && row >= 0 && row < band) {
+                    // the furthest cell of the row within s errors before its matches: behind a mismatch on the row, an "up" move
+                    // from the row below (same column), a "left" move from the row above (next column)
+                    const int up = jj > 0 ? Q[s - 1][jj - 1] - 1 : -2, left = jj + 1 < NJ ? Q[s - 1][jj + 1] : -2;
+                    c = min(n - 1, max(Q[s - 1][jj], max(up, left))) + 1;
+                    if (c < n) run |= 1u << jj;
+                }
+                Q[s][jj] = c;
+            }
+            extend(Q[s], run);
+        }
+        if (STAMP) t1 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
+        int ci = n - 1, plen = 0, start = end, j = E, dir = 0;
+#pragma unroll
+        for (int s = E - 1; s >= 0; s--) {      // the walk has s + 1 errors left: its neighbours are judged on level s
+            int fa = -1, fb = -2, fc = -1;      // first columns (from the end) where the mismatch / up / left move is open
+#pragma unroll
+            for (int i = 0; i < NJ; i++) { fa = i == j ? Q[s][i] : fa; fb = i == j - 1 ? Q[s][i] - 1 : fb; fc = i == j + 1 ? Q[s][i] : fc; }
+            const int cstop = min(ci, max(fa, max(fb, fc)));    // fa >= 0: column 0 is a mismatch at the latest
+            const int steps = ci - cstop;
+            plen += steps; start -= steps; ci = cstop;
+            const uint32_t code = ci <= fa ? 1u : ci <= fb ? 2u : 3u;
+            s_ops[plen >> 4][lane64] |= code << ((plen & 15) << 1);
+            plen++;
+            start -= (int)(code != 3u);
+            j += (int)(code == 3u) - (int)(code == 2u);
+            ci -= (int)(code != 2u);
+            dir = (int)code;
+        }
+        if (STAMP) t2 = __builtin_amdgcn_s_memtime();
+        path_finish(store, t, P, s_ops, lane64, ci + 1, dir, plen, start, end, E);
+        if (STAMP) { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); t_tab += t1 - t0; t_walk += t2 - t1; t_fin += t3 - t2; }
+    }
+    if (STAMP && lane64 == 0) { atomicAdd(&stamps[0], t_tab); atomicAdd(&stamps[1], t_walk); atomicAdd(&stamps[2], t_fin); atomicAdd(&stamps[3], 1ull); }
 }
 
 // ---- K6 for wide bands (k > 31, up to 95): the ONT profile ---------------------------------------------------------------------

@@ -255,7 +255,7 @@ typedef struct fsv_asm_stats {
     uint64_t algo_bytes;       /* packed operand + result bytes of all DP tasks + reads in + contigs out */
     uint64_t n_exact_overlaps;  /* overlaps handed to the layout (exact, or inexact ones the last correction round verified) */
     uint64_t n_inexact_candidates; /* pairs re-chained with the gapped bandwidth in the final pass */
-    uint64_t n_path_indel1;     /* distance-1 windows whose path was derived without the DP (single inserted / deleted base) */
+    uint64_t n_path_fr;         /* of those, distance <= 3: walked without the DP matrix (k_path_fr) */
     double   ms_sketch, ms_chain, ms_verify, ms_path, ms_consensus, ms_final, ms_total;
     uint32_t n_kernels, pad;
     fsv_kernel_stat kernels[FSV_MAX_KERNEL_STATS];
