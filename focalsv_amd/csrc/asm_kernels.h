@@ -2046,6 +2046,98 @@ __device__ __forceinline__ void answer_insertions(DagLds &D, uint32_t *s_evhead,
     }
 }
 
+// ---- one overlap's votes on the columns of a window: the walk over its 2-bit path --------------------------------------------------
+// A match op votes for the backbone's own base, so a path only contributes its deviations.  The walk jumps from deviation to
+// deviation (a bit per non-zero path word, count-trailing-zeros inside a word) and does not touch memory: what needs a base of y
+// -- a mismatch's vote, the string of an insertion -- is put aside, four at a time, and the y words of all four are requested
+// together (a load per deviating op inside the walk was a dependent memory round trip per deviation for the whole wave).
+// row: the lane's 26 op words in LDS (fields past plen are 0), nz: bit w set = word w is not all matches.
+// pend: an insertion in front of column xs is already pending (the junction vote).  Returns the number of y-only ops (n2).
+#define FSV_PEND_N 4
+struct ConsLds {
+    uint32_t (*cnt)[3]; int32_t *cov; uint32_t *fl; uint32_t *evn; uint32_t *evkey; uint16_t *evnext; uint32_t *evhead;
+};
+template <int EVC>
+__device__ __forceinline__ void cons_flush(const ConsLds &S, const uint32_t *__restrict__ store, uint32_t y_word, int y_len, int y_rev, int ry_start,
+                                           const uint32_t (&ent)[FSV_PEND_N], int n)
+{
+    // entry: column | (y position - ry_start) << 9 | L << 19 (0: a mismatch) | flagged << 23
+    uint32_t bits[FSV_PEND_N];
+#pragma unroll
+    for (int i = 0; i < FSV_PEND_N; i++) if (i < n) bits[i] = fetch16(store, y_word, y_len, y_rev, ry_start + (int)((ent[i] >> 9) & 1023u)).bits;
+#pragma unroll
+    for (int i = 0; i < FSV_PEND_N; i++) {
+        if (i >= n) continue;
+        const uint32_t e = ent[i], xp = e & 511u, L = (e >> 19) & 15u;
+        if (L == 0u) {
+            const uint32_t yb = bits[i] & 3u;
+            atomicAdd(&S.cnt[xp][yb >> 1], 1u << ((yb & 1u) << 4));
+            if (e >> 23) atomicAdd(&S.fl[xp], 1u << (yb << 3));
+        } else {
+            const uint32_t key = (L << 24) | (bits[i] & ((1u << (2u * L)) - 1u));
+            const uint32_t ev = atomicAdd(S.evn, 1u);
+            if (ev < (uint32_t)EVC) { S.evkey[ev] = key; S.evnext[ev] = (uint16_t)atomicExch(&S.evhead[xp], ev); }
+        }
+    }
+}
+template <int EVC>
+__device__ __forceinline__ int cons_walk(const ConsLds &S, const uint32_t *row, uint32_t nz, int plen, int xs, int xlim, bool pend,
+                                         const uint32_t *__restrict__ store, uint32_t y_word, int y_len, int y_rev, int ry_start)
+{
+    int n2 = 0, n3 = 0, fstart = -1, fmm_pos = -1, np = 0, p = 0;
+    uint32_t ent[FSV_PEND_N] = {0u, 0u, 0u, 0u};
+    while (true) {
+        if (np == FSV_PEND_N) { cons_flush<EVC>(S, store, y_word, y_len, y_rev, ry_start, ent, np); np = 0; }
+        if (!pend) {       // on to the next op that is not a match
+            int w = p >> 4;
+            if (w >= 26) break;
+            uint32_t rest = row[w] >> ((p & 15) << 1);
+            if (rest == 0u) {
+                const uint32_t m = nz >> (w + 1);
+                if (m == 0u) break;
+                w += 1 + __builtin_ctz(m);
+                p = w << 4;
+                rest = row[w];
+            }
+            p += __builtin_ctz(rest) >> 1;
+        }
+        if (p >= plen) break;
+        const uint32_t op = (row[p >> 4] >> ((p & 15) << 1)) & 3u;
+        const int xp = xs + p - n2;
+        if (fstart >= 0 && op != 0u) { atomicAdd(&S.cov[fstart], 65536); atomicAdd(&S.cov[xp], -65536); fstart = -1; }   // the match run after an insertion ends here
+        if (op == 2u) {     // run of y-only ops in front of column xp
+            int L = 1;
+            while (p + L < plen && ((row[(p + L) >> 4] >> (((p + L) & 15) << 1)) & 3u) == 2u) L++;
+            if (xp < xlim) {
+                pend = true;
+                if (L <= FSV_INS_MAXLEN) {
+                    const uint32_t e = (uint32_t)xp | ((uint32_t)(p - n3) << 9) | ((uint32_t)L << 19);
+                    if (np == 0) ent[0] = e; else if (np == 1) ent[1] = e; else if (np == 2) ent[2] = e; else ent[3] = e;
+                    np++;
+                }
+            }
+            n2 += L; p += L;
+            continue;
+        }
+        const bool after_ins = pend && p > 0;      // (a junction vote is no cigar run)
+        if (pend) { atomicAdd(&S.cnt[xp][2], 1u << 16); pend = false; }
+        if (op == 3u) { atomicAdd(&S.cnt[xp][2], 1u); n3++; }
+        else if (op == 1u) {
+            // add_mismatchEdge_weight (POA.h:492) looks at the previous cigar RUN: every base of the run that follows an insertion
+            // counts as "after an insertion", not only the first
+            const bool flagged = after_ins || fmm_pos == p;
+            const uint32_t e = (uint32_t)xp | ((uint32_t)(p - n3) << 9) | (flagged ? 1u << 23 : 0u);
+            if (np == 0) ent[0] = e; else if (np == 1) ent[1] = e; else if (np == 2) ent[2] = e; else ent[3] = e;
+            np++;
+            if (flagged) fmm_pos = p + 1;
+        } else if (after_ins) fstart = xp;
+        p++;
+    }
+    if (fstart >= 0) { atomicAdd(&S.cov[fstart], 65536); atomicAdd(&S.cov[xs + plen - n2], -65536); }
+    if (np) cons_flush<EVC>(S, store, y_word, y_len, y_rev, ry_start, ent, np);
+    return n2;
+}
+
 struct SiteLists {
     uint32_t *site_cnt;        // per grid window: FSV_SITE_MARK after k_consensus<., 1>, the number of kept sites after k_snp_sites
     uint32_t *win_list;        // marked windows, [0] of win_n
@@ -2100,6 +2192,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_fl[i] = 0;
     if (lane == 0) { s_evn = 0; s_cover = 0; s_anydev = 0; s_nins = 0; s_ndev = 0; }
     __syncthreads();
+    const ConsLds CL = {s_cnt, s_cov, s_fl, &s_evn, s_evkey, s_evnext, s_evhead};
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
 #define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
 #define CNT_GET(c, b) ((s_cnt[(c)][(b) >> 1] >> (((b) & 1u) << 4)) & 0xffffu)
@@ -2125,14 +2218,16 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
         if ((h0.w & 0xffu) != 1u) continue;
         // a path at distance 0 is all matches: it only adds its coverage interval
         const bool clean_path = (int16_t)(h0.z >> 16) == 0;
+        uint32_t nz = 0;
         if (!clean_path) {
 #pragma unroll
-            for (int i = 0; i < 13; i++) { s_path[lane][2 * i] = pv[i].x; s_path[lane][2 * i + 1] = pv[i].y; }
+            for (int i = 0; i < 13; i++) {
+                s_path[lane][2 * i] = pv[i].x; s_path[lane][2 * i + 1] = pv[i].y;
+                nz |= (pv[i].x ? 1u << (2 * i) : 0u) | (pv[i].y ? 2u << (2 * i) : 0u);
+            }
         }
-        bool dev_here = false;
         const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
         const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
-#define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))
         const int xs = max(gs, o_x_s) - gs;
         bool pend = false;
         if (j > 0 && A.junction_vote) {
@@ -2140,64 +2235,23 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
             if ((hp.w & 0xffu) == 1u) {
                 const int gap = ry_start - (int)hp.y - 1;
                 if (gap > 0 && xs == 0) {
-                    pend = true; dev_here = true;
+                    pend = true;
                     if (gap <= FSV_INS_MAXLEN) {
                         uint32_t key = (uint32_t)gap << 24;
-                        for (int b = 0; b < gap; b++) key |= YB(ry_start - gap + b) << (2 * b);
+                        for (int b = 0; b < gap; b++) key |= fsv_base_at(A.store, y_word, y_len, y_rev, ry_start - gap + b) << (2 * b);
                         uint32_t e = atomicAdd(&s_evn, 1u);
                         if (e < (uint32_t)EVC) { s_evkey[e] = key; s_evnext[e] = (uint16_t)atomicExch(&s_evhead[0], e); }
                     }
                 }
             }
         }
-        // deviations: skip the all-match remainder of a path word at a time; n2 / n3 = y-only / x-only ops seen so far
-#define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
-        int n2 = 0, n3 = 0, fstart = -1, fmm_pos = -1;
-        if (clean_path && pend) { CNT_ADD(xs, 5u); pend = false; }   // the first op is a match at column xs
-        for (int p = 0; !clean_path && p < plen;) {
-            const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1); // this word from field p on (fields past plen are 0)
-            if (rest == 0u && !pend) { p = ((p >> 4) + 1) << 4; continue; }
-            dev_here = true;
-            const uint32_t op = rest & 3u;
-            const int xp = xs + p - n2;
-            if (fstart >= 0 && op != 0u) { atomicAdd(&s_cov[fstart], 65536); atomicAdd(&s_cov[xp], -65536); fstart = -1; }   // the match run after an insertion ends here
-            if (op == 2u) { // run of y-only ops in front of column xp
-                fmm_pos = -1;
-                int L = 1;
-                while (p + L < plen && OP(p + L) == 2u) L++;
-                if (xp < glen) {
-                    pend = true;
-                    if (L <= FSV_INS_MAXLEN) {
-                        uint32_t key = (uint32_t)L << 24;
-                        const int yp = ry_start + p - n3;
-                        for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
-                        uint32_t e = atomicAdd(&s_evn, 1u);
-                        if (e < (uint32_t)EVC) { s_evkey[e] = key; s_evnext[e] = (uint16_t)atomicExch(&s_evhead[xp], e); }
-                    }
-                }
-                n2 += L; p += L;
-                continue;
-            }
-            const bool after_ins = pend && p > 0;      // (a junction vote is no cigar run)
-            if (pend) { CNT_ADD(xp, 5u); pend = false; }
-            if (op == 3u) { CNT_ADD(xp, 4u); n3++; fmm_pos = -1; }
-            else if (op == 1u) {
-                const uint32_t yb = YB(ry_start + p - n3);
-                CNT_ADD(xp, yb);
-                // add_mismatchEdge_weight (POA.h:492) looks at the previous cigar RUN: every base of the run that follows an insertion
-                // counts as "after an insertion", not only the first
-                if (after_ins || fmm_pos == p) { atomicAdd(&s_fl[xp], 1u << (yb << 3)); fmm_pos = p + 1; } else fmm_pos = -1;
-            } else { if (after_ins) fstart = xp; fmm_pos = -1; }
-            p++;
-        }
-#undef OP
-        if (fstart >= 0) { atomicAdd(&s_cov[fstart], 65536); atomicAdd(&s_cov[xs + plen - n2], -65536); }
+        if (pend || nz) s_anydev = 1u;
+        int n2 = 0;
+        if (clean_path) { if (pend) CNT_ADD(xs, 5u); }      // the first op is a match at column xs
+        else n2 = cons_walk<EVC>(CL, s_path[lane], nz, plen, xs, glen, pend, A.store, y_word, y_len, y_rev, ry_start);
         // coverage interval: every x base of the task is consumed exactly once
-        const int xcols = plen - n2;
         atomicAdd(&s_cov[xs], 1);
-        atomicAdd(&s_cov[xs + xcols], -1);
-        if (dev_here) s_anydev = 1u;
-#undef YB
+        atomicAdd(&s_cov[xs + plen - n2], -1);
     }
     __syncthreads();
     // arrived[c] = prefix sum of the difference array; each lane owns the contiguous columns [c0, c1)
@@ -2903,6 +2957,7 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
         for (int i = lane; i < FSV_WINDOW + 1; i += 64) s_fl[i] = 0;
         if (lane == 0) { s_evn = 0; s_cover = 0; s_terr = 0; s_nins = 0; s_ndev = 0; }
         __syncthreads();
+        const ConsLds CL = {s_cnt, s_cov, s_fl, &s_evn, s_evkey, s_evnext, s_evhead};
 #define XB(p) ((s_xraw[((p) >> 4) - xw0] >> (((p) & 15) << 1)) & 3u)
 #define CNT_ADD(c, b) atomicAdd(&s_cnt[(c)][(b) >> 1], 1u << (((b) & 1u) << 4))
 #define CNT_GET(c, b) ((s_cnt[(c)][(b) >> 1] >> (((b) & 1u) << 4)) & 0xffffu)
@@ -2921,53 +2976,18 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
             const int perr = (int)(int16_t)(h0.z >> 16);
             atomicAdd(&s_cover, 1u);
             const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
-            int n2 = 0, n3 = 0;
+            int n2 = 0;
             if (perr != 0) {
                 atomicAdd(&s_terr, (uint32_t)perr);
                 const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
+                uint32_t nz = 0;
 #pragma unroll
-                for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
-                const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
-#define YB(qq) fsv_base_at(A.store, y_word, y_len, y_rev, (qq))
-#define OP(i) ((s_path[lane][(i) >> 4] >> (((i) & 15) << 1)) & 3u)
-                bool pend = false;
-                int fstart = -1, fmm_pos = -1;
-                for (int p = 0; p < plen;) {
-                    const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1);
-                    if (rest == 0u && !pend) { p = ((p >> 4) + 1) << 4; continue; }
-                    const uint32_t op = rest & 3u;
-                    const int xp = p - n2;
-                    if (fstart >= 0 && op != 0u) { atomicAdd(&s_cov[fstart], 65536); atomicAdd(&s_cov[xp], -65536); fstart = -1; }
-                    if (op == 2u) {
-                        fmm_pos = -1;
-                        int L = 1;
-                        while (p + L < plen && OP(p + L) == 2u) L++;
-                        if (xp < blen) {
-                            pend = true;
-                            if (L <= FSV_INS_MAXLEN) {
-                                uint32_t key = (uint32_t)L << 24;
-                                const int yp = ry_start + p - n3;
-                                for (int b = 0; b < L; b++) key |= YB(yp + b) << (2 * b);
-                                uint32_t e = atomicAdd(&s_evn, 1u);
-                                if (e < (uint32_t)EVC) { s_evkey[e] = key; s_evnext[e] = (uint16_t)atomicExch(&s_evhead[xp], e); }
-                            }
-                        }
-                        n2 += L; p += L;
-                        continue;
-                    }
-                    const bool after_ins = pend;
-                    if (pend) { CNT_ADD(xp, 5u); pend = false; }
-                    if (op == 3u) { CNT_ADD(xp, 4u); n3++; fmm_pos = -1; }
-                    else if (op == 1u) {
-                        const uint32_t yb = YB(ry_start + p - n3);
-                        CNT_ADD(xp, yb);
-                        if (after_ins || fmm_pos == p) { atomicAdd(&s_fl[xp], 1u << (yb << 3)); fmm_pos = p + 1; } else fmm_pos = -1;
-                    } else { if (after_ins) fstart = xp; fmm_pos = -1; }
-                    p++;
+                for (int i = 0; i < 13; i++) {
+                    const uint2 v = src[i];
+                    s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y;
+                    nz |= (v.x ? 1u << (2 * i) : 0u) | (v.y ? 2u << (2 * i) : 0u);
                 }
-                if (fstart >= 0) { atomicAdd(&s_cov[fstart], 65536); atomicAdd(&s_cov[plen - n2], -65536); }
-#undef OP
-#undef YB
+                n2 = cons_walk<EVC>(CL, s_path[lane], nz, plen, 0, blen, false, A.store, h1.x, (int)h1.y, (int)((h0.w >> 8) & 0xffu), ry_start);
             }
             atomicAdd(&s_cov[0], 1);
             atomicAdd(&s_cov[plen - n2], -1);
