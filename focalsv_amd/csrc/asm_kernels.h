@@ -2046,6 +2046,37 @@ __device__ __forceinline__ void answer_insertions(DagLds &D, uint32_t *s_evhead,
     }
 }
 
+// if_is_homopolymer_strict (Correct.h:447-530) on 2-bit bases: the run that starts right after the site and the run that starts right
+// before it, each looked at over at most three bases; the site joins the forward run if it has that base, else the backward run if
+// it has that one; a run of three (the site included or merely beside it) makes a homopolymer site, and so do a forward and a
+// backward run of the site's own base that add up to three.  B(p): base at read position p (0 <= p < len).
+template <class F>
+__device__ __forceinline__ bool homo_strict(F B, int site, int len)
+{
+    const int beg = max(0, site - 3), end = min(len - 1, site + 3);
+    const uint32_t own = B(site);
+    uint32_t f_ch = 4u, b_ch = 4u;      // 4: no base seen
+    int f_len = 0, b_len = 0;
+    for (int i = site + 1; i <= end; i++) {
+        const uint32_t v = B(i);
+        if (f_ch == 4u) { f_ch = v; f_len = 1; } else if (v != f_ch) break; else f_len++;
+    }
+    for (int i = site - 1; i >= beg; i--) {
+        const uint32_t v = B(i);
+        if (b_ch == 4u) { b_ch = v; b_len = 1; } else if (v != b_ch) break; else b_len++;
+    }
+    if (f_ch == own) f_len++;
+    else if (b_ch == own) b_len++;
+    return f_len >= 3 || b_len >= 3 || (own == f_ch && b_ch == f_ch && f_len + b_len >= 3);
+}
+
+// inclusive prefix sum over the wavefront's lanes
+__device__ __forceinline__ int wave_incl_sum(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(v, off, 64); if (lane >= off) v += o; }
+    return v;
+}
 // ---- one overlap's votes on the columns of a window: the walk over its 2-bit path --------------------------------------------------
 // A match op votes for the backbone's own base, so a path only contributes its deviations.  The walk jumps from deviation to
 // deviation (a bit per non-zero path word, count-trailing-zeros inside a word) and does not touch memory: what needs a base of y
@@ -2167,7 +2198,6 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     static_assert(sizeof(DagLds) <= sizeof(uint32_t) * 64 * 27, "the DAG scratch lives in the path buffer between the tally and the decisions");
     DagLds &s_dag = *reinterpret_cast<DagLds *>(&s_path[0][0]);
     __shared__ uint32_t s_xraw[28];                // raw store words covering x[gs-16 .. gs+glen+16)
-    __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
     const uint4 gt = A.gwin_tab[gw];
     const uint32_t r = gt.x, pbase = gt.y, n_ovl = gt.z;
@@ -2268,10 +2298,8 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
             if (!same && A.ins_dag) { const uint32_t k = atomicAdd(&s_nins, 1u); if (k < FSV_INSLIST) s_inslist[k] = (uint16_t)c; }
         }
     }
-    s_scan[lane] = ((uint32_t)run & 0xffffu) | ((uint32_t)frun << 16);
+    const int before = wave_incl_sum(run, lane) - run, fbefore = wave_incl_sum(frun, lane) - frun;
     __syncthreads();
-    int before = 0, fbefore = 0;
-    for (int i = 0; i < lane; i++) { before += (int)(int16_t)(s_scan[i] & 0xffffu); fbefore += (int)(int16_t)(s_scan[i] >> 16); }
     if (lane == 0 && s_nins) answer_insertions<EVC>(s_dag, s_evhead, s_evkey, s_evnext, s_inslist, (int)s_nins, glen);
     __syncthreads();
     uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]); // 375 x 14 B = 5.2 KB <= 64 x 27 x 4 B; paths are done
@@ -2318,8 +2346,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
         }
         {
             // the node in front of column c (poa_decide); the homopolymer relief looks at the PREVIOUS backbone base
-            const int q = gs + c - 1;
-            const bool homo = c > 0 && ((q > 0 && XB(q - 1) == XB(q)) || (q + 1 < xlen && XB(q + 1) == XB(q)));
+            const bool homo = c > 0 && homo_strict([&](int pp) { return XB(pp); }, gs + c - 1, xlen);
             int W[4], Ifl[4], dev = 0;
 #pragma unroll
             for (int b = 0; b < 4; b++) { W[b] = (int)CNT_GET(c, (uint32_t)b); dev += W[b]; Ifl[b] = (int)((s_fl[c] >> (b << 3)) & 0xffu); }
@@ -2352,10 +2379,9 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     __syncthreads();
     uint32_t mine = 0;
     for (int c = c0; c < c1; c++) mine += s_out[c][0];
-    s_scan[lane] = mine;
-    __syncthreads();
-    uint32_t off = 0, tot = 0;
-    for (int i = 0; i < 64; i++) { uint32_t v = s_scan[i]; if (i < lane) off += v; tot += v; }
+    const int incl = wave_incl_sum((int)mine, lane);
+    uint32_t off = (uint32_t)incl - mine;
+    const uint32_t tot = (uint32_t)__shfl(incl, 63, 64);
     if (tot > FSV_CW_STRIDE) { // cannot happen with <= 12-base insertions winning at a few columns; keep the read as it is
         for (int c = lane; c < glen; c += 64) dst[c] = (uint8_t)XB(gs + c);
         if (lane == 0) { A.cwin_len[gw] = (uint16_t)glen; atomicOr(&A.warn[r], (uint32_t)FSV_W_WINDOW_KEPT); }
@@ -2551,8 +2577,7 @@ __device__ __forceinline__ void snp_sites_window(const ConsArgs &A, const uint32
             if (!s_alt[c]) continue;
             s_sidx[c] = (uint8_t)k;
             const int p = gs + c;
-            const uint32_t own = XB(p);
-            const bool homo = (p > 0 && XB(p - 1) == own) || (p + 1 < xlen && XB(p + 1) == own);
+            const bool homo = homo_strict([&](int pp) { return XB(pp); }, p, xlen);
             S.site_rec[(size_t)s_rbase + k] = make_uint2((uint32_t)p | (homo ? 0x80000000u : 0u), s_vbase + (uint32_t)k * vstride);
             k++;
         }
@@ -2935,7 +2960,6 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
     static_assert(sizeof(DagLds) <= sizeof(uint32_t) * 64 * 27, "the DAG scratch lives in the path buffer between the tally and the decisions");
     DagLds &s_dag = *reinterpret_cast<DagLds *>(&s_path[0][0]);
     __shared__ uint32_t s_xraw[28];
-    __shared__ uint32_t s_scan[64];
     const int lane = threadIdx.x;
     const uint32_t n_list = *B.n_bnd;
     for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -3007,10 +3031,8 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
                 if (!same && A.ins_dag) { const uint32_t k = atomicAdd(&s_nins, 1u); if (k < FSV_INSLIST) s_inslist[k] = (uint16_t)c; }
             }
         }
-        s_scan[lane] = ((uint32_t)run & 0xffffu) | ((uint32_t)frun << 16);
+        int arrived = wave_incl_sum(run, lane) - run, farrived = wave_incl_sum(frun, lane) - frun;
         __syncthreads();
-        int arrived = 0, farrived = 0;
-        for (int i = 0; i < lane; i++) { arrived += (int)(int16_t)(s_scan[i] & 0xffffu); farrived += (int)(int16_t)(s_scan[i] >> 16); }
         if (lane == 0 && s_nins) answer_insertions<EVC>(s_dag, s_evhead, s_evkey, s_evnext, s_inslist, (int)s_nins, blen);
         __syncthreads();
         uint8_t (*s_out)[14] = reinterpret_cast<uint8_t (*)[14]>(&s_path[0][0]);
@@ -3032,8 +3054,7 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
             arrived = (int)(int16_t)((uint32_t)s_cov[c] & 0xffffu); farrived = (int)(int16_t)((uint32_t)s_cov[c] >> 16);
             const int p = cws + c;
             const uint32_t own = XB(p);
-            const int q = p - 1;
-            const bool homo = c > 0 && ((q > 0 && XB(q - 1) == XB(q)) || (q + 1 < len_now && XB(q + 1) == XB(q)));
+            const bool homo = c > 0 && homo_strict([&](int pp) { return XB(pp); }, p - 1, len_now);
             int W[4], Ifl[4], dev = 0;
 #pragma unroll
             for (int b = 0; b < 4; b++) { W[b] = (int)CNT_GET(c, (uint32_t)b); dev += W[b]; Ifl[b] = (int)((s_fl[c] >> (b << 3)) & 0xffu); }
@@ -3057,11 +3078,8 @@ __global__ __launch_bounds__(64) void k_bnd_consensus(ConsArgs A, BndArgs B, con
         __syncthreads();
         int mine = 0;
         for (int c = c0; c < c1; c++) mine += s_out[c][0];
-        s_scan[lane] = (uint32_t)mine;
-        __syncthreads();
         if (__ballot(differs) == 0ull) continue;          // the new cigar is one run of matches
-        int off = 0;
-        for (int i = 0; i < lane; i++) off += (int)s_scan[i];
+        int off = wave_incl_sum(mine, lane) - mine;
         for (int c = c0; c < c1; c++) { s_off[c] = (uint16_t)off; off += s_out[c][0]; }
         // the first and the last column to replace: the first kept column at or after 25 / at or after blen - 1 - 25
         const int sb = FSV_BND_SIDE, eb = blen - 1 - FSV_BND_SIDE;

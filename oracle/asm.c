@@ -309,9 +309,28 @@ static int ins_winner(const ins_list *l, int col, uint32_t *key_out)
 
 static int is_homopolymer_site(const char *x, int xlen, int p)
 {
-    /* if_is_homopolymer_strict (Correct.cpp): the base equals a neighbour */
-    if (p > 0 && x[p - 1] == x[p]) return 1;
-    if (p + 1 < xlen && x[p + 1] == x[p]) return 1;
+    /* if_is_homopolymer_strict (Correct.h:447-530), statement by statement: the run that starts right after the site and the run that
+     * starts right before it, each looked at over at most three bases; the site joins the forward run if it has that base, else the
+     * backward run if it has that one; a run of three (the site included or merely beside it) makes the site a homopolymer site,
+     * and so do a forward and a backward run of the site's own base that add up to three */
+    const int threshold = 3;
+    int beg = p - threshold < 0 ? 0 : p - threshold, end = p + threshold >= xlen ? xlen - 1 : p + threshold, i;
+    char f_ch = 0, b_ch = 0;
+    int f_len = 0, b_len = 0;
+    for (i = p + 1; i <= end; i++) {
+        if (f_ch == 0) { f_ch = x[i]; f_len = 1; }
+        else if (x[i] != f_ch) break;
+        else f_len++;
+    }
+    for (i = p - 1; i >= beg; i--) {
+        if (b_ch == 0) { b_ch = x[i]; b_len = 1; }
+        else if (x[i] != b_ch) break;
+        else b_len++;
+    }
+    if (f_ch == x[p]) f_len++;
+    else if (b_ch == x[p]) b_len++;
+    if (f_len >= threshold || b_len >= threshold) return 1;
+    if (x[p] == f_ch && b_ch == f_ch && f_len + b_len >= threshold) return 1;
     return 0;
 }
 
@@ -848,6 +867,15 @@ static int correct_read(const readset *R, const orc_asm_params *P, int q, const 
                 }
             }
         }
+        if (getenv("ORC_DEBUG_VOTE")) {      /* "read,position": the window alignments that vote there, as run-length cigars */
+            int dq = -1, dp = -1, z;
+            sscanf(getenv("ORC_DEBUG_VOTE"), "%d,%d", &dq, &dp);
+            if (dq == q && gs <= dp && dp < gs + glen) for (i = 0; i < nA; i++) {
+                fprintf(stderr, "VOTE win %d cover %d aln %d rev %d xs %d ry_start %d:", gs, cover, i, A[i].rev, A[i].xs, A[i].ry_start);
+                for (z = 0; z < A[i].path_len; ) { int z2 = z; while (z2 < A[i].path_len && A[i].path[z2] == A[i].path[z]) z2++; fprintf(stderr, " %d%c", z2 - z, "MXID"[A[i].path[z]]); z = z2; }
+                fprintf(stderr, "\n");
+            }
+        }
         if (cover < 3) { /* MIN_COVERAGE_THRESHOLD: copy verbatim */
             memcpy(out + outn, x + gs, (size_t)glen); outn += glen;
         } else {
@@ -1079,6 +1107,11 @@ static void partition_read(const readset *R, int q, orc_ovl *ov, int n_ov, const
                 else if (ev[i] > 0) { ev[i] = 2; S[nS].occ2++; }
             }
             S[nS].vec = ev;
+            if (getenv("ORC_DEBUG_K7") && atoi(getenv("ORC_DEBUG_K7")) == q) {
+                fprintf(stderr, "K7SITE site %d occ0 %d occ1 %d occ2 %d max %d base %c:", gs + c, occ0, occ1, occ2, mx, "ACGT"[mi]);
+                for (i = 0; i < n; i++) if (ev[i] >= 0) fprintf(stderr, " t%u:%d", ov[o0 + i].t, ev[i]);
+                fprintf(stderr, "\n");
+            }
             nS++;
         }
         /* bounds of the HIP path (FSV_SITE_WIN_CAP, FSV_SITE_RAW_CAP, FSV_SITE_READ_CAP; hifiasm has none): a window with more than 255 kept sites
