@@ -28,7 +28,7 @@ assert WPATH_DTYPE.itemsize == 128
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final",
                                          "min_contig_reads", "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "partition", "second_round", "ins_dag",
-                                         "min_anchors_final", "min_ovlp_final", "graph_layout")]
+                                         "min_anchors_final", "min_ovlp_final", "graph_layout", "junction_cigars")]
 
 
 class ReadSets(C.Structure):
@@ -54,7 +54,7 @@ class KernelStat(C.Structure):
 
 class AsmStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_pairs", "n_overlaps", "n_windows", "n_windows_matched", "n_paths", "n_path_dp",
-                                          "dp_columns", "algo_bytes", "n_exact_overlaps", "n_inexact_candidates", "n_path_fr")] + \
+                                          "dp_columns", "algo_bytes", "n_exact_overlaps", "n_inexact_candidates", "n_path_fr", "n_junction_cigars")] + \
                [(n, C.c_double) for n in ("ms_sketch", "ms_chain", "ms_verify", "ms_path", "ms_consensus", "ms_final", "ms_total")] + \
                [("n_kernels", C.c_uint32), ("pad", C.c_uint32), ("kernels", KernelStat * 16)]
 

@@ -57,10 +57,10 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
        CT_SLOT = 22 };      // even: the 64-bit sums stay aligned in every slot
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, bc_idx, bc_rec, bc_win, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
-    std::vector<size_t> sk_rec, uq_rec, chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
+    std::vector<size_t> sk_rec, uq_rec, chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec, bc_bpm_rec, bc_fast_rec, bc_dp_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
     // state of the last run (for fsv_asm_fetch_reads / stats)
     std::vector<uint32_t> h_word_off;
     std::vector<int32_t> h_len;
@@ -72,7 +72,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &bc_idx, &bc_rec, &bc_win, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -355,7 +355,7 @@ extern "C" void fsv_asm_default_params(fsv_asm_params *p)
     p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
     p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0; p->partition = 1; p->second_round = 1; p->ins_dag = 1;
-    p->min_anchors_final = 1; p->min_ovlp_final = 1; p->graph_layout = 1;
+    p->min_anchors_final = 1; p->min_ovlp_final = 1; p->graph_layout = 1; p->junction_cigars = 1;
 }
 
 extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
@@ -482,9 +482,10 @@ extern "C" int fsv_asm_last_stats(const fsv_ctx *ctx, fsv_asm_stats *out)
 // K6 for a task list: the fast paths, then the DP kernels on what is left (the lists and their counters live in the counter row ct).
 // Used for the window tasks of a round and, with second_round, for the junction tasks of its second consensus pass.
 static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_wtask *tasks, const fsv_wres *res, fsv_wpath *paths, uint32_t task_cap,
-                      const uint32_t *n_tasks_dev, uint32_t *ct, int round, bool wide_bands, const fsv_asm_params &P, bool first_pass)
+                      const uint32_t *n_tasks_dev, uint32_t *ct, int round, bool wide_bands, const fsv_asm_params &P, int pass_kind)
 {
-    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_FAST, 0); (first_pass ? W.fast_rec : W.fast2_rec).push_back(rec_); }
+    // pass_kind 0: the round's window tasks, 1: the junction tasks of its second consensus pass, 2: the junction cigars of the partition
+    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_FAST, 0); (pass_kind == 0 ? W.fast_rec : pass_kind == 1 ? W.fast2_rec : W.bc_fast_rec).push_back(rec_); }
     const PathLists lists{{(uint32_t *)W.dp_list16.p, (uint32_t *)W.dp_list.p, (uint32_t *)W.dp_list_e3.p, (uint32_t *)W.dp_list2.p, (uint32_t *)W.dp_list3.p, (uint32_t *)W.dp_wide.p, (uint32_t *)W.dp_xwide.p},
                           {ct + CT_DP_SB16, ct + CT_DP, ct + CT_DP_FR3, ct + CT_DP_SB, ct + CT_DP_GEN, ct + CT_DP_WIDE, ct + CT_DP_XW}};
     hipLaunchKernelGGL(k_path_fast, dim3((fsv_grid_for(task_cap, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
@@ -493,7 +494,7 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
     W.kt.end(ctx);
     // what the fast paths left: distance <= 3 is walked without the DP matrix (k_path_fr), <= FSV_SB_MAXERR by the sub-band kernel,
     // the rest by the general one
-    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_DP, 0); (first_pass ? W.dp_rec : W.dp2_rec).push_back(rec_); }
+    { const size_t rec_ = W.kt.begin(ctx, KN_PATH_DP, 0); (pass_kind == 0 ? W.dp_rec : pass_kind == 1 ? W.dp2_rec : W.bc_dp_rec).push_back(rec_); }
     // persistent grids: as many blocks as the device holds at once, each striding through its list, so the column scratch
     // is a fixed few hundred MB whatever the number of windows
     {
@@ -636,7 +637,7 @@ static int second_pass(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G
     FSV_HIP(ctx, hipGetLastError());
     W.kt.end(ctx);
     TRY(path_stage(ctx, W, store2, (const fsv_wtask *)W.tasks2.p, (const fsv_wres *)W.res2.p, (fsv_wpath *)W.paths2.p, task_cap, (const uint32_t *)(ct2 + CT_TASKS), ct2,
-                   round, wide_bands, P, false));
+                   round, wide_bands, P, 1));
     // the junctions' consensus, handed to the windows as patches
     const uint32_t grid_l = std::min<uint32_t>(std::max(1u, n_gwin), (uint32_t)ctx->n_cu * 16);
     W.bndc_rec.push_back(W.kt.begin(ctx, KN_BND_CONS, 0));
@@ -659,7 +660,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     memset(&W.stats, 0, sizeof(W.stats));
     W.kt.reset();
     W.sk_rec.clear(); W.uq_rec.clear(); W.chain_rec.clear(); W.bpm_rec.clear(); W.rescue_rec.clear(); W.fast_rec.clear(); W.dp_rec.clear(); W.cons_rec.clear();
-    W.bnd_rec.clear(); W.bpm2_rec.clear(); W.fast2_rec.clear(); W.dp2_rec.clear(); W.bndc_rec.clear();
+    W.bnd_rec.clear(); W.bpm2_rec.clear(); W.fast2_rec.clear(); W.dp2_rec.clear(); W.bndc_rec.clear(); W.bc_bpm_rec.clear(); W.bc_fast_rec.clear(); W.bc_dp_rec.clear();
     const auto t_enter = std::chrono::steady_clock::now();
 
     Batch B;
@@ -727,9 +728,10 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     const bool wide_bands = P.k_cap > FSV_K_MAX;   // the error model allows thresholds above hifiasm's 31: wide-band K5 / K6 / rescue
     bool short_reads = true;     // every read below 65 536 bases: k_chain's compact LDS layout
     for (uint32_t r = 0; r < B.n_reads; r++) { reads_in_bytes += (uint64_t)(len[r] + 3) / 4; if (len[r] >= 65536) short_reads = false; }
-    // rows 0 .. n_rounds: the rounds and the final pass; rows n_rounds + 1 ..: the second consensus pass of every round
-    TRY(ensure(ctx, W.counters, (size_t)(2 * P.n_rounds + 2) * CT_SLOT * 4));
-    FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, (size_t)(2 * P.n_rounds + 2) * CT_SLOT * 4, ctx->stream));
+    // rows 0 .. n_rounds: the rounds and the final pass; rows n_rounds + 1 ..: the second consensus pass of every round; rows
+    // 2 n_rounds + 2 ..: the junction cigars of every round's partition
+    TRY(ensure(ctx, W.counters, (size_t)(3 * P.n_rounds + 2) * CT_SLOT * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.counters.p, 0, (size_t)(3 * P.n_rounds + 2) * CT_SLOT * 4, ctx->stream));
     TRY(ensure(ctx, W.set_cols, (size_t)B.n_reads * 4));       // K5 columns per set, summed over the rounds (statistics)
     FSV_HIP(ctx, hipMemsetAsync(W.set_cols.p, 0, (size_t)B.n_reads * 4, ctx->stream));
 
@@ -737,7 +739,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
     // counts the kernels produce stay in the round's counter slot.  One synchronisation per round is left: the corrected reads'
     // lengths, which the host turns into the next round's geometry -- the round's counters ride along with it.
     auto ct_of = [&](int slot) { return (uint32_t *)W.counters.p + (size_t)slot * CT_SLOT; };
-    std::vector<uint32_t> h_ct((size_t)(2 * P.n_rounds + 2) * CT_SLOT, 0u);   // rows as on the device: rounds, final pass, the rounds' second passes
+    std::vector<uint32_t> h_ct((size_t)(3 * P.n_rounds + 2) * CT_SLOT, 0u);   // rows as on the device: rounds, final pass, the rounds' second passes
     for (int round = 0; round < P.n_rounds; round++) {
         uint32_t *ct = ct_of(round);
         TRY(upload(ctx, W.word_off, G.word_off));
@@ -780,7 +782,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             W.kt.end(ctx);
             tv.stop();
             Span tp(ctx, W.kt, ST_PATH);
-            TRY(path_stage(ctx, W, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, (fsv_wpath *)W.paths.p, task_cap, (const uint32_t *)(ct + CT_TASKS), ct, round, wide_bands, P, true));
+            TRY(path_stage(ctx, W, store, (const fsv_wtask *)W.tasks.p, (const fsv_wres *)W.res.p, (fsv_wpath *)W.paths.p, task_cap, (const uint32_t *)(ct + CT_TASKS), ct, round, wide_bands, P, 0));
             tp.stop();
         }
         // consensus -> corrected windows -> new read store
@@ -838,6 +840,38 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             SL.site_cnt = SA.site_cnt; SL.win_list = (uint32_t *)W.site_lists.p; SL.redo_list = SL.win_list + std::max(1u, n_gwin);
             SL.win_n = (uint32_t *)W.site_cursor.p + 1;
         }
+        if (partition && P.junction_cigars) {
+            // calculate_boundary_cigars (Correct.cpp:2310): junction tasks -> K5 -> K6 -> which of the new cigars the partition uses
+            uint32_t *ct3 = ct_of(2 * P.n_rounds + 2 + round);
+            TRY(ensure(ctx, W.tasks2, (size_t)task_cap * sizeof(fsv_wtask)));
+            TRY(ensure(ctx, W.res2, (size_t)task_cap * sizeof(fsv_wres)));
+            TRY(ensure(ctx, W.paths2, (size_t)task_cap * sizeof(fsv_wpath)));
+            TRY(ensure(ctx, W.bc_idx, (size_t)task_cap * 4));
+            TRY(ensure(ctx, W.bc_rec, (size_t)task_cap * sizeof(uint4)));
+            TRY(ensure(ctx, W.bc_win, (size_t)(n_gwin + 2) * 4));
+            FSV_HIP(ctx, hipMemsetAsync(W.bc_win.p, 0, (size_t)(n_gwin + 2) * 4, ctx->stream));
+            BcigArgs BA;
+            BA.tasks = (const fsv_wtask *)W.tasks.p; BA.paths = (const fsv_wpath *)W.paths.p; BA.n_tasks = ct + CT_TASKS;
+            BA.pair_read = (const uint32_t *)W.pair_read.p; BA.read_dirty = (const uint32_t *)W.read_dirty.p; BA.gwin_off = (const uint32_t *)W.gwin_off.p;
+            BA.thr_tab = (const uint8_t *)W.thr_tab.p; BA.k_cap = P.k_cap;
+            BA.tasks2 = (fsv_wtask *)W.tasks2.p; BA.bc_idx = (int32_t *)W.bc_idx.p; BA.n_tasks2 = ct3 + CT_TASKS;
+            BA.res2 = (const fsv_wres *)W.res2.p; BA.paths2 = (const fsv_wpath *)W.paths2.p; BA.bc_rec = (uint4 *)W.bc_rec.p; BA.bc_win = (uint32_t *)W.bc_win.p;
+            W.kt.begin(ctx, KN_PARTITION, 0);
+            hipLaunchKernelGGL(k_bcig_tasks, dim3((fsv_grid_for(task_cap, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, BA);
+            FSV_HIP(ctx, hipGetLastError());
+            W.kt.end(ctx);
+            W.bc_bpm_rec.push_back(W.kt.begin(ctx, KN_BPM, 0));
+            TRY(fsv_bpm_windows_dev_n(ctx, store, (const fsv_wtask *)W.tasks2.p, task_cap, ct3 + CT_TASKS, (fsv_wres *)W.res2.p, P.k_cap));
+            W.kt.end(ctx);
+            TRY(path_stage(ctx, W, store, (const fsv_wtask *)W.tasks2.p, (const fsv_wres *)W.res2.p, (fsv_wpath *)W.paths2.p, task_cap, (const uint32_t *)(ct3 + CT_TASKS), ct3,
+                           round, wide_bands, P, 2));
+            W.kt.begin(ctx, KN_PARTITION, 0);
+            hipLaunchKernelGGL(k_bcig_accept, dim3(fsv_grid_for(task_cap, 256)), dim3(256), 0, ctx->stream, BA);
+            FSV_HIP(ctx, hipGetLastError());
+            W.kt.end(ctx);
+            SA.bc_idx = (const int32_t *)W.bc_idx.p; SA.bc_rec = (const uint4 *)W.bc_rec.p; SA.bc_paths = (const fsv_wpath *)W.paths2.p;
+            SL.bc_win = (const uint32_t *)W.bc_win.p;
+        }
         // consensus of every window; with the haplotype partition (K7) on, the windows that hold a candidate site are listed on the
         // way, k_snp_sites / k_hap_partition take the overlaps with the other allele out (is_match 2 / 4: out of the consensus and,
         // through that, out of what the final pass accepts as verified), and the reads that lost an overlap get their windows redone
@@ -874,6 +908,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         FSV_HIP(ctx, hipMemcpyAsync(nlen.data(), W.new_len.p, (size_t)B.n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipMemcpyAsync(h_ct.data() + (size_t)round * CT_SLOT, ct, CT_SLOT * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipMemcpyAsync(h_ct.data() + (size_t)(P.n_rounds + 1 + round) * CT_SLOT, ct_of(P.n_rounds + 1 + round), CT_SLOT * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FSV_HIP(ctx, hipMemcpyAsync(h_ct.data() + (size_t)(2 * P.n_rounds + 2 + round) * CT_SLOT, ct_of(2 * P.n_rounds + 2 + round), CT_SLOT * 4, hipMemcpyDeviceToHost, ctx->stream));
         FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (h_ct[(size_t)round * CT_SLOT + CT_OVERFLOW]) return fsv_fail(ctx, FSV_ECAP, "internal window task buffer overflow");
         Geometry G2;
@@ -1118,6 +1153,15 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
         // the round's second consensus pass (its counters sit n_rounds + 1 rows further): the junction tasks are window tasks like
         // the first pass's; k_bnd_tasks reads every first-pass task and path record and writes the junction tasks; the junctions'
         // consensus reads their path records and writes a patch per junction
+        if ((size_t)sl < W.bc_bpm_rec.size()) {      // the junction cigars of the round's partition: window tasks like the others
+            const uint32_t *c3 = h_ct.data() + (size_t)(2 * P.n_rounds + 2 + sl) * CT_SLOT;
+            const uint64_t n3 = c3[CT_TASKS], n_dp3 = (uint64_t)c3[CT_DP_SB] + c3[CT_DP_SB16] + c3[CT_DP] + c3[CT_DP_FR3] + c3[CT_DP_GEN] + c3[CT_DP_WIDE] + c3[CT_DP_XW];
+            n_windows2 += n3;
+            W.stats.n_junction_cigars += n3;
+            W.kt.recs[W.bc_bpm_rec[sl]].bytes = n3 * 212ull;
+            if ((size_t)sl < W.bc_fast_rec.size()) W.kt.recs[W.bc_fast_rec[sl]].bytes = n3 * (16ull + 196ull) + (n3 - n_dp3) * 128ull;
+            if ((size_t)sl < W.bc_dp_rec.size()) W.kt.recs[W.bc_dp_rec[sl]].bytes = n_dp3 * (196ull + 128ull);
+        }
         if ((size_t)sl < W.bnd_rec.size()) {
             const uint32_t *c2 = h_ct.data() + (size_t)(P.n_rounds + 1 + sl) * CT_SLOT;
             const uint64_t n2 = c2[CT_TASKS], n3 = c2[CT_B_RETRY], n_dp2 = (uint64_t)c2[CT_DP_SB] + c2[CT_DP_SB16] + c2[CT_DP] + c2[CT_DP_FR3] + c2[CT_DP_GEN] + c2[CT_DP_WIDE] + c2[CT_DP_XW];

@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     // without the matrix up to 3 (nine in ten; a list per distance), the sub-band matrix up to 7, the general kernel beyond; the doubled thresholds of the
     // rescue pass (k <= 31); bands above 63 rows (k_path_wide).  One atomic instruction per wave: a class's first lane reserves its slots.
     {
-        const int cls = ok ? -1 : t.k <= 15 ? (r.err <= FSV_FR_MAXERR ? r.err - 1 : r.err <= FSV_SB_MAXERR ? 3 : 4) : t.k <= FSV_K_MAX ? 5 : 6;
+        const int cls = ok ? -1 : (t.k <= FSV_K_MAX && r.err <= FSV_FR_MAXERR) ? r.err - 1 : t.k <= 15 ? (r.err <= FSV_SB_MAXERR ? 3 : 4) : t.k <= FSV_K_MAX ? 5 : 6;
         if (__any(cls >= 0)) {
             const int lane = (int)(threadIdx.x & 63u);
             unsigned long long mine = 0ull;
@@ -1776,7 +1776,7 @@ __global__ __launch_bounds__(64) void k_read_dirty(const uint4 *__restrict__ ovl
             const bool ok = (h0.w & 0xffu) == 1u;
             if (ok) {
                 if ((int16_t)(h0.z >> 16) != 0) dirty = true;
-                if (prev_ok && (int)h0.x - prev_end - 1 > 0) dirty = true;
+                if (prev_ok && (int)h0.x - prev_end - 1 != 0) dirty = true;     // bases of y skipped, or used twice
                 prev_end = (int)h0.y;
             }
             prev_ok = ok;
@@ -2174,6 +2174,7 @@ struct SiteLists {
     uint32_t *win_list;        // marked windows, [0] of win_n
     uint32_t *redo_list;       // windows of the reads that lost an overlap to the partition
     uint32_t *win_n;           // {marked windows, redo windows}
+    const uint32_t *bc_win;    // per grid window: a used junction cigar reaches into it (k_bcig_accept); nullptr: none anywhere
 };
 template <int EVC, int MODE>
 __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32_t gw, const SiteLists &L)
@@ -2370,7 +2371,9 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     }
     if (differs && A.changed) A.changed[r] = 1u;
     if (MODE == 1) {
-        const bool any_site = __ballot(site) != 0ull;
+        // a window a used junction cigar reaches into is looked at by k_snp_sites whatever the window cigars say: what its overlaps
+        // show beside the junction is read off that cigar there (markSNP_advance, Correct.cpp:5054)
+        const bool any_site = __ballot(site) != 0ull || (L.bc_win && L.bc_win[gw]);
         if (lane == 0) {
             L.site_cnt[gw] = any_site ? FSV_SITE_MARK : 0u;
             if (any_site) L.win_list[atomicAdd(&L.win_n[0], 1u)] = gw;
@@ -2412,6 +2415,174 @@ __global__ __launch_bounds__(64) void k_consensus_redo(ConsArgs A, SiteLists L)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ k_bcig_tasks / k_bcig_accept
+// calculate_boundary_cigars (Correct.cpp:2310-2530), for the haplotype partition: the junction between two matched windows of an
+// accepted overlap whose alignments do not simply meet (bases of y skipped or used twice, or an error within 10 columns of the
+// junction on either side) is aligned once more -- up to 100 columns on each side, doubled threshold, no fix_boundary -- and the
+// partition reads the ~50 columns on each side of the junction off that cigar unless it has clearly more errors there than the two
+// window cigars (markSNP_advance :5054, addSNPtohaplotype_advance :5351).  k_bcig_tasks writes the junction tasks (one thread per
+// window task; K5 and the K6 kernels then run on them as on any task list), k_bcig_accept decides which of the new cigars are used.
+// oracle/asm.c:boundary_cigars / window_evidence are the same, statement for statement.
+#define FSV_BC_SIDE 100
+#define FSV_BC_USELESS 50
+#define FSV_BC_SCAN 10
+struct BcigArgs {
+    const fsv_wtask *tasks; const fsv_wpath *paths; const uint32_t *n_tasks;     // the round's window tasks and their paths
+    const uint32_t *pair_read, *read_dirty, *gwin_off; const uint8_t *thr_tab; int k_cap;
+    fsv_wtask *tasks2; int32_t *bc_idx; uint32_t *n_tasks2;                      // junction tasks; bc_idx[window task] = the task of the junction behind it or -1
+    const fsv_wres *res2; const fsv_wpath *paths2; uint4 *bc_rec; uint32_t *bc_win;
+};
+// op i of a path record's 2-bit stream, through one cached word
+struct OpReader {
+    const uint32_t *w; uint32_t cur = 0; int idx = -1;
+    __device__ __forceinline__ OpReader(const fsv_wpath *P) : w(reinterpret_cast<const uint32_t *>(P->ops)) {}
+    __device__ __forceinline__ uint32_t get(int i) { const int wi = i >> 4; if (wi != idx) { cur = w[wi]; idx = wi; } return (cur >> ((i & 15) << 1)) & 3u; }
+};
+// scan_cigar (Correct.cpp:1070-1200): errors met while the first (dir 0) / last (dir 1) scan_x columns of x go by; y-only ops count
+// whenever they are met.  err0: the path's distance (a distance-0 record carries no ops)
+__device__ __forceinline__ int scan_ops(const fsv_wpath *P, int plen, int err0, int scan_x, int dir)
+{
+    if (err0 == 0) return 0;
+    OpReader R(P);
+    int x_i = 0, err = 0;
+    for (int p = 0; p < plen; p++) {
+        const uint32_t op = R.get(dir ? plen - 1 - p : p);
+        if (op == 2u) { err++; continue; }
+        if (op != 0u) err++;
+        if (++x_i >= scan_x) return err;
+    }
+    return err;
+}
+// scan_cigar_interval (Correct.cpp:1204-1290): errors over the columns [xb, xe] of x
+__device__ __forceinline__ int scan_ops_interval(const fsv_wpath *P, int plen, int err0, int xb, int xe)
+{
+    if (err0 == 0) return 0;
+    OpReader R(P);
+    int x_i = 0, err = 0;
+    for (int p = 0; p < plen; p++) {
+        const uint32_t op = R.get(p);
+        if (op == 2u) { err++; continue; }
+        if (x_i == xb) err = 0;
+        x_i++;
+        if (op != 0u) err++;
+        if (x_i == xe + 1) return err;
+    }
+    return err;
+}
+
+__global__ __launch_bounds__(256) void k_bcig_tasks(BcigArgs A)
+{
+    const uint32_t n_tasks = min(*A.n_tasks, gridDim.x * blockDim.x);
+    uint32_t blk;
+    if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
+    const uint32_t ti = blk * blockDim.x + threadIdx.x;
+    if (ti >= n_tasks) return;
+    A.bc_idx[ti] = -1;
+    if (ti + 1 >= n_tasks) return;
+    const fsv_wtask t0 = A.tasks[ti], t1 = A.tasks[ti + 1];
+    if (t1.ovl != t0.ovl) return;                           // the overlap's last window
+    if (!A.read_dirty[A.pair_read[t0.ovl]]) return;         // every overlap of the read matches it base for base, window after window
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(A.paths + ti), h1 = *reinterpret_cast<const uint4 *>(A.paths + ti + 1);
+    if ((h0.w & 0xffu) != 1u || (h1.w & 0xffu) != 1u) return;
+    const int y_distance = (int)h1.x - (int)h0.y - 1;
+    if (y_distance == 0 && scan_ops(A.paths + ti, (int)(int16_t)(h0.z & 0xffffu), (int)(int16_t)(h0.z >> 16), FSV_BC_SCAN, 1) == 0 &&
+        scan_ops(A.paths + ti + 1, (int)(int16_t)(h1.z & 0xffffu), (int)(int16_t)(h1.z >> 16), FSV_BC_SCAN, 0) == 0) return;
+    int y_start = (int)h0.y, x_start = t0.x_start + (int)t0.x_len - 1;
+    const int leftLen = min(min(x_start - t0.x_start, y_start), FSV_BC_SIDE);
+    const int rightLen = min(min(t1.x_start + (int)t1.x_len - x_start, t0.y_len - y_start), FSV_BC_SIDE);
+    const int xLen = leftLen + rightLen;
+    if (xLen <= 0) return;
+    x_start -= leftLen; y_start -= leftLen;
+    const int thr = double_thr(A.thr_tab[xLen], xLen, A.k_cap);
+    if (thr > FSV_K_MAX) return;
+    const uint32_t slot = atomicAdd(A.n_tasks2, 1u);
+    fsv_wtask w;
+    w.x_word = t0.x_word; w.y_word = t0.y_word; w.x_start = x_start; w.y_start = y_start; w.y_len = t0.y_len;
+    w.x_len = (uint16_t)xLen; w.k = (uint8_t)thr; w.y_rev = t0.y_rev; w.ovl = t0.ovl; w.win = ti;
+    A.tasks2[slot] = w;
+    A.bc_idx[ti] = (int32_t)slot;
+}
+
+// one thread per junction task: is its cigar used?  Not when it has clearly more errors in its inner columns than the two window
+// cigars have there; and not when it shows, column for column, what the window cigars show (then nothing changes and the windows
+// beside it need no second look by k_snp_sites -- most of them: the re-alignment usually finds the two window alignments again)
+__global__ __launch_bounds__(256) void k_bcig_accept(BcigArgs A)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= *A.n_tasks2) return;
+    A.bc_rec[slot] = make_uint4(0, 0, 0, 0);
+    const fsv_wtask w = A.tasks2[slot];
+    const fsv_wres r = A.res2[slot];
+    const uint32_t ti = w.win;
+    const fsv_wpath *PB = A.paths2 + slot, *P0 = A.paths + ti, *P1 = A.paths + ti + 1;
+    const uint4 hb = *reinterpret_cast<const uint4 *>(PB);
+    if (r.err < 0 || (hb.w & 0xffu) != 1u) return;
+    const int xLen = w.x_len, thr = w.k;
+    if (xLen + 2 * thr - r.extra_begin - r.extra_end < xLen) return;      // o_len < xLen
+    const fsv_wtask t0 = A.tasks[ti], t1 = A.tasks[ti + 1];
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(P0), h1 = *reinterpret_cast<const uint4 *>(P1);
+    const int x_end0 = t0.x_start + (int)t0.x_len - 1, leftLen = x_end0 - w.x_start, rightLen = xLen - leftLen;
+    int y_distance = (int)h1.x - (int)h0.y - 1;
+    if (y_distance < 0) y_distance = -y_distance;
+    int L = FSV_BC_USELESS, R = FSV_BC_USELESS;
+    const uint32_t first_ti = ti - t0.win;                  // (window tasks carry their index inside the overlap)
+    if (t0.win == 0 && w.x_start == t0.x_start) L = 0;
+    {
+        // the overlap's last window: the next task belongs to another overlap (or there is none)
+        const bool last_junction = ti + 2 >= *A.n_tasks || A.tasks[ti + 2].ovl != t0.ovl;
+        if (last_junction && w.x_start + xLen - 1 == t1.x_start + (int)t1.x_len - 1) R = 0;
+    }
+    (void)first_ti;
+    if (leftLen <= L || rightLen <= R) return;
+    const int plb = (int)(int16_t)(hb.z & 0xffffu), eb = (int)(int16_t)(hb.z >> 16);
+    const int pl0 = (int)(int16_t)(h0.z & 0xffffu), e0 = (int)(int16_t)(h0.z >> 16), pl1 = (int)(int16_t)(h1.z & 0xffffu), e1 = (int)(int16_t)(h1.z >> 16);
+    const int m_err = scan_ops_interval(PB, plb, eb, L, xLen - R - 1);
+    const int b_err = scan_ops(P0, pl0, e0, leftLen - L, 1), f_err = scan_ops(P1, pl1, e1, rightLen - R, 0);
+    if (f_err + b_err + y_distance + 1 < m_err) return;
+    // Does it show anything the window cigars do not?  Column by column over the columns it would be used for: the same op, and
+    // for a column with a partner the same base of y (its position).
+    bool differs = false;
+    {
+        // columns of the junction cigar that stand for window 0: [L, leftLen] (its last column included); for window 1:
+        // [leftLen + 1, leftLen + 1 + (rightLen - 1 - R) - 1] (markSNP_advance's intervals, restated in snp_sites_window)
+        OpReader RB(PB), R0(P0), R1(P1);
+        int pb = 0, xb = 0, yb = (int)hb.x;
+        // window 0 from its column x0c on: skip its ops in front of that column
+        const int x0c = (w.x_start + L) - t0.x_start;
+        int p0 = 0, x0 = 0, y0 = (int)h0.x;
+        if (e0 != 0) { while (p0 < pl0 && x0 < x0c) { const uint32_t op = R0.get(p0++); if (op == 2u) y0++; else { x0++; if (op != 3u) y0++; } } }
+        else { x0 = x0c; y0 += x0c; p0 = x0c; }
+        if (eb != 0) { while (pb < plb && xb < L) { const uint32_t op = RB.get(pb++); if (op == 2u) yb++; else { xb++; if (op != 3u) yb++; } } }
+        else { xb = L; yb += L; pb = L; }
+        auto next = [](OpReader &Rd, int &p, int pl, int e, int &y, uint32_t &op_out, int &y_out) {
+            // the next op that consumes a column of x: its code and the position of its partner in y
+            if (e == 0) { op_out = 0u; y_out = y; y++; p++; return; }
+            while (p < pl) { const uint32_t op = Rd.get(p++); if (op == 2u) { y++; continue; } op_out = op; y_out = y; if (op != 3u) y++; return; }
+            op_out = 0u; y_out = y;
+        };
+        const int hi0 = leftLen;                                   // last junction column read for window 0
+        for (; xb <= hi0 && !differs; xb++) {
+            uint32_t ob, ow; int ybp, ywp;
+            next(RB, pb, plb, eb, yb, ob, ybp);
+            next(R0, p0, pl0, e0, y0, ow, ywp);
+            if (ob != ow || (ob != 3u && ybp != ywp)) differs = true;
+        }
+        // window 1: junction columns leftLen + 1 .. leftLen + (rightLen - 1 - R)
+        int p1 = 0, y1 = (int)h1.x;
+        const int hi1 = leftLen + (rightLen - 1 - R);
+        for (; xb <= hi1 && !differs; xb++) {
+            uint32_t ob, ow; int ybp, ywp;
+            next(RB, pb, plb, eb, yb, ob, ybp);
+            next(R1, p1, pl1, e1, y1, ow, ywp);
+            if (ob != ow || (ob != 3u && ybp != ywp)) differs = true;
+        }
+    }
+    if (!differs) return;
+    A.bc_rec[slot] = make_uint4(1u, (uint32_t)w.x_start, (uint32_t)xLen | ((uint32_t)L << 16) | ((uint32_t)R << 24), 0u);
+    const uint32_t rd = A.pair_read[t0.ovl], g0 = A.gwin_off[rd] + (uint32_t)(t0.x_start / FSV_WINDOW);
+    A.bc_win[g0] = 1u; A.bc_win[g0 + 1] = 1u;
+}
+
 // ------------------------------------------------------------------------------------------------ k_snp_sites / k_hap_partition
 // partition_overlaps_advance (Correct.cpp:7127-7206), for every read of every set as hifiasm runs it (it has no notion of a phased
 // input: in a phased set the "heterozygous" columns are coincident read errors, and the few overlaps set aside by them are
@@ -2439,6 +2610,10 @@ struct SiteArgs {
     uint32_t *vec_cursor;          // bytes handed out
     uint32_t vec_cap;
     uint32_t *read_sites;          // per read: some window of it kept a site
+    // the re-aligned junction cigars (k_bcig_tasks / k_bcig_accept); nullptr: the window cigars everywhere
+    const int32_t *bc_idx;         // per window task: the junction task between it and the next window of its overlap, or -1
+    const uint4 *bc_rec;           // per junction task: {bit 0: used, first column in x, columns | L << 16 | R << 24, -}
+    const fsv_wpath *bc_paths;     // per junction task: its path
 };
 
 __device__ __forceinline__ void snp_sites_window(const ConsArgs &A, const uint32_t gw, const SiteArgs &S)
@@ -2476,52 +2651,74 @@ __device__ __forceinline__ void snp_sites_window(const ConsArgs &A, const uint32
             const int o_x_s = (int)oc.x, o_n_win = (int)(oc.z & 0x7fffffffu);
             const int j = g - o_x_s / FSV_WINDOW;
             if (!(oc.z >> 31) || j < 0 || j >= o_n_win) continue;
-            const fsv_wpath *P = A.paths + (oc.y + (uint32_t)j);
+            const uint32_t ti = oc.y + (uint32_t)j;
+            const fsv_wpath *P = A.paths + ti;
             const uint4 h0 = *reinterpret_cast<const uint4 *>(P);
             if ((h0.w & 0xffu) != 1u) continue;
-            const uint2 h1 = *reinterpret_cast<const uint2 *>((const uint8_t *)P + 16);
-            const bool clean_path = (int16_t)(h0.z >> 16) == 0;
-            const int ry_start = (int)h0.x, plen = (int)(int16_t)(h0.z & 0xffffu);
             const int xs = max(gs, o_x_s) - gs;
             if (pass == 0) atomicAdd(&s_cover, 1u);
-            int n2 = 0, n3 = 0;
-            if (!clean_path) {
-                const uint2 *src = reinterpret_cast<const uint2 *>(P->ops);
+            // What the overlap shows at the columns [lo, hi] (counted from the cigar's first column, which is column x0 of the read)
+            // of one cigar.  pass 0: mismatches and x bases without a partner are tallied (markSNP_detail, Correct.cpp:4998);
+            // pass 1: the kept sites get their evidence (addSNPtohaplotype_details :5247).  Returns the cigar's x columns.
+            auto walk = [&](const fsv_wpath *Q, int x0, int lo, int hi) -> int {
+                const uint4 q0 = *reinterpret_cast<const uint4 *>(Q);
+                const int plen = (int)(int16_t)(q0.z & 0xffffu), ry0 = (int)q0.x, col0 = x0 - gs;
+                if ((int16_t)(q0.z >> 16) == 0) {          // distance 0: all matches, the record carries no ops
+                    if (pass == 1) for (int xi = max(lo, -col0); xi <= min(hi, plen - 1) && col0 + xi < glen; xi++) if (s_alt[col0 + xi]) S.vec[s_vbase + (uint32_t)s_sidx[col0 + xi] * vstride + oi] = 0;
+                    return plen;
+                }
+                const uint2 q1 = *reinterpret_cast<const uint2 *>((const uint8_t *)Q + 16);
+                const uint32_t y_word = q1.x; const int y_len = (int)q1.y, y_rev = (int)((q0.w >> 8) & 0xffu);
+                const uint2 *src = reinterpret_cast<const uint2 *>(Q->ops);
 #pragma unroll
                 for (int i = 0; i < 13; i++) { const uint2 v = src[i]; s_path[lane][2 * i] = v.x; s_path[lane][2 * i + 1] = v.y; }
-                const uint32_t y_word = h1.x; const int y_len = (int)h1.y, y_rev = (int)((h0.w >> 8) & 0xffu);
-                if (pass == 0) {
-                    for (int p = 0; p < plen;) {
-                        const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1);
-                        if (rest == 0u) { p = ((p >> 4) + 1) << 4; continue; }
-                        const uint32_t op = rest & 3u;
-                        const int xp = xs + p - n2;
-                        if (op == 2u) { n2++; p++; continue; }
-                        if (op == 3u) { CNT_ADD(xp, 4u); n3++; }
-                        else if (op == 1u) CNT_ADD(xp, fsv_base_at(A.store, y_word, y_len, y_rev, ry_start + p - n3));
-                        p++;
-                    }
-                } else {
-                    // every column: the kept sites want the matching overlaps too
-                    for (int p = 0; p < plen; p++) {
-                        const uint32_t op = (s_path[lane][p >> 4] >> ((p & 15) << 1)) & 3u;
-                        const int xp = xs + p - n2;
-                        if (op == 2u) { n2++; continue; }
-                        const uint32_t alt = s_alt[xp];
-                        if (alt) {
-                            int8_t v = 0;
-                            if (op == 3u) v = 2;
-                            else if (op == 1u) v = fsv_base_at(A.store, y_word, y_len, y_rev, ry_start + p - n3) + 1u == alt ? 1 : 2;
-                            S.vec[s_vbase + (uint32_t)s_sidx[xp] * vstride + oi] = v;
+                int n2 = 0, n3 = 0;
+                for (int p = 0; p < plen; p++) {
+                    const uint32_t rest = s_path[lane][p >> 4] >> ((p & 15) << 1);
+                    if (pass == 0 && rest == 0u) { p = (((p >> 4) + 1) << 4) - 1; continue; }    // the rest of the word: matches
+                    const uint32_t op = rest & 3u;
+                    if (op == 2u) { n2++; continue; }
+                    const int xi = p - n2, c = col0 + xi;
+                    if (xi >= lo && xi <= hi && c >= 0 && c < glen) {
+                        if (pass == 0) {
+                            if (op == 3u) CNT_ADD(c, 4u);
+                            else if (op == 1u) CNT_ADD(c, fsv_base_at(A.store, y_word, y_len, y_rev, ry0 + p - n3));
+                        } else {
+                            const uint32_t alt = s_alt[c];
+                            if (alt) {
+                                int8_t v = 0;
+                                if (op == 3u) v = 2;
+                                else if (op == 1u) v = fsv_base_at(A.store, y_word, y_len, y_rev, ry0 + p - n3) + 1u == alt ? 1 : 2;
+                                S.vec[s_vbase + (uint32_t)s_sidx[c] * vstride + oi] = v;
+                            }
                         }
-                        if (op == 3u) n3++;
+                    }
+                    if (op == 3u) n3++;
+                }
+                return plen - n2;
+            };
+            // the window cigar in the middle; beside a junction whose re-aligned cigar is in use, that cigar (markSNP_advance :5054)
+            int cur_beg = 0, cur_end = 0x7fffffff;
+            if (S.bc_idx) {
+                const int32_t sb = j >= 1 ? S.bc_idx[ti - 1] : -1, se = j + 1 < o_n_win ? S.bc_idx[ti] : -1;
+                const uint4 rb = sb >= 0 ? S.bc_rec[sb] : make_uint4(0, 0, 0, 0), re = se >= 0 ? S.bc_rec[se] : make_uint4(0, 0, 0, 0);
+                if ((rb.x | re.x) & 1u) {
+                    const fsv_wtask t = A.tasks[ti];
+                    const int x_total_start = t.x_start, x_length = t.x_len, x_total_end = x_total_start + x_length - 1;
+                    if (rb.x & 1u) {
+                        const int bx = (int)rb.y, blen = (int)(rb.z & 0xffffu), bL = (int)((rb.z >> 16) & 0xffu), bR = (int)(rb.z >> 24);
+                        const int xleft = x_total_start - bx, xright = bx + blen - 1 - x_total_start + 1;
+                        if (xleft > bL && xright > bR) { cur_beg = xright - bR; walk(S.bc_paths + sb, bx, xleft, xleft + (xright - bR) - 1); }
+                    }
+                    if (re.x & 1u) {
+                        const int bx = (int)re.y, blen = (int)(re.z & 0xffffu), bL = (int)((re.z >> 16) & 0xffu), bR = (int)(re.z >> 24);
+                        const int xleft = x_total_end - bx, xright = bx + blen - 1 - x_total_end + 1;
+                        if (xleft > bL && xright > bR) { cur_end = (x_length - 1) - ((xleft + 1) - bL); walk(S.bc_paths + se, bx, bL, xleft); }
                     }
                 }
-            } else if (pass == 1) {
-                for (int c = xs; c < xs + plen; c++) if (s_alt[c]) S.vec[s_vbase + (uint32_t)s_sidx[c] * vstride + oi] = 0;
             }
+            const int xcols = walk(P, gs + xs, cur_beg, cur_end);
             if (pass == 0) {
-                const int xcols = plen - n2;   // clean paths: n2 = 0
                 atomicAdd(&s_cov[xs], 1);
                 atomicAdd(&s_cov[xs + xcols], -1);
             }

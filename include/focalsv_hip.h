@@ -174,6 +174,8 @@ typedef struct fsv_asm_params {
     int32_t graph_layout;     /* 1 (default): the layout as hifiasm-0.14 makes it -- chimeric-read detection, containment in read order, string graph with
                                * transitive reduction and tip cutting, unitig polishing (Overlaps.cpp:1698, 1031, 2152, 4531, 4666, 7759, 8480, 8893) --
                                * for every set that is not flagged FSV_SET_UNPHASED; 0: best-buddy chains (ONT profile, unphased sets) */
+    int32_t junction_cigars;  /* 1 (default): the haplotype partition reads the ~50 columns on each side of a window junction off the re-aligned
+                               * junction cigar, as hifiasm does (calculate_boundary_cigars, Correct.cpp:2310; markSNP_advance :5054); 0: window cigars */
 } fsv_asm_params;
 void fsv_asm_default_params(fsv_asm_params *p);
 /* ONT-profile reads (BASELINE configs[4]: ~10 % error): k = 15, w = 15 without homopolymer compression (a 30 kb read then has ~3 750 minimizers: below the 4 096 a list holds), chain indel budget 0.15 / 0.05,
@@ -256,6 +258,7 @@ typedef struct fsv_asm_stats {
     uint64_t n_exact_overlaps;  /* overlaps handed to the layout (exact, or inexact ones the last correction round verified) */
     uint64_t n_inexact_candidates; /* pairs re-chained with the gapped bandwidth in the final pass */
     uint64_t n_path_fr;         /* of those, distance <= 3: walked without the DP matrix (k_path_fr) */
+    uint64_t n_junction_cigars; /* junctions re-aligned for the haplotype partition (k_bcig_tasks) */
     double   ms_sketch, ms_chain, ms_verify, ms_path, ms_consensus, ms_final, ms_total;
     uint32_t n_kernels, pad;
     fsv_kernel_stat kernels[FSV_MAX_KERNEL_STATS];

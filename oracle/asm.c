@@ -1030,34 +1030,171 @@ static void k7_preorder(k7_ctx *C, int id, int plen)
     for (j = 0; j < C->bt_len[id]; j++) k7_preorder(C, C->bt[id][j], plen);
 }
 
-static void partition_read(const readset *R, int q, orc_ovl *ov, int n_ov, const orc_win *W)
+/* ---- the re-aligned junction cigars of an accepted overlap: calculate_boundary_cigars (Correct.cpp:2310-2530) --------------------
+ * For every junction between two matched windows of the overlap whose alignments do not simply meet (bases of y skipped or used
+ * twice, or an error within 10 columns of the junction on either side), up to 100 columns on each side of the junction are aligned
+ * once more with the doubled threshold (no fix_boundary, no cigar adjustment).  The new cigar is used by the haplotype partition
+ * for the ~50 columns on each side of the junction, in place of the two window cigars, unless it has clearly more errors there. */
+#define ORC_BC_SIDE 100        /* boundaryLen / 2 */
+#define ORC_BC_USELESS 50      /* force_useless_side */
+#define ORC_BC_SCAN 10
+typedef struct { int avail, x_start, x_end, ry_start, L, R, path_len; uint8_t path[2 * ORC_BC_SIDE + 2 * ORC_K_MAX + 8]; } orc_bcig;
+
+/* scan_cigar (Correct.cpp:1070-1200): errors met while the first (dir 0) / last (dir 1) scan_x columns of x go by; y-only ops count
+ * whenever they are met */
+static int scan_ops(const uint8_t *path, int plen, int scan_x, int dir)
+{
+    int x_i = 0, err = 0, p;
+    for (p = 0; p < plen; p++) {
+        const int op = path[dir ? plen - 1 - p : p];
+        if (op == 2) { err++; continue; }
+        if (op != 0) err++;
+        if (++x_i >= scan_x) return err;
+    }
+    return err;
+}
+/* scan_cigar_interval (Correct.cpp:1204-1290): errors over the columns [xb, xe] of x */
+static int scan_ops_interval(const uint8_t *path, int plen, int xb, int xe)
+{
+    int x_i = 0, err = 0, p;
+    for (p = 0; p < plen; p++) {
+        const int op = path[p];
+        if (op == 2) { err++; continue; }
+        if (x_i == xb) err = 0;
+        x_i++;
+        if (op != 0) err++;
+        if (x_i == xe + 1) return err;
+    }
+    return err;
+}
+
+static void boundary_cigars(const readset *R, const orc_asm_params *P, const orc_ovl *o, const orc_win *W, orc_bcig *bc)
+{
+    const char *x = R->seq[o->q], *y = R->seq[o->t];
+    const int ylen = R->len[o->t];
+    char ybuf[2 * ORC_BC_SIDE + 2 * ORC_K_MAX + 8];
+    static __thread uint64_t cols[5 * 4 * (ORC_WINDOW + 4)];
+    uint8_t tmp[2 * ORC_WINDOW + 4 * ORC_K_WIDE + 16];
+    int rl[2 * ORC_WINDOW + 64];
+    uint8_t ro[2 * ORC_WINDOW + 64];
+    int i;
+    for (i = 0; i + 1 < o->n_win; i++) {
+        const orc_win *w0 = &W[o->first_win + i], *w1 = &W[o->first_win + i + 1];
+        orc_win t;
+        int y_distance, y_start, x_start, x_end, leftLen, rightLen, xLen, thr, L, Rr, m_err, b_err, f_err, o_len;
+        bc[i].avail = 0;
+        if (w0->err < 0 || w1->err < 0) continue;
+        y_distance = w1->ry_start - w0->ry_end - 1;
+        if (y_distance == 0 && scan_ops(w0->path, w0->path_len, ORC_BC_SCAN, 1) == 0 && scan_ops(w1->path, w1->path_len, ORC_BC_SCAN, 0) == 0) continue;
+        y_start = w0->ry_end; x_start = w0->x_start + w0->x_len - 1;
+        leftLen = x_start - w0->x_start; if (y_start < leftLen) leftLen = y_start; if (leftLen > ORC_BC_SIDE) leftLen = ORC_BC_SIDE;
+        rightLen = w1->x_start + w1->x_len - x_start; if (ylen - y_start < rightLen) rightLen = ylen - y_start; if (rightLen > ORC_BC_SIDE) rightLen = ORC_BC_SIDE;
+        xLen = leftLen + rightLen; x_start -= leftLen; x_end = x_start + xLen - 1; y_start -= leftLen;
+        if (xLen <= 0) continue;
+        thr = orc_double_thr_p(P, orc_thr_for_len_p(P, xLen), xLen);
+        if (thr > ORC_K_MAX) continue;      /* (hifiasm's thresholds: 16 for 200 columns) */
+        memset(&t, 0, sizeof t);
+        t.x_start = x_start; t.x_len = (int16_t)xLen; t.k = (uint8_t)thr; t.y_start = y_start;
+        if (!window_verify(x, y, ylen, o->rev, &t, ybuf, P->k_cap)) continue;
+        o_len = xLen + 2 * thr - t.extra_begin - t.extra_end;
+        if (o_len < xLen || t.err < 0) continue;
+        window_path(x, y, ylen, o->rev, &t, ybuf, cols, tmp, rl, ro);
+        if (t.err < 0 || t.path_len > (int)sizeof bc[i].path) continue;
+        if (y_distance < 0) y_distance = -y_distance;
+        L = Rr = ORC_BC_USELESS;
+        if (i == 0 && x_start == W[o->first_win].x_start) L = 0;
+        if (i == o->n_win - 2 && x_end == W[o->first_win + o->n_win - 1].x_start + W[o->first_win + o->n_win - 1].x_len - 1) Rr = 0;
+        if (leftLen <= L || rightLen <= Rr) continue;
+        m_err = scan_ops_interval(t.path, t.path_len, L, xLen - Rr - 1);
+        b_err = scan_ops(w0->path, w0->path_len, leftLen - L, 1);
+        f_err = scan_ops(w1->path, w1->path_len, rightLen - Rr, 0);
+        if (f_err + b_err + y_distance + 1 < m_err) continue;
+        bc[i].avail = 1; bc[i].x_start = x_start; bc[i].x_end = x_end; bc[i].ry_start = t.ry_start; bc[i].L = L; bc[i].R = Rr;
+        bc[i].path_len = t.path_len; memcpy(bc[i].path, t.path, (size_t)t.path_len);
+    }
+}
+
+/* the columns [lo, hi] (local to the cigar's first column) of one cigar as evidence per window column: ev[column - gs] = 0 match,
+ * 1 + base mismatch, 5 x base without partner (markSNP_detail / addSNPtohaplotype_details, Correct.cpp:4998, :5247) */
+static void cigar_evidence(const uint8_t *path, int plen, int x0, int ry0, int lo, int hi, const char *y, int ylen, int rev, int gs, int glen, int8_t *ev)
+{
+    int x_i = 0, yp = ry0, p;
+    if (lo > hi) return;
+    for (p = 0; p < plen && x_i <= hi; p++) {
+        const int op = path[p];
+        if (op == 2) { yp++; continue; }
+        if (x_i >= lo) {
+            const int c = x0 + x_i - gs;
+            if (c >= 0 && c < glen) ev[c] = op == 0 ? 0 : op == 1 ? (int8_t)(1 + base2(ybase(y, ylen, rev, yp))) : 5;
+        }
+        if (op != 3) yp++;
+        x_i++;
+    }
+}
+
+/* what overlap o shows at the columns of grid window g: the window cigar in the middle, the junction cigars (where available) for
+ * the columns beside the two junctions (markSNP_advance / addSNPtohaplotype_advance, Correct.cpp:5054, :5351) */
+static void window_evidence(const readset *R, const orc_ovl *o, const orc_win *W, const orc_bcig *bc, int jw, int gs, int glen, int8_t *ev)
+{
+    const orc_win *w = &W[o->first_win + jw];
+    const char *y = R->seq[o->t];
+    const int ylen = R->len[o->t], x_total_start = w->x_start, x_length = w->x_len, x_total_end = x_total_start + x_length - 1;
+    int cur_beg = 0, cur_end = x_length - 1;
+    memset(ev, -1, (size_t)glen);
+    if (bc && jw >= 1 && bc[jw - 1].avail) {
+        const orc_bcig *b = &bc[jw - 1];
+        const int xleft = x_total_start - b->x_start, xright = b->x_end - x_total_start + 1;
+        if (xleft > b->L && xright > b->R) {
+            cur_beg = xright - b->R;
+            cigar_evidence(b->path, b->path_len, b->x_start, b->ry_start, xleft, xleft + (xright - b->R) - 1, y, ylen, o->rev, gs, glen, ev);
+        }
+    }
+    if (bc && jw < o->n_win - 1 && bc[jw].avail) {
+        const orc_bcig *b = &bc[jw];
+        const int xleft = x_total_end - b->x_start, xright = b->x_end - x_total_end + 1;
+        if (xleft > b->L && xright > b->R) {
+            cur_end = (x_length - 1) - ((xleft + 1) - b->L);
+            cigar_evidence(b->path, b->path_len, b->x_start, b->ry_start, xleft - ((xleft + 1) - b->L) + 1, xleft, y, ylen, o->rev, gs, glen, ev);
+        }
+    }
+    cigar_evidence(w->path, w->path_len, x_total_start, w->ry_start, cur_beg, cur_end, y, ylen, o->rev, gs, glen, ev);
+}
+
+static void partition_read(const readset *R, const orc_asm_params *P, int q, orc_ovl *ov, int n_ov, const orc_win *W)
 {
     const char *x = R->seq[q];
     int xlen = R->len[q], nwin = (xlen + ORC_WINDOW - 1) / ORC_WINDOW, g, i, j, o0 = 0, o1, n, nS = 0, capS = 0;
     snp_site *S = NULL;
     uint8_t flag[ORC_WINDOW + 1];
+    orc_bcig *bcs = NULL;
+    int *bc_off = NULL;
+    int8_t *evw;
     while (o0 < n_ov && (int)ov[o0].q != q) o0++;
     o1 = o0;
     while (o1 < n_ov && (int)ov[o1].q == q) o1++;
     n = o1 - o0;
     if (n == 0) return;
+    if (P->junction_cigars) {      /* calculate_boundary_cigars for every accepted overlap (Correct.cpp:3012) */
+        int tot = 0;
+        bc_off = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+        for (i = o0; i < o1; i++) { bc_off[i - o0] = tot; if (ov[i].is_match == 1 && ov[i].n_win > 1) tot += ov[i].n_win - 1; }
+        bc_off[n] = tot;
+        bcs = (orc_bcig *)malloc(sizeof(orc_bcig) * (size_t)(tot + 1));
+        for (i = o0; i < o1; i++) if (ov[i].is_match == 1 && ov[i].n_win > 1) boundary_cigars(R, P, &ov[i], W, bcs + bc_off[i - o0]);
+    }
+    evw = (int8_t *)malloc((size_t)n * (ORC_WINDOW + 1));
     for (g = 0; g < nwin; g++) {
         int gs = g * ORC_WINDOW, glen = (gs + ORC_WINDOW <= xlen ? ORC_WINDOW : xlen - gs), c, any = 0, nS_win = nS;
         memset(flag, 0, sizeof flag);
-        for (i = o0; i < o1; i++) { /* markSNP_detail: mismatch columns */
+        for (i = o0; i < o1; i++) { /* markSNP_advance: mismatch columns; what every overlap shows at every column of the window */
             const orc_ovl *o = &ov[i];
-            const orc_win *w;
-            int jw = g - o->x_s / ORC_WINDOW, xp, p;
+            int8_t *e = evw + (size_t)(i - o0) * (ORC_WINDOW + 1);
+            int jw = g - o->x_s / ORC_WINDOW;
+            memset(e, -1, (size_t)glen);
             if (o->is_match != 1 || jw < 0 || jw >= o->n_win) continue;
-            w = &W[o->first_win + jw];
-            if (w->err <= 0) continue;
-            xp = w->x_start - gs;
-            for (p = 0; p < w->path_len; p++) {
-                int op = w->path[p];
-                if (op == 2) continue;
-                if (op == 1 && flag[xp] < 127) { flag[xp]++; any = 1; }
-                xp++;
-            }
+            if (W[o->first_win + jw].err < 0) continue;
+            window_evidence(R, o, W, bcs && o->n_win > 1 ? bcs + bc_off[i - o0] : NULL, jw, gs, glen, e);
+            for (c = 0; c < glen; c++) if (e[c] >= 1 && e[c] <= 4 && flag[c] < 127) { flag[c]++; any = 1; }
         }
         if (!any) continue;
         for (c = 0; c < glen; c++) {
@@ -1065,30 +1202,11 @@ static void partition_read(const readset *R, int q, orc_ovl *ov, int n_ov, const
             int8_t *ev;
             if (flag[c] <= 1) continue;
             ev = (int8_t *)malloc((size_t)n);     /* -1 none, 0 same, 1..4 other base + 1, 5 gap */
-            memset(ev, -1, (size_t)n);
-            for (i = o0; i < o1; i++) { /* addSNPtohaplotype_details at column c */
-                const orc_ovl *o = &ov[i];
-                const orc_win *w;
-                const char *y = R->seq[o->t];
-                int ylen = R->len[o->t], jw = g - o->x_s / ORC_WINDOW, xp, yp, p;
-                if (o->is_match != 1 || jw < 0 || jw >= o->n_win) continue;
-                w = &W[o->first_win + jw];
-                if (w->err < 0) continue;
-                xp = w->x_start - gs; yp = w->ry_start;
-                if (c < xp || c >= xp + w->x_len) continue;
-                if (w->err == 0) { ev[i - o0] = 0; occ0++; continue; }
-                for (p = 0; p < w->path_len; p++) {
-                    int op = w->path[p];
-                    if (op == 2) { yp++; continue; }
-                    if (xp == c) {
-                        if (op == 0) { ev[i - o0] = 0; occ0++; }
-                        else if (op == 1) { b = base2(ybase(y, ylen, o->rev, yp)); ev[i - o0] = (int8_t)(1 + b); oa[b]++; occ1++; }
-                        else { ev[i - o0] = 5; occ2++; }
-                        break;
-                    }
-                    if (op != 3) yp++;
-                    xp++;
-                }
+            for (i = 0; i < n; i++) { /* addSNPtohaplotype_advance at column c */
+                ev[i] = evw[(size_t)i * (ORC_WINDOW + 1) + c];
+                if (ev[i] == 0) occ0++;
+                else if (ev[i] >= 1 && ev[i] <= 4) { oa[ev[i] - 1]++; occ1++; }
+                else if (ev[i] == 5) occ2++;
             }
             /* split_sub_list */
             mx = occ2; mi = -1;
@@ -1118,6 +1236,7 @@ static void partition_read(const readset *R, int q, orc_ovl *ov, int n_ov, const
          * contributes none, a read with more than 1 024 (512 once the sites beside another site are gone) is not partitioned */
         if (nS - nS_win > ORC_SITE_WIN_CAP) { while (nS > nS_win) free(S[--nS].vec); }
     }
+    free(evw); free(bcs); free(bc_off);
     if (nS > ORC_SITE_RAW_CAP) { for (j = 0; j < nS; j++) free(S[j].vec); free(S); return; }
     if (nS == 0) { free(S); return; }
     /* generate_haplotypes_DP: a site directly beside another one is dropped */
@@ -1190,7 +1309,7 @@ static void correction_round(readset *R, const orc_asm_params *P, int w, int do_
     sketch_set(R, P, w, &uq, &nuq);
     collect_overlaps(R, P, P->bw_ec, uq, nuq, &ov, &cq, &ct, &n_ov);
     W = align_overlaps(R, P, ov, n_ov, cq, ct, &n_win);
-    if (P->partition) for (q = 0; q < R->n; q++) partition_read(R, q, ov, n_ov, W); /* every read of every set, phased or not, as hifiasm */
+    if (P->partition) for (q = 0; q < R->n; q++) partition_read(R, P, q, ov, n_ov, W); /* every read of every set, phased or not, as hifiasm */
     for (q = 0; q < R->n; q++) {
         nseq[q] = (char *)malloc((size_t)R->len[q] * 2 + 64 + (size_t)ORC_WINDOW * 16);
         nlen[q] = correct_read(R, P, q, ov, n_ov, W, nseq[q]);
@@ -1215,6 +1334,7 @@ void orc_asm_default_params(orc_asm_params *P)
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->partition = 1;
     P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1; P->ins_dag = 1;
     P->min_anchors_final = 1; P->min_ovlp_final = 1; P->graph_layout = 1;
+    P->junction_cigars = 1;
     P->left_rescue = 0;   /* restated here, not yet in the HIP path: off so that the two stay bit-identical (it changes none of the golden sets) */
 }
 

@@ -43,6 +43,8 @@ typedef struct {
     int32_t min_ovlp_final;   /* shortest final overlap: 1 (the graph drops what is below 50 bases: ma_hit_cut) */
     int32_t graph_layout;     /* 1: the layout as hifiasm's string graph + unitig polishing (oracle/layout.c); 0: best-buddy chains (ONT profile) */
     int32_t left_rescue;      /* 1: the rescue pass also walks left from a matched window (recalcate_window_advance, Correct.cpp:2745-2905) */
+    int32_t junction_cigars;  /* 1: the haplotype partition reads the columns beside a window junction off the re-aligned junction cigar
+                                 (calculate_boundary_cigars, Correct.cpp:2310; markSNP_advance :5054) */
 } orc_asm_params;
 
 typedef struct {

@@ -90,7 +90,7 @@ def sketch(seq: str, w=51, k=51, hpc=1):
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "partition",
                                          "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "second_round", "ins_dag",
-                                         "min_anchors_final", "min_ovlp_final", "graph_layout", "left_rescue")]
+                                         "min_anchors_final", "min_ovlp_final", "graph_layout", "left_rescue", "junction_cigars")]
 
 
 def default_params():

@@ -161,7 +161,7 @@ def _round_sets(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
 # 14 055 -- round 3 checked: every window of all six overlaps is matched, so this is a vote, not the left-extension rescue pass round 2
 # suspected; that pass, recalcate_window_advance Correct.cpp:2745-2905, is restated in oracle/asm.c behind orc_asm_params.left_rescue
 # and changes neither set).  Listed so that a fix shows.
-KNOWN_ROUND1_DEVIATIONS = {77}
+KNOWN_ROUND1_DEVIATIONS = set()
 
 
 def _round_ids():
