@@ -54,7 +54,7 @@ class KernelStat(C.Structure):
 
 class AsmStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_pairs", "n_overlaps", "n_windows", "n_windows_matched", "n_paths", "n_path_dp",
-                                          "dp_columns", "algo_bytes", "n_exact_overlaps", "n_inexact_candidates", "n_path_fr", "n_junction_cigars")] + \
+                                          "dp_columns", "algo_bytes", "n_exact_overlaps", "n_inexact_candidates", "n_path_fr", "n_junction_cigars", "n_junction_used")] + \
                [(n, C.c_double) for n in ("ms_sketch", "ms_chain", "ms_verify", "ms_path", "ms_consensus", "ms_final", "ms_total")] + \
                [("n_kernels", C.c_uint32), ("pad", C.c_uint32), ("kernels", KernelStat * 16)]
 

@@ -848,14 +848,16 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             TRY(ensure(ctx, W.paths2, (size_t)task_cap * sizeof(fsv_wpath)));
             TRY(ensure(ctx, W.bc_idx, (size_t)task_cap * 4));
             TRY(ensure(ctx, W.bc_rec, (size_t)task_cap * sizeof(uint4)));
-            TRY(ensure(ctx, W.bc_win, (size_t)(n_gwin + 2) * 4));
-            FSV_HIP(ctx, hipMemsetAsync(W.bc_win.p, 0, (size_t)(n_gwin + 2) * 4, ctx->stream));
+            TRY(ensure(ctx, W.bc_win, (size_t)(n_gwin + 2) * 12));
+            hipLaunchKernelGGL(k_bcwin_init, dim3(fsv_grid_for(n_gwin + 2, 256)), dim3(256), 0, ctx->stream, (int32_t *)W.bc_win.p, n_gwin + 2);
+            FSV_HIP(ctx, hipGetLastError());
             BcigArgs BA;
             BA.tasks = (const fsv_wtask *)W.tasks.p; BA.paths = (const fsv_wpath *)W.paths.p; BA.n_tasks = ct + CT_TASKS;
             BA.pair_read = (const uint32_t *)W.pair_read.p; BA.read_dirty = (const uint32_t *)W.read_dirty.p; BA.gwin_off = (const uint32_t *)W.gwin_off.p;
             BA.thr_tab = (const uint8_t *)W.thr_tab.p; BA.k_cap = P.k_cap;
             BA.tasks2 = (fsv_wtask *)W.tasks2.p; BA.bc_idx = (int32_t *)W.bc_idx.p; BA.n_tasks2 = ct3 + CT_TASKS;
-            BA.res2 = (const fsv_wres *)W.res2.p; BA.paths2 = (const fsv_wpath *)W.paths2.p; BA.bc_rec = (uint4 *)W.bc_rec.p; BA.bc_win = (uint32_t *)W.bc_win.p;
+            BA.n_same = ct3 + CT_B_RETRY; BA.n_used = ct3 + CT_B_LIST;
+            BA.res2 = (const fsv_wres *)W.res2.p; BA.paths2 = (const fsv_wpath *)W.paths2.p; BA.bc_rec = (uint4 *)W.bc_rec.p; BA.bc_win = (int32_t *)W.bc_win.p;
             W.kt.begin(ctx, KN_PARTITION, 0);
             hipLaunchKernelGGL(k_bcig_tasks, dim3((fsv_grid_for(task_cap, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, BA);
             FSV_HIP(ctx, hipGetLastError());
@@ -870,7 +872,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             FSV_HIP(ctx, hipGetLastError());
             W.kt.end(ctx);
             SA.bc_idx = (const int32_t *)W.bc_idx.p; SA.bc_rec = (const uint4 *)W.bc_rec.p; SA.bc_paths = (const fsv_wpath *)W.paths2.p;
-            SL.bc_win = (const uint32_t *)W.bc_win.p;
+            SL.bc_win = (const int32_t *)W.bc_win.p;
         }
         // consensus of every window; with the haplotype partition (K7) on, the windows that hold a candidate site are listed on the
         // way, k_snp_sites / k_hap_partition take the overlaps with the other allele out (is_match 2 / 4: out of the consensus and,
@@ -1158,6 +1160,8 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             const uint64_t n3 = c3[CT_TASKS], n_dp3 = (uint64_t)c3[CT_DP_SB] + c3[CT_DP_SB16] + c3[CT_DP] + c3[CT_DP_FR3] + c3[CT_DP_GEN] + c3[CT_DP_WIDE] + c3[CT_DP_XW];
             n_windows2 += n3;
             W.stats.n_junction_cigars += n3;
+            W.stats.n_junction_used += c3[CT_B_LIST];
+            if (getenv("FSV_BCIG_DEBUG")) fprintf(stderr, "[fsv] round %d: %llu junction cigars, %u accepted but showing what the window cigars show, %u used\n", sl, (unsigned long long)n3, c3[CT_B_RETRY], c3[CT_B_LIST]);
             W.kt.recs[W.bc_bpm_rec[sl]].bytes = n3 * 212ull;
             if ((size_t)sl < W.bc_fast_rec.size()) W.kt.recs[W.bc_fast_rec[sl]].bytes = n3 * (16ull + 196ull) + (n3 - n_dp3) * 128ull;
             if ((size_t)sl < W.bc_dp_rec.size()) W.kt.recs[W.bc_dp_rec[sl]].bytes = n_dp3 * (196ull + 128ull);

@@ -1185,7 +1185,13 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     }
     P->ry_start = t.y_start - t.k + s2;
     P->ry_end = t.y_start - t.k + e2;
-    P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
+    uint32_t flags10 = 0;      // as in path_finish: an op other than a match among the first / last ten
+    if (r.err > 0) {
+        const int a = max(n - 10, 0), wi = a >> 4, sh = (a & 15) << 1;
+        const uint32_t lo = ops32[wi] >> sh, hi = (sh && wi + 1 < 26) ? ops32[wi + 1] << (32 - sh) : 0u;
+        flags10 = ((ops32[0] & 0xfffffu) ? 1u : 0u) | (((lo | hi) & 0xfffffu) ? 2u : 0u);
+    }
+    P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1; P->y_rev = t.y_rev; P->pad = (uint16_t)flags10; P->y_word = t.y_word; P->y_len = t.y_len;
     // a distance-0 record carries no ops: its consumers (k_consensus, k_het) look at err first and never read them, and in the
     // later correction rounds nearly every window is one -- 24 bytes out instead of 128
     if (r.err == 0 && !write_clean_ops) return;
@@ -1264,6 +1270,7 @@ __device__ __forceinline__ void path_finish(const uint32_t *__restrict__ store, 
     // pack start-to-end: output word wd holds the source fields plen-16-16wd .. plen-1-16wd in reverse order
     const int pl = min(plen, FSV_PATH_CAP);
     uint32_t *dst = reinterpret_cast<uint32_t *>(P->ops);
+    uint32_t head10 = 0;
     for (int wd = 0; wd < 26; wd++) {
         const int a = plen - 16 - 16 * wd;
         uint32_t v = 0;
@@ -1272,11 +1279,16 @@ __device__ __forceinline__ void path_finish(const uint32_t *__restrict__ store, 
             const uint32_t w0 = s_ops[wi][lane64], w1 = (sh && wi + 1 < 28) ? s_ops[wi + 1][lane64] : 0u;
             v = sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
         } else if (a > -16) v = s_ops[0][lane64] << ((-a) << 1);
-        dst[wd] = rev_fields2(v);
+        v = rev_fields2(v);
+        if (wd == 0) head10 = v & 0xfffffu;
+        dst[wd] = v;
     }
     P->ry_start = t.y_start - t.k + start;
     P->ry_end = t.y_start - t.k + end;
-    P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1; P->y_rev = t.y_rev; P->pad = 0; P->y_word = t.y_word; P->y_len = t.y_len;
+    // pad: bit 0 = an op other than a match among the first ten, bit 1 = among the last ten -- what scan_cigar (Correct.cpp:1070) over ten
+    // columns from either end asks about (calculate_boundary_cigars :2360; k_bcig_tasks reads the header only)
+    const uint32_t tail10 = s_ops[0][lane64] & 0xfffffu;
+    P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1; P->y_rev = t.y_rev; P->pad = (uint16_t)((head10 ? 1u : 0u) | (tail10 ? 2u : 0u)); P->y_word = t.y_word; P->y_len = t.y_len;
 }
 #undef TMP
 #undef TMP_SET
@@ -2174,7 +2186,10 @@ struct SiteLists {
     uint32_t *win_list;        // marked windows, [0] of win_n
     uint32_t *redo_list;       // windows of the reads that lost an overlap to the partition
     uint32_t *win_n;           // {marked windows, redo windows}
-    const uint32_t *bc_win;    // per grid window: a used junction cigar reaches into it (k_bcig_accept); nullptr: none anywhere
+    // per grid window, from k_bcig_accept (nullptr: no junction cigars anywhere): [0] a used junction cigar, or a window cigar it stands in
+    // for, has a mismatch in the window; [1] / [2] first / last column at which a used junction cigar shows something else than the
+    // window cigar ([1] > [2]: none)
+    const int32_t *bc_win;
 };
 template <int EVC, int MODE>
 __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32_t gw, const SiteLists &L)
@@ -2314,6 +2329,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     // columns, nearly every trip had some lane with a deviating column and the whole wave went through the decision six times.
     int arrived = before, farrived = fbefore;
     bool differs = false, site = false;
+    const int bc_lo = (MODE == 1 && L.bc_win) ? L.bc_win[3 * (size_t)gw + 1] : 1, bc_hi = (MODE == 1 && L.bc_win) ? L.bc_win[3 * (size_t)gw + 2] : 0;
     for (int c = c0; c < c1; c++) {
         arrived += COV_LO(s_cov[c]);
         farrived += COV_HI(s_cov[c]);
@@ -2334,6 +2350,9 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
             int oa[4], occ1 = 0;
 #pragma unroll
             for (int b = 0; b < 4; b++) { oa[b] = (int)CNT_GET(c, (uint32_t)b); occ1 += oa[b]; }
+            // (a column with two mismatch votes where some overlap's junction cigar shows something else than its window cigar: the
+            // tallies of the partition differ from these -- k_snp_sites decides)
+            if (occ1 > 1 && c >= bc_lo && c <= bc_hi) site = true;
             if (occ1 > 1) {
                 const int occ2 = (int)CNT_GET(c, 4u), occ0 = arrived - occ1 - occ2;
                 int mx = occ2, mi = -1;
@@ -2373,7 +2392,7 @@ __device__ __forceinline__ void consensus_window(const ConsArgs &A, const uint32
     if (MODE == 1) {
         // a window a used junction cigar reaches into is looked at by k_snp_sites whatever the window cigars say: what its overlaps
         // show beside the junction is read off that cigar there (markSNP_advance, Correct.cpp:5054)
-        const bool any_site = __ballot(site) != 0ull || (L.bc_win && L.bc_win[gw]);
+        const bool any_site = __ballot(site) != 0ull || (L.bc_win && L.bc_win[3 * (size_t)gw]);
         if (lane == 0) {
             L.site_cnt[gw] = any_site ? FSV_SITE_MARK : 0u;
             if (any_site) L.win_list[atomicAdd(&L.win_n[0], 1u)] = gw;
@@ -2430,7 +2449,8 @@ struct BcigArgs {
     const fsv_wtask *tasks; const fsv_wpath *paths; const uint32_t *n_tasks;     // the round's window tasks and their paths
     const uint32_t *pair_read, *read_dirty, *gwin_off; const uint8_t *thr_tab; int k_cap;
     fsv_wtask *tasks2; int32_t *bc_idx; uint32_t *n_tasks2;                      // junction tasks; bc_idx[window task] = the task of the junction behind it or -1
-    const fsv_wres *res2; const fsv_wpath *paths2; uint4 *bc_rec; uint32_t *bc_win;
+    const fsv_wres *res2; const fsv_wpath *paths2; uint4 *bc_rec; int32_t *bc_win;      // bc_win: see SiteLists
+    uint32_t *n_same, *n_used;      // statistics: accepted cigars that show what the window cigars show / that are used
 };
 // op i of a path record's 2-bit stream, through one cached word
 struct OpReader {
@@ -2470,6 +2490,12 @@ __device__ __forceinline__ int scan_ops_interval(const fsv_wpath *P, int plen, i
     return err;
 }
 
+__global__ void k_bcwin_init(int32_t *__restrict__ bc_win, uint32_t n_gwin)
+{
+    const uint32_t gw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw < n_gwin) { bc_win[3 * (size_t)gw] = 0; bc_win[3 * (size_t)gw + 1] = 0x7fffffff; bc_win[3 * (size_t)gw + 2] = -1; }
+}
+
 __global__ __launch_bounds__(256) void k_bcig_tasks(BcigArgs A)
 {
     const uint32_t n_tasks = min(*A.n_tasks, gridDim.x * blockDim.x);
@@ -2479,14 +2505,18 @@ __global__ __launch_bounds__(256) void k_bcig_tasks(BcigArgs A)
     if (ti >= n_tasks) return;
     A.bc_idx[ti] = -1;
     if (ti + 1 >= n_tasks) return;
-    const fsv_wtask t0 = A.tasks[ti], t1 = A.tasks[ti + 1];
-    if (t1.ovl != t0.ovl) return;                           // the overlap's last window
-    if (!A.read_dirty[A.pair_read[t0.ovl]]) return;         // every overlap of the read matches it base for base, window after window
+    // (the two headers say everything about the junction but where it lies: loaded together with the task, one round trip)
+    const fsv_wtask t0 = A.tasks[ti];
+    // a clean read (most reads from the second round on): every path at distance 0, every junction met -- its path records (a 128-byte
+    // line each for 16 bytes of header) are not even looked at
+    if (!A.read_dirty[A.pair_read[t0.ovl]]) return;
     const uint4 h0 = *reinterpret_cast<const uint4 *>(A.paths + ti), h1 = *reinterpret_cast<const uint4 *>(A.paths + ti + 1);
-    if ((h0.w & 0xffu) != 1u || (h1.w & 0xffu) != 1u) return;
+    if ((h0.w & 0xffu) != 1u || (h1.w & 0xffu) != 1u) return;     // (a path only exists for a matched window of an accepted overlap)
     const int y_distance = (int)h1.x - (int)h0.y - 1;
-    if (y_distance == 0 && scan_ops(A.paths + ti, (int)(int16_t)(h0.z & 0xffffu), (int)(int16_t)(h0.z >> 16), FSV_BC_SCAN, 1) == 0 &&
-        scan_ops(A.paths + ti + 1, (int)(int16_t)(h1.z & 0xffffu), (int)(int16_t)(h1.z >> 16), FSV_BC_SCAN, 0) == 0) return;
+    // nothing to re-align where the two alignments meet and neither shows an error within ten columns of the junction
+    if (y_distance == 0 && !((h0.w >> 16) & 2u) && !((h1.w >> 16) & 1u)) return;
+    const fsv_wtask t1 = A.tasks[ti + 1];
+    if (t1.ovl != t0.ovl) return;                           // the overlap's last window
     int y_start = (int)h0.y, x_start = t0.x_start + (int)t0.x_len - 1;
     const int leftLen = min(min(x_start - t0.x_start, y_start), FSV_BC_SIDE);
     const int rightLen = min(min(t1.x_start + (int)t1.x_len - x_start, t0.y_len - y_start), FSV_BC_SIDE);
@@ -2541,7 +2571,8 @@ __global__ __launch_bounds__(256) void k_bcig_accept(BcigArgs A)
     if (f_err + b_err + y_distance + 1 < m_err) return;
     // Does it show anything the window cigars do not?  Column by column over the columns it would be used for: the same op, and
     // for a column with a partner the same base of y (its position).
-    bool differs = false;
+    bool differs = false, mm0 = false, mm1 = false;
+    int lo0 = 0x7fffffff, hi0d = -1, lo1 = 0x7fffffff, hi1d = -1;      // first / last differing junction column on either side
     {
         // columns of the junction cigar that stand for window 0: [L, leftLen] (its last column included); for window 1:
         // [leftLen + 1, leftLen + 1 + (rightLen - 1 - R) - 1] (markSNP_advance's intervals, restated in snp_sites_window)
@@ -2561,26 +2592,39 @@ __global__ __launch_bounds__(256) void k_bcig_accept(BcigArgs A)
             op_out = 0u; y_out = y;
         };
         const int hi0 = leftLen;                                   // last junction column read for window 0
-        for (; xb <= hi0 && !differs; xb++) {
+        for (; xb <= hi0; xb++) {
             uint32_t ob, ow; int ybp, ywp;
             next(RB, pb, plb, eb, yb, ob, ybp);
             next(R0, p0, pl0, e0, y0, ow, ywp);
-            if (ob != ow || (ob != 3u && ybp != ywp)) differs = true;
+            if (ob != ow || (ob != 3u && ybp != ywp)) { if (lo0 > xb) lo0 = xb; hi0d = xb; }
+            if (ob == 1u || ow == 1u) mm0 = true;
         }
         // window 1: junction columns leftLen + 1 .. leftLen + (rightLen - 1 - R)
         int p1 = 0, y1 = (int)h1.x;
         const int hi1 = leftLen + (rightLen - 1 - R);
-        for (; xb <= hi1 && !differs; xb++) {
+        for (; xb <= hi1; xb++) {
             uint32_t ob, ow; int ybp, ywp;
             next(RB, pb, plb, eb, yb, ob, ybp);
             next(R1, p1, pl1, e1, y1, ow, ywp);
-            if (ob != ow || (ob != 3u && ybp != ywp)) differs = true;
+            if (ob != ow || (ob != 3u && ybp != ywp)) { if (lo1 > xb) lo1 = xb; hi1d = xb; }
+            if (ob == 1u || ow == 1u) mm1 = true;
         }
+        differs = lo0 <= hi0d || lo1 <= hi1d;
     }
-    if (!differs) return;
+    if (!differs) { atomicAdd(A.n_same, 1u); return; }
+    atomicAdd(A.n_used, 1u);
     A.bc_rec[slot] = make_uint4(1u, (uint32_t)w.x_start, (uint32_t)xLen | ((uint32_t)L << 16) | ((uint32_t)R << 24), 0u);
+    // what k_consensus needs to know about the two windows: the columns where the partition's tallies can differ from its own
     const uint32_t rd = A.pair_read[t0.ovl], g0 = A.gwin_off[rd] + (uint32_t)(t0.x_start / FSV_WINDOW);
-    A.bc_win[g0] = 1u; A.bc_win[g0 + 1] = 1u;
+    const int gs0 = (t0.x_start / FSV_WINDOW) * FSV_WINDOW;
+    if (lo0 <= hi0d) {
+        if (mm0) A.bc_win[3 * (size_t)g0] = 1;
+        atomicMin(&A.bc_win[3 * (size_t)g0 + 1], w.x_start + lo0 - gs0); atomicMax(&A.bc_win[3 * (size_t)g0 + 2], w.x_start + hi0d - gs0);
+    }
+    if (lo1 <= hi1d) {
+        if (mm1) A.bc_win[3 * (size_t)(g0 + 1)] = 1;
+        atomicMin(&A.bc_win[3 * (size_t)(g0 + 1) + 1], w.x_start + lo1 - gs0 - FSV_WINDOW); atomicMax(&A.bc_win[3 * (size_t)(g0 + 1) + 2], w.x_start + hi1d - gs0 - FSV_WINDOW);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_snp_sites / k_hap_partition

@@ -259,6 +259,7 @@ typedef struct fsv_asm_stats {
     uint64_t n_inexact_candidates; /* pairs re-chained with the gapped bandwidth in the final pass */
     uint64_t n_path_fr;         /* of those, distance <= 3: walked without the DP matrix (k_path_fr) */
     uint64_t n_junction_cigars; /* junctions re-aligned for the haplotype partition (k_bcig_tasks) */
+    uint64_t n_junction_used;   /* of those, cigars the partition reads (accepted, and showing something the window cigars do not) */
     double   ms_sketch, ms_chain, ms_verify, ms_path, ms_consensus, ms_final, ms_total;
     uint32_t n_kernels, pad;
     fsv_kernel_stat kernels[FSV_MAX_KERNEL_STATS];
