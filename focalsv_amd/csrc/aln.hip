@@ -369,13 +369,30 @@ __global__ __launch_bounds__(256) void k_thin_seeds(fsv_mz *__restrict__ mz, con
 // ------------------------------------------------------------------------------------------------ events
 // query base of the strand-oriented contig
 __device__ __forceinline__ uint32_t qbase(const uint32_t *__restrict__ store, uint32_t qw, int lenq, int rev, int p) { return fsv_base_at(store, qw, lenq, rev, p); }
+// target base of a reference window: 0-3, or 4 where the window has an N (nm: one word per 16 bases, bit j = base j is an N; nullptr:
+// the batch has no N at all).  An N pairs with nothing (no padding, no gap-free run across it, no exact match) and costs
+// FSV_SC_AMBI in a score, as in minimap2 (sc_ambi = 1: the alignment runs through a short run of N as 'M').  In the 2-bit store an
+// N holds a base hashed from its position (k_pack_ascii): the seeds of an N run then look like random sequence, unique and
+// matching nothing, where minimap2 skips k-mers with an N.
+#define FSV_SC_AMBI 1
+__device__ __forceinline__ uint32_t tbase(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, uint32_t tw, int p)
+{
+    if (nm && ((nm[tw + ((uint32_t)p >> 4)] >> ((uint32_t)p & 15u)) & 1u)) return 4u;
+    return fsv_base_fwd(store, tw, p);
+}
+__device__ __forceinline__ int pair_score(uint32_t qb, uint32_t tb, const fsv_aln_params &P) { return tb > 3u ? -FSV_SC_AMBI : (qb == tb ? P.a : -P.b); }
+__host__ __device__ __forceinline__ uint32_t n_substitute(uint32_t pos)
+{
+    uint32_t x = pos * 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    return x >> 30;
+}
 
 // GLOBAL: the box of an oversize event (k_chain_aln<true>): the chain carries its two fixed end pairs, the walk runs from the
 // box's first base pair to its last (no X-drop extension, no clips).
 // An event of more than max_cells cells is not handed to the DP: it is listed with qs = -1 - qs, WITHOUT its padding (the box
 // between the two anchors) -- the host has it seeded again (first level) or closed from its corners (k_corner, inside a box).
 template <bool GLOBAL>
-__global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
                                                     const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                     const uint32_t *__restrict__ pair_t, const uint64_t *__restrict__ chain,
                                                     AlnHeader *__restrict__ hdr, AlnEvent *__restrict__ events, AlnEvent *__restrict__ packed,
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
         uint8_t cls = 2;
         if (dq == dt) {
             int mm = 0;
-            for (int k2 = 1; k2 <= dq && mm <= P.max_mm_run; k2++) mm += qbase(store, qw, lenq, rev, q0 + k2) != fsv_base_fwd(store, tw, t0 + k2);
+            for (int k2 = 1; k2 <= dq && mm <= P.max_mm_run; k2++) mm += qbase(store, qw, lenq, rev, q0 + k2) != tbase(store, nm, tw, t0 + k2);
             cls = mm == 0 ? 0 : (mm <= P.max_mm_run ? 1 : 2);
         }
         s_cls[s] = cls;
@@ -408,14 +425,14 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
         const int qs0 = CQ(0) - P.k + 1, ts0 = CT(0) - P.k + 1;
         int x = 0, best = 0, bi = 0;
         for (int i = 1; qs0 - i >= 0 && ts0 - i >= 0; i++) {
-            x += qbase(store, qw, lenq, rev, qs0 - i) == fsv_base_fwd(store, tw, ts0 - i) ? P.a : -P.b;
+            x += pair_score(qbase(store, qw, lenq, rev, qs0 - i), tbase(store, nm, tw, ts0 - i), P);
             if (x > best) { best = x; bi = i; }
             if (best - x > P.xdrop) break;
         }
         qbeg = qs0 - bi; tbeg = ts0 - bi;
         x = 0; best = 0; bi = 0;
         for (int i = 1; CQ(nch - 1) + i < lenq && CT(nch - 1) + i < lent; i++) {
-            x += qbase(store, qw, lenq, rev, CQ(nch - 1) + i) == fsv_base_fwd(store, tw, CT(nch - 1) + i) ? P.a : -P.b;
+            x += pair_score(qbase(store, qw, lenq, rev, CQ(nch - 1) + i), tbase(store, nm, tw, CT(nch - 1) + i), P);
             if (x > best) { best = x; bi = i; }
             if (best - x > P.xdrop) break;
         }
@@ -430,12 +447,12 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
         int eqs = CQ(s) + 1, eqe = CQ(e + 1), ets = CT(s) + 1, ete = CT(e + 1);
         int lp = 0, rp = 0;
         int lim_l = min(eqs - mstart_q, P.pad);
-        while (lp < lim_l && qbase(store, qw, lenq, rev, eqs - 1 - lp) == fsv_base_fwd(store, tw, ets - 1 - lp)) lp++;
+        while (lp < lim_l && qbase(store, qw, lenq, rev, eqs - 1 - lp) == tbase(store, nm, tw, ets - 1 - lp)) lp++;
         int lim_r = P.pad;
         if (eqe + lim_r > qend) lim_r = qend - eqe;
         if (ete + lim_r > tend) lim_r = tend - ete;
         { int nx = e + 1; while (nx < nseg && s_cls[nx] < 2) nx++; if (nx < nseg && eqe + lim_r > CQ(nx)) lim_r = CQ(nx) - eqe; }
-        while (rp < lim_r && qbase(store, qw, lenq, rev, eqe + 1 + rp) == fsv_base_fwd(store, tw, ete + 1 + rp)) rp++;
+        while (rp < lim_r && qbase(store, qw, lenq, rev, eqe + 1 + rp) == tbase(store, nm, tw, ete + 1 + rp)) rp++;
         if (ne >= ALN_EV_CAP) { status = FSV_ECAP; break; }
         if ((long long)(eqe - eqs + 1 + lp + rp) * (ete - ets + 1 + lp + rp) > P.max_cells) {
             ev[ne].qs = -1 - eqs; ev[ne].qe = eqe; ev[ne].ts = ets; ev[ne].te = ete; ne++;
@@ -461,9 +478,9 @@ __global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__
 // The two sides of an event's box as sequences of their own (strand-oriented, word-aligned) in a second store, where the
 // seeding / chaining / event kernels see them as an ordinary (contig, window) pair.  One thread per output word.
 struct BoxSrc { uint32_t src_word; int32_t src_len, rev, start; };     // source read (word offset, length, strand), first base of the box side
-__global__ __launch_bounds__(256) void k_extract_boxes(const uint32_t *__restrict__ src_store, const BoxSrc *__restrict__ box,
+__global__ __launch_bounds__(256) void k_extract_boxes(const uint32_t *__restrict__ src_store, const uint32_t *__restrict__ src_nm, const BoxSrc *__restrict__ box,
                                                        const uint32_t *__restrict__ word_off, const int32_t *__restrict__ read_len,
-                                                       uint32_t n_seq, uint32_t total_words, uint32_t *__restrict__ words)
+                                                       uint32_t n_seq, uint32_t total_words, uint32_t *__restrict__ words, uint32_t *__restrict__ nm_out)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= total_words) return;
@@ -474,6 +491,11 @@ __global__ __launch_bounds__(256) void k_extract_boxes(const uint32_t *__restric
     uint32_t v = 0;
     for (int j = 0; j < 16 && b0 + j < len; j++) v |= fsv_base_at(src_store, b.src_word, b.src_len, b.rev, b.start + b0 + j) << (2 * j);
     words[w] = v;
+    if (nm_out) {      // the N positions of the side (only a reference window has any; it is never read on the other strand)
+        uint32_t m = 0;
+        if (!b.rev) for (int j = 0; j < 16 && b0 + j < len; j++) { const int sp = b.start + b0 + j; m |= ((src_nm[b.src_word + ((uint32_t)sp >> 4)] >> ((uint32_t)sp & 15u)) & 1u) << j; }
+        nm_out[w] = m;
+    }
 }
 
 // An event of a box's inner walk that is still larger than max_cells (nothing in it could be seeded: unrelated sequence, or a
@@ -481,7 +503,7 @@ __global__ __launch_bounds__(256) void k_extract_boxes(const uint32_t *__restric
 // deletion (oracle/aln.c:corner_event).  One wavefront per event, 64 positions per step: the running score is a prefix sum,
 // the running best a prefix maximum, the first position where best - score > xdrop ends the run.
 struct CornerTask { uint32_t pair; int32_t qs, ql, ts, tl; };
-__global__ __launch_bounds__(64) void k_corner(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(64) void k_corner(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
                                                const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                                const CornerTask *__restrict__ tasks, int2 *__restrict__ out, fsv_aln_params P)
@@ -500,7 +522,7 @@ __global__ __launch_bounds__(64) void k_corner(const uint32_t *__restrict__ stor
             int d = 0;
             if (i < n) {
                 const int qp = side == 0 ? T.qs + i : T.qs + T.ql - 1 - i, tp = side == 0 ? T.ts + i : T.ts + T.tl - 1 - i;
-                d = qbase(store, qw, lenq, rev, qp) == fsv_base_fwd(store, tw, tp) ? P.a : -P.b;
+                d = pair_score(qbase(store, qw, lenq, rev, qp), tbase(store, nm, tw, tp), P);
             }
             int x = d;
             for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(x, off, 64); if (lane >= off) x += o; }
@@ -531,7 +553,7 @@ __global__ __launch_bounds__(64) void k_corner(const uint32_t *__restrict__ stor
 // all gaps of the batch at once (one wavefront per gap, 64 positions per step); the host then applies the shifts in CIGAR
 // order, each bounded by the M run in front of it.
 struct GapQuery { uint32_t slot; int32_t is_ins, off, len, cap; };
-__global__ __launch_bounds__(64) void k_gap_shift(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(64) void k_gap_shift(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
                                                   const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                   const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                                   const GapQuery *__restrict__ gaps, int32_t *__restrict__ max_shift)
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(64) void k_gap_shift(const uint32_t *__restrict__ s
         if (l < g.cap) {
             const int a = g.off - 1 - l, b = g.off + g.len - 1 - l;
             stop = g.is_ins ? qbase(store, qw, lenq, rev, a) != qbase(store, qw, lenq, rev, b)
-                            : fsv_base_fwd(store, tw, a) != fsv_base_fwd(store, tw, b);
+                            : tbase(store, nm, tw, a) != tbase(store, nm, tw, b);
         }
         const uint64_t m = __ballot(stop);
         if (m) { res = base + (int)__ffsll((long long)m) - 1; break; }
@@ -596,7 +618,7 @@ __device__ __forceinline__ void nw_cell(const NwRows &R, int d, int i, int j, ui
         const int hleft = max(g1, g2); // H(i, -1)
         b = hleft - P.q - P.e; if (two) b2 = hleft - P.q2 - P.e2;
     } else { b = R.F(d - 1)[xf]; if (two) b2 = R.F2(d - 1)[xf]; }
-    int32_t h = hdiag + (tb == qb ? P.a : -P.b);
+    int32_t h = hdiag + pair_score(qb, tb, P);
     uint8_t dd = 0;
     if (a > h) { h = a; dd = 1; }
     if (b > h) { h = b; dd = 2; }
@@ -677,7 +699,7 @@ __device__ __forceinline__ void nw_backtrack(const uint8_t *__restrict__ bt, int
 // sweep, so its query bases sit in registers; the target bases of the rows the sweep is crossing sit in an LDS ring that the
 // workgroup refills every CH diagonals.  No global load on the per-diagonal critical path.
 template <int QCAP, int NT>
-__global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
                                            const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                            const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                            const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all,
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, c
     for (int d = 0; d <= ql + tl - 2; d++) {
         if (d % CH == 0) {
             // rows d .. d+CH-1 enter the sweep during the next CH diagonals; rows below d-ql+1 have left it
-            for (int i = d + tid; i < min(d + CH, tl); i += NT) s_t[i & (TB - 1)] = (uint8_t)fsv_base_fwd(store, tw, T.ts + i);
+            for (int i = d + tid; i < min(d + CH, tl); i += NT) s_t[i & (TB - 1)] = (uint8_t)tbase(store, nm, tw, T.ts + i);
             __syncthreads();
         }
 #pragma unroll
@@ -725,7 +747,7 @@ __global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, c
 // ring.  With the rows of such an event in ONE wavefront a diagonal costs a single-wave barrier; round 1 sent these events to
 // k_nw<3072, 1024>, where each of their ~2 000 diagonals paid a 16-wave barrier for a few dozen cells (7.3 ms per bench step).
 template <int RCAP, int NT>
-__global__ __launch_bounds__(NT) void k_nw_rows(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(NT) void k_nw_rows(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
                                                 const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                 const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                                 const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all,
@@ -747,7 +769,7 @@ __global__ __launch_bounds__(NT) void k_nw_rows(const uint32_t *__restrict__ sto
     uint8_t *bt = bt_all + T.bt_off;
     uint32_t tb[C];
 #pragma unroll
-    for (int m = 0; m < C; m++) { const int i = tid + m * NT; tb[m] = i < tl ? fsv_base_fwd(store, tw, T.ts + i) : 0u; }
+    for (int m = 0; m < C; m++) { const int i = tid + m * NT; tb[m] = i < tl ? tbase(store, nm, tw, T.ts + i) : 0u; }
     for (int d = 0; d <= ql + tl - 2; d++) {
         if (d % CH == 0) {
             // columns d .. d+CH-1 enter the sweep during the next CH diagonals; columns below d-tl+1 have left it
@@ -767,7 +789,7 @@ __global__ __launch_bounds__(NT) void k_nw_rows(const uint32_t *__restrict__ sto
 }
 
 // Any query length: rolling rows in HBM, bases fetched per cell (events with queries above NW_LDS_Q bases: rare, slow path)
-__global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ store, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
                                                 const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                 const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                                 const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all, int32_t *__restrict__ rows_all,
@@ -786,7 +808,7 @@ __global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ sto
         const int jlo = max(0, d - (tl - 1)), jhi = min(ql - 1, d);
         for (int j = jlo + (int)threadIdx.x; j <= jhi; j += blockDim.x) {
             const int i = d - j;
-            nw_cell(R, d, i, j, fsv_base_fwd(store, tw, T.ts + i), qbase(store, qw, lenq, rev, T.qs + j), two, P, bt, ql);
+            nw_cell(R, d, i, j, tbase(store, nm, tw, T.ts + i), qbase(store, qw, lenq, rev, T.qs + j), two, P, bt, ql);
         }
         __threadfence_block();
         __syncthreads();
@@ -799,13 +821,15 @@ __global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ sto
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 struct AlnWs {
-    DevBuf store, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, ev_packed, ev_count, tasks, bt, rows, cg, cg_n, scores, gaps, gap_shift, thin, box_src, corner, corner_out;
+    DevBuf store, nmask, ascii, asc_off, word_off, len, wper, pair_q, pair_t, sk_ends, sk_low, sk_high, mz, mz_off, mz_cnt, warn, chain, hdr, events, ev_packed, ev_count, tasks, bt, rows, cg, cg_n, scores, gaps, gap_shift, thin, box_src, corner, corner_out;
     fsv_aln_stats stats;
     // the size classes of the event DP run side by side: a class is a handful of long-running blocks, never a full chip
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     AlnWs *sub = nullptr;       // the workspace of the boxes of oversize events (a second, smaller alignment pass)
-    std::vector<DevBuf *> all() { return {&store, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores, &gaps, &gap_shift, &thin, &box_src, &corner, &corner_out}; }
+    bool has_n = false;         // some reference window of the batch has an N: the kernels get the mask (nullptr otherwise)
+    const uint32_t *nm() const { return has_n ? (const uint32_t *)nmask.p : nullptr; }
+    std::vector<DevBuf *> all() { return {&store, &nmask, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores, &gaps, &gap_shift, &thin, &box_src, &corner, &corner_out}; }
 };
 
 void aln_ws_release(AlnWs *w)
@@ -853,11 +877,11 @@ struct Timer {
 };
 
 // packs pairs (query, target) into a store; returns lens / offsets
-// ASCII -> 2-bit store on the device: one thread per output word, 16 source bytes each (N and anything else -> A,
-// as fsv_pack_reads does on the host)
+// ASCII -> 2-bit store on the device: one thread per output word, 16 source bytes each.  Without nm_out N and anything else -> A, as
+// fsv_pack_reads does on the host; with it (a batch that holds an N) an N gets a base hashed from its position and its mask bit
 __global__ __launch_bounds__(256) void k_pack_ascii(const char *__restrict__ ascii, const uint64_t *__restrict__ asc_off,
                                                     const uint32_t *__restrict__ word_off, const int32_t *__restrict__ read_len,
-                                                    uint32_t n_reads, uint32_t total_words, uint32_t *__restrict__ words)
+                                                    uint32_t n_reads, uint32_t total_words, uint32_t *__restrict__ words, uint32_t *__restrict__ nm_out)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= total_words) return;
@@ -867,13 +891,15 @@ __global__ __launch_bounds__(256) void k_pack_ascii(const char *__restrict__ asc
     const int len = read_len[r];
     const int b0 = (int)(w - word_off[r]) * 16;
     const char *src = ascii + asc_off[r] + b0;
-    uint32_t v = 0;
+    uint32_t v = 0, m = 0;
     for (int j = 0; j < 16 && b0 + j < len; j++) {
         const char c = src[j];
-        const uint32_t code = (c == 'C' || c == 'c') ? 1u : (c == 'G' || c == 'g') ? 2u : (c == 'T' || c == 't') ? 3u : 0u;
+        uint32_t code = (c == 'C' || c == 'c') ? 1u : (c == 'G' || c == 'g') ? 2u : (c == 'T' || c == 't') ? 3u : 0u;
+        if (nm_out && code == 0u && c != 'A' && c != 'a') { code = n_substitute((uint32_t)(b0 + j)); m |= 1u << j; }     // N (anything else): see tbase
         v |= code << (2 * j);
     }
     words[w] = v;
+    if (nm_out) nm_out[w] = m;
 }
 
 // sequences (already concatenated by the caller in two buffers: reference windows, contigs) -> device 2-bit store
@@ -908,8 +934,16 @@ int pack_pairs(fsv_ctx *ctx, AlnWs &W, const std::vector<const char *> &seq, con
     TRY(upload(ctx, W.len, len));
     TRY(ensure(ctx, W.store, (w + 8) * 4));
     FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.store.p + w, 0, 32, ctx->stream));
+    // does any sequence that comes from the host (the reference windows; contigs handed over as text) hold anything but ACGT?
+    // (13 MB of text per 256 regions: a millisecond of the host's time, off the GPU's path)
+    W.has_n = false;
+    for (uint32_t r = 0; r < n_host && !W.has_n; r++) {
+        const char *sq = seq[r];
+        for (uint64_t i = 0; i < slen[r]; i++) { const char c = (char)(sq[i] & ~0x20); if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { W.has_n = true; break; } }
+    }
+    if (W.has_n) { TRY(ensure(ctx, W.nmask, (w + 8) * 4)); FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.nmask.p + w, 0, 32, ctx->stream)); }
     hipLaunchKernelGGL(k_pack_ascii, dim3(fsv_grid_for(w, 256)), dim3(256), 0, ctx->stream, (const char *)W.ascii.p, (const uint64_t *)W.asc_off.p,
-                       (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, n, (uint32_t)w, (uint32_t *)W.store.p);
+                       (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, n, (uint32_t)w, (uint32_t *)W.store.p, W.has_n ? (uint32_t *)W.nmask.p : (uint32_t *)nullptr);
     FSV_HIP(ctx, hipGetLastError());
     return FSV_OK;
 }
@@ -953,24 +987,24 @@ int run_nw(fsv_ctx *ctx, AlnWs &W, const std::vector<NwTask> &tasks, uint64_t bt
     for (int c = 1; c < 4; c++)
         if (cls_end[c] > cls_end[c - 1]) { used[c] = true; FSV_HIP(ctx, hipStreamWaitEvent(W.side[c - 1], W.fork, 0)); }
     if (cls_end[0])
-        hipLaunchKernelGGL((k_nw<256, 64>), dim3((uint32_t)cls_end[0]), dim3(64), 0, lane(0), (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+        hipLaunchKernelGGL((k_nw<256, 64>), dim3((uint32_t)cls_end[0]), dim3(64), 0, lane(0), (const uint32_t *)W.store.p, W.nm(), (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
                            (const NwTask *)W.tasks.p, (uint8_t *)W.bt.p, (uint32_t *)W.cg.p, (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
     if (used[1])
-        hipLaunchKernelGGL((k_nw<NW_LDS_Q, 1024>), dim3((uint32_t)(cls_end[1] - cls_end[0])), dim3(1024), 0, lane(1), (const uint32_t *)W.store.p,
+        hipLaunchKernelGGL((k_nw<NW_LDS_Q, 1024>), dim3((uint32_t)(cls_end[1] - cls_end[0])), dim3(1024), 0, lane(1), (const uint32_t *)W.store.p, W.nm(),
                            (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
                            (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + cls_end[0], (uint8_t *)W.bt.p, (uint32_t *)W.cg.p,
                            (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
     if (used[2])
-        hipLaunchKernelGGL(k_nw_any, dim3((uint32_t)(cls_end[2] - cls_end[1])), dim3(256), 0, lane(2), (const uint32_t *)W.store.p,
+        hipLaunchKernelGGL(k_nw_any, dim3((uint32_t)(cls_end[2] - cls_end[1])), dim3(256), 0, lane(2), (const uint32_t *)W.store.p, W.nm(),
                            (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
                            (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + cls_end[1], (uint8_t *)W.bt.p, (int32_t *)W.rows.p, (uint32_t *)W.cg.p,
                            (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
     FSV_HIP(ctx, hipGetLastError());
     if (used[3])
-        hipLaunchKernelGGL((k_nw_rows<256, 64>), dim3((uint32_t)(cls_end[3] - cls_end[2])), dim3(64), 0, lane(3), (const uint32_t *)W.store.p,
+        hipLaunchKernelGGL((k_nw_rows<256, 64>), dim3((uint32_t)(cls_end[3] - cls_end[2])), dim3(64), 0, lane(3), (const uint32_t *)W.store.p, W.nm(),
                            (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p,
                            (const AlnHeader *)W.hdr.p, (const NwTask *)W.tasks.p + cls_end[2], (uint8_t *)W.bt.p, (uint32_t *)W.cg.p,
                            (uint32_t *)W.cg_n.p, (int32_t *)W.scores.p, P);
@@ -1094,11 +1128,11 @@ int align_pass(fsv_ctx *ctx, AlnWs &W, const PassIn &S, const fsv_aln_params &P,
     TRY(ensure(ctx, W.ev_count, 16));
     FSV_HIP(ctx, hipMemsetAsync(W.ev_count.p, 0, 4, ctx->stream));
     if (depth == 0)
-        hipLaunchKernelGGL(k_aln_events<false>, dim3(ns), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+        hipLaunchKernelGGL(k_aln_events<false>, dim3(ns), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, W.nm(), (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const uint64_t *)W.chain.p,
                            (AlnHeader *)W.hdr.p, (AlnEvent *)W.events.p, (AlnEvent *)W.ev_packed.p, (uint32_t *)W.ev_count.p, P);
     else
-        hipLaunchKernelGGL(k_aln_events<true>, dim3(ns), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+        hipLaunchKernelGGL(k_aln_events<true>, dim3(ns), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, W.nm(), (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const uint64_t *)W.chain.p,
                            (AlnHeader *)W.hdr.p, (AlnEvent *)W.events.p, (AlnEvent *)W.ev_packed.p, (uint32_t *)W.ev_count.p, P);
     FSV_HIP(ctx, hipGetLastError());
@@ -1194,8 +1228,10 @@ int align_pass(fsv_ctx *ctx, AlnWs &W, const PassIn &S, const fsv_aln_params &P,
         TRY(upload(ctx, W2.box_src, src));
         TRY(ensure(ctx, W2.store, (w + 8) * 4));
         FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W2.store.p + w, 0, 32, ctx->stream));
-        hipLaunchKernelGGL(k_extract_boxes, dim3(fsv_grid_for(w, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, (const BoxSrc *)W2.box_src.p,
-                           (const uint32_t *)W2.word_off.p, (const int32_t *)W2.len.p, 2 * nb, (uint32_t)w, (uint32_t *)W2.store.p);
+        W2.has_n = W.has_n;
+        if (W.has_n) { TRY(ensure(ctx, W2.nmask, (w + 8) * 4)); FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W2.nmask.p + w, 0, 32, ctx->stream)); }
+        hipLaunchKernelGGL(k_extract_boxes, dim3(fsv_grid_for(w, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, W.nm(), (const BoxSrc *)W2.box_src.p,
+                           (const uint32_t *)W2.word_off.p, (const int32_t *)W2.len.p, 2 * nb, (uint32_t)w, (uint32_t *)W2.store.p, W.has_n ? (uint32_t *)W2.nmask.p : (uint32_t *)nullptr);
         FSV_HIP(ctx, hipGetLastError());
         PassOut O2;
         TRY(align_pass(ctx, W2, S2, P, 1, O2, nullptr));
@@ -1211,7 +1247,7 @@ int align_pass(fsv_ctx *ctx, AlnWs &W, const PassIn &S, const fsv_aln_params &P,
         std::vector<int2> lr(bigs.size());
         TRY(upload(ctx, W.corner, ct));
         TRY(ensure(ctx, W.corner_out, bigs.size() * sizeof(int2)));
-        hipLaunchKernelGGL(k_corner, dim3((uint32_t)bigs.size()), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+        hipLaunchKernelGGL(k_corner, dim3((uint32_t)bigs.size()), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, W.nm(), (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
                            (const CornerTask *)W.corner.p, (int2 *)W.corner_out.p, P);
         FSV_HIP(ctx, hipGetLastError());
@@ -1405,7 +1441,7 @@ static int align_batch_impl(fsv_ctx *ctx, const char *contig_seq, const uint64_t
     if (!gaps.empty()) {
         TRY(upload(ctx, W.gaps, gaps));
         TRY(ensure(ctx, W.gap_shift, gaps.size() * 4));
-        hipLaunchKernelGGL(k_gap_shift, dim3((uint32_t)gaps.size()), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, (const uint32_t *)W.word_off.p,
+        hipLaunchKernelGGL(k_gap_shift, dim3((uint32_t)gaps.size()), dim3(64), 0, ctx->stream, (const uint32_t *)W.store.p, W.nm(), (const uint32_t *)W.word_off.p,
                            (const int32_t *)W.len.p, (const uint32_t *)W.pair_q.p, (const uint32_t *)W.pair_t.p, (const AlnHeader *)W.hdr.p,
                            (const GapQuery *)W.gaps.p, (int32_t *)W.gap_shift.p);
         FSV_HIP(ctx, hipGetLastError());

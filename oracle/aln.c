@@ -27,6 +27,22 @@
 #include "oracle.h"
 
 static char comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+/* A reference window may hold N (anything that is not A/C/G/T).  An N pairs with nothing -- no gap-free run, no padding, no exact
+ * match across it -- and costs ORC_SC_AMBI in a score, as in minimap2 (sc_ambi = 1: the alignment runs through a short run of N
+ * as 'M').  For SEEDING an N holds a base hashed from its position in the window (n_substitute: the HIP path's 2-bit store has to
+ * hold something): the k-mers of an N run then look like random sequence, unique and matching nothing, where minimap2 skips
+ * k-mers with an N; a k-mer with one or two N can still seed where the contig happens to carry the hashed base -- on the true diagonal. */
+#define ORC_SC_AMBI 1
+static inline int is_acgt(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+static inline int pair_score(char qc, char tc, const orc_aln_params *P) { return !is_acgt(tc) ? -ORC_SC_AMBI : (qc == tc ? P->a : -P->b); }
+static inline uint32_t n_substitute(uint32_t pos)
+{
+    uint32_t x = pos * 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    return x >> 30;
+}
+/* the window of the alignment in progress and its seeding copy (NULL: no N in it): sub_align seeds a box from the copy */
+static __thread const char *g_ref = NULL, *g_ref_seed = NULL;
+static __thread int g_ref_len = 0;
 
 void orc_aln_default_params(orc_aln_params *P)
 {
@@ -72,7 +88,7 @@ int orc_nw(const char *t, int tl, const char *q, int ql, const orc_aln_params *P
             f = hleft - P->q - P->e; f2 = two ? hleft - P->q2 - P->e2 : NEG;
             hdiag = H[0]; /* H(i-1, -1) */
             for (j = 1; j <= ql; j++) {
-                int32_t z = hdiag + (t[i] == q[j - 1] && t[i] != 'N' ? P->a : -P->b);
+                int32_t z = hdiag + pair_score(q[j - 1], t[i], P);
                 int32_t a = E[j], b = f, a2 = E2[j], b2 = f2, h, o;
                 uint8_t d = 0;
                 h = z;
@@ -274,12 +290,20 @@ static void push(uint32_t *cg, int *n, int cap, uint32_t op, uint32_t len)
  * sides, move it left while the base entering the gap on the left equals the base leaving it on the right", bounded by the
  * preceding M run; an M run shifted away completely leaves two neighbouring gap ops, same-op neighbours are merged).
  * A deletion compares reference bases only, an insertion query bases only, so the alignment score is unchanged.
- * Anything that is not A/C/G/T compares as 'A' (the device store has two bits per base). */
+ * On the query anything that is not A/C/G/T compares as 'A' (the device store has two bits per base; contigs hold none); on the
+ * reference an N equals an N only (ref_gap_max_shift). */
 static inline char acgt(char c) { return (c == 'C' || c == 'G' || c == 'T') ? c : 'A'; }
 int orc_gap_max_shift(const char *s, int off, int len, int cap)
 {
     int l = 0;
     while (l < cap && acgt(s[off - 1 - l]) == acgt(s[off + len - 1 - l])) l++;
+    return l;
+}
+static inline char ref_norm(char c) { return is_acgt(c) ? c : 'N'; }
+static int ref_gap_max_shift(const char *s, int off, int len, int cap)      /* the reference side: an N equals an N only */
+{
+    int l = 0;
+    while (l < cap && ref_norm(s[off - 1 - l]) == ref_norm(s[off + len - 1 - l])) l++;
     return l;
 }
 static void shift_gaps_left(uint32_t *cg, int *n_io, const char *Q, const char *ref, int tbeg)
@@ -292,7 +316,7 @@ static void shift_gaps_left(uint32_t *cg, int *n_io, const char *Q, const char *
         else {
             if (k > 0 && k < n - 1 && (cg[k - 1] & 0xf) == 0 && (cg[k + 1] & 0xf) == 0) {
                 int prev = (int)(cg[k - 1] >> 4);
-                int l = op == 1 ? orc_gap_max_shift(Q, qoff, (int)len, prev) : orc_gap_max_shift(ref, toff, (int)len, prev);
+                int l = op == 1 ? orc_gap_max_shift(Q, qoff, (int)len, prev) : ref_gap_max_shift(ref, toff, (int)len, prev);
                 if (l > 0) { cg[k - 1] -= (uint32_t)l << 4; cg[k + 1] += (uint32_t)l << 4; toff -= l; qoff -= l; }
             }
             if (op == 2) toff += (int)len; else qoff += (int)len;
@@ -321,13 +345,13 @@ static void corner_event(const char *Qb, int ql, const char *Tb, int tl, const o
 {
     int lim = ql < tl ? ql : tl, i, x = 0, best = 0, l = 0, r = 0;
     for (i = 0; i < lim; i++) {
-        x += Qb[i] == Tb[i] ? P->a : -P->b;
+        x += pair_score(Qb[i], Tb[i], P);
         if (x > best) { best = x; l = i + 1; }
         if (best - x > P->xdrop) break;
     }
     x = 0; best = 0;
     for (i = 0; i < lim - l; i++) {
-        x += Qb[ql - 1 - i] == Tb[tl - 1 - i] ? P->a : -P->b;
+        x += pair_score(Qb[ql - 1 - i], Tb[tl - 1 - i], P);
         if (x > best) { best = x; r = i + 1; }
         if (best - x > P->xdrop) break;
     }
@@ -380,7 +404,8 @@ static void sub_align(const char *Qb, int ql, const char *Tb, int tl, const orc_
     orc_mz *mq = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)(ql + 8)), *mt = (orc_mz *)malloc(sizeof(orc_mz) * (size_t)(tl + 8));
     int thin, w = seed_window(P->w, ql > tl ? ql : tl, ORC_ALN_SUB_PER, &thin);
     int nq = ql >= P->k ? sketch_thinned(Qb, ql, w, P->k, thin, mq, ql + 8) : 0;
-    int nt = tl >= P->k ? sketch_thinned(Tb, tl, w, P->k, thin, mt, tl + 8) : 0;
+    const char *Ts = (g_ref_seed && Tb >= g_ref && Tb + tl <= g_ref + g_ref_len) ? g_ref_seed + (Tb - g_ref) : Tb;
+    int nt = tl >= P->k ? sketch_thinned(Ts, tl, w, P->k, thin, mt, tl + 8) : 0;
     int i = 0, j = 0, na = 0, nch = 0, c;
     anc_t *a; int32_t *f, *pre, *cq, *ct;
     nq = orc_occ_sorted(mq, nq, ORC_ALN_SUB_OCC);
@@ -493,14 +518,14 @@ static void align_chain(const char *Q, int lenq, const char *ref, int lent, cons
     /* gap-free X-drop extension to the left of the first anchor and to the right of the last one */
     x = 0; best = 0; bi = 0;
     for (i = 1; qs0 - i >= 0 && ts0 - i >= 0; i++) {
-        x += Q[qs0 - i] == ref[ts0 - i] ? P->a : -P->b;
+        x += pair_score(Q[qs0 - i], ref[ts0 - i], P);
         if (x > best) { best = x; bi = i; }
         if (best - x > P->xdrop) break;
     }
     qbeg = qs0 - bi; tbeg = ts0 - bi;
     x = 0; best = 0; bi = 0;
     for (i = 1; cq[nch - 1] + i < lenq && ct[nch - 1] + i < lent; i++) {
-        x += Q[cq[nch - 1] + i] == ref[ct[nch - 1] + i] ? P->a : -P->b;
+        x += pair_score(Q[cq[nch - 1] + i], ref[ct[nch - 1] + i], P);
         if (x > best) { best = x; bi = i; }
         if (best - x > P->xdrop) break;
     }
@@ -522,20 +547,28 @@ int orc_align_contig_multi(const char *contig, int lenq, const char *ref, int le
     int nq, nt, rev = 0, n_rec, i, r, off = 0, thin, w;
     int chain_n[ORC_ALN_MAX_REC]; uint8_t chain_rev[ORC_ALN_MAX_REC];
     int32_t *cq, *ct;
-    char *qrc = NULL;
+    char *qrc = NULL, *ref_seed = NULL;
     if (max_rec > ORC_ALN_MAX_REC) max_rec = ORC_ALN_MAX_REC;
     /* long windows: fewer seeds, as fsv_align_batch picks them -- the minimizer window grows with the longer of the two
      * sequences (one seed list of a 50 kb .. 760 kb window stays below the 8 192 the chaining tile holds), and beyond
      * w = 255 the minimizers are thinned by their hash instead (every m-th survives on both sequences alike) */
     w = seed_window(P->w, lenq > lent ? lenq : lent, 3000, &thin);
     nq = sketch_thinned(contig, lenq, w, P->k, thin, mq, lenq + 8);
-    nt = sketch_thinned(ref, lent, w, P->k, thin, mt, lent + 8);
+    {
+        char *seed = NULL;
+        for (i = 0; i < lent; i++) if (!is_acgt(ref[i])) {
+            if (!seed) { seed = (char *)malloc((size_t)lent + 1); memcpy(seed, ref, (size_t)lent); }
+            seed[i] = "ACGT"[n_substitute((uint32_t)i)];
+        }
+        g_ref = ref; g_ref_len = lent; g_ref_seed = seed; ref_seed = seed;
+        nt = sketch_thinned(seed ? seed : ref, lent, w, P->k, thin, mt, lent + 8);
+    }
     nq = orc_unique_sorted(mq, nq);
     nt = orc_unique_sorted(mt, nt);
     cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nq + 1) * 2); ct = cq + nq + 1;
     n_rec = orc_aln_chains(mq, nq, lenq, mt, nt, P, &rev, cq, ct, nq, chain_n, chain_rev, max_rec);
     free(mq); free(mt);
-    if (n_rec == 0) { free(cq); return 0; }
+    if (n_rec == 0) { free(cq); free(ref_seed); g_ref_seed = NULL; return 0; }
     for (r = 0; r < n_rec; r++) {
         const char *Q = contig;
         if (chain_rev[r]) {
@@ -545,7 +578,7 @@ int orc_align_contig_multi(const char *contig, int lenq, const char *ref, int le
         align_chain(Q, lenq, ref, lent, cq + off, ct + off, chain_n[r], chain_rev[r], P, &out[r], cigar + (size_t)r * cigar_cap, cigar_cap);
         off += chain_n[r];
     }
-    free(cq); free(qrc);
+    free(cq); free(qrc); free(ref_seed); g_ref_seed = NULL;
     return n_rec;
 }
 

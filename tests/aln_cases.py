@@ -124,6 +124,42 @@ def inversion_cases(sizes=(2000, 5000)):
     return out
 
 
+def n_window_cases():
+    """reference windows that hold runs of N (they used to be stored -- and to seed and match -- as poly-A).
+    The contig carries real sequence where the reference has N; minimap2 scores an N against anything as -1 and skips k-mers with
+    an N: the alignment runs through a short run as 'M', nothing is called there, and the contig's real SVs still are."""
+    out = []
+    rng = np.random.default_rng(4242)
+    L, M, R = rnd(rng, 12000), rnd(rng, 9000), rnd(rng, 12000)
+    small = ("DEL", left_del(L, 5000, 120), 120)
+    hap = _with_small_del(L) + M + R
+    for name, runs in (("N-run-3", [(3000, 3)]), ("N-run-200", [(3000, 200)]), ("N-run-1500", [(3000, 1500)]),
+                       ("N-runs-many", [(500, 1), (1200, 40), (4000, 300), (7000, 17)])):
+        m = bytearray(M)
+        for at, n in runs:
+            m[at:at + n] = b"N" * n
+        out.append(Case(name, L + bytes(m) + R, hap, [small]))
+    # an N run of 60 next to a real 400 bp deletion (30 bases apart) and one inside a 500 bp insertion's flank
+    m = bytearray(M)
+    m[2970:3030 - 30] = b"N" * 30
+    ref = L + bytes(m) + R
+    hap2 = _with_small_del(L) + M[:3100] + M[3500:] + R
+    out.append(Case("N-run-beside-DEL", ref, hap2, [small, ("DEL", left_del(L + M + R, len(L) + 3100, 400), 400)]))
+    ins = rnd(rng, 500)
+    m = bytearray(M)
+    m[5050:5090] = b"N" * 40
+    ref = L + bytes(m) + R
+    hap3 = _with_small_del(L) + M[:5000] + ins + M[5000:] + R
+    out.append(Case("N-run-beside-INS", ref, hap3, [small, ("INS", left_ins(hap3, len(L) - 120 + 5000, 500, len(L) + 5000), 500)]))
+    # a window that starts and ends in N, and poly-A in the contig opposite an N run (what "N stored as A" made an exact match)
+    m = bytearray(M)
+    m[3000:3300] = b"N" * 300
+    hm = bytearray(M)
+    hm[3000:3300] = b"A" * 300
+    out.append(Case("N-run-vs-polyA", b"N" * 700 + L[700:] + bytes(m) + R[:-900] + b"N" * 900, _with_small_del(L) + bytes(hm) + R, [small]))
+    return out
+
+
 def check_case(case, recs):
     """recs: the records of the contig (dicts with ref_start, rev, cigar): every planted SV within 1 bp with its exact length,
     nothing else; the expected number of records and their strands"""

@@ -185,3 +185,18 @@ def test_left_shift_regressions_and_tandem_regions(ctx):
         assert not misses and extra == 0, (idx[cref[i]], i & 1, misses, extra)
         n_sv += len(a["cigar"]) // 2
     assert n_sv > 100
+
+
+@pytest.mark.gpu
+def test_reference_windows_with_n_runs(ctx):
+    """reference windows with N (k_pack_ascii keeps a mask; an N pairs with nothing, costs 1 in a score and
+    seeds as hashed sequence): records bit-identical to the oracle's, no call at the N runs, the planted SVs called -- in one batch with
+    windows that have no N at all"""
+    from tests import aln_cases as A
+    cases = A.n_window_cases() + A.inversion_cases(sizes=(2000,))[:1] + A.duplication_cases(sizes=(6000,), divs=(0.0,))
+    rec, cigar, status = ctx.align_batch([c.hap for c in cases], list(range(len(cases))), [c.ref for c in cases])
+    assert (status == 0).all(), list(status)
+    by = _records_by_contig(rec, cigar, len(cases))
+    for c, got in zip(cases, by):
+        A.check_case(c, got)
+        _same_records(got, O.align_contig_multi(c.hap, c.ref), c.name)

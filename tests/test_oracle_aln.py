@@ -152,3 +152,13 @@ def test_split_records_beyond_max_gap():
         assert len(recs) == 2
         calls = A.split_calls(recs)
         assert len(calls) == 1 and calls[0][1] == want[0] and abs(calls[0][2] - want[1]) <= 2 and abs(calls[0][3] - want[2]) <= 2
+
+
+def test_reference_windows_with_n_runs():
+    """an N of the reference window pairs with nothing and costs 1 (minimap2's sc_ambi), N runs do not
+    seed -- the alignment runs through runs of 1 .. 1 500 N as 'M', no SV is called there (nor where the contig has poly-A against
+    the N), and the contig's real SVs come out at their left-aligned positions"""
+    from tests import aln_cases as A
+    for case in A.n_window_cases():
+        recs = O.align_contig_multi(case.hap, case.ref)
+        A.check_case(case, recs)
