@@ -58,7 +58,7 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
 
 struct AsmWs {
     DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, bc_idx, bc_rec, bc_win, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
-        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+        cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, upair_tab_sw, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> sk_rec, uq_rec, chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec, bc_bpm_rec, bc_fast_rec, bc_dp_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
     // state of the last run (for fsv_asm_fetch_reads / stats)
@@ -72,7 +72,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &bc_idx, &bc_rec, &bc_win, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &bc_idx, &bc_rec, &bc_win, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &upair_tab_sw, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -231,7 +231,7 @@ int overlap_stage(fsv_ctx *ctx, AsmWs &W, const Batch &B, const Geometry &G, con
     A.mz = (const fsv_mz *)W.mz.p; A.mz_off = (const uint32_t *)W.mz_off.p; A.mz_cnt = (const uint32_t *)W.mz_cnt.p;
     A.ovl = (fsv_ovl *)W.ovl.p; A.tasks = (fsv_wtask *)W.tasks.p; A.task_counter = ct + CT_TASKS; A.task_cap = task_cap;
     A.overflow = ct + CT_OVERFLOW; A.warn = (uint32_t *)W.warn.p; A.set_cols = (uint32_t *)W.set_cols.p; A.thr_tab = (const uint8_t *)W.thr_tab.p;
-    A.n_sets = B.n_sets; A.k_score = P.k; A.min_anchors = P.min_anchors; A.min_ovlp = P.min_ovlp; A.bw = bw; A.emit_tasks = emit_tasks ? 1 : 0;
+    A.n_sets = B.n_sets; A.k_score = P.k; A.min_anchors = P.min_anchors; A.min_ovlp = P.min_ovlp; A.bw = bw; A.emit_tasks = emit_tasks ? 1 : 0; A.primary_only = 0;
     // LDS per pair: the anchor arrays for FSV_AMAX entries -- 12 B each in the compact layout (every read of the batch below
     // 65 536 bases), so the tile no longer has to be cut to the batch's longest list to keep several pairs per CU
     A.upair_tab = (const uint4 *)W.upair_tab.p; A.pair_list = nullptr; A.n_list_dev = nullptr;
@@ -352,7 +352,7 @@ void layout_set(const int32_t *len, uint32_t n, const fsv_hit *hits, uint32_t n_
 extern "C" void fsv_asm_default_params(fsv_asm_params *p)
 {
     if (!p) return;
-    p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 500; p->min_anchors = 3; p->lookback = 64;
+    p->k = 51; p->w = 51; p->hpc = 1; p->n_rounds = 3; p->min_ovlp = 1; p->min_anchors = 1; p->lookback = 64;   // hifiasm keeps every (target, strand) group that shares a minimizer, whatever its length
     p->bw_ec = 20; p->bw_final = 0; p->min_contig_reads = 4;
     p->win_rate_pm = 40; p->k_cap = FSV_K_MAX; p->accept_err_pm = 30; p->bw_rechain = 1; p->w_later = 0; p->partition = 1; p->second_round = 1; p->ins_dag = 1;
     p->min_anchors_final = 1; p->min_ovlp_final = 1; p->graph_layout = 1; p->junction_cigars = 1;
@@ -362,6 +362,7 @@ extern "C" void fsv_asm_ont_params(fsv_asm_params *p)
 {
     if (!p) return;
     fsv_asm_default_params(p);
+    p->min_ovlp = 500; p->min_anchors = 3;      // chains of noisy reads: three seeds and 500 bases make an overlap (hifiasm's HiFi rule -- one shared seed -- would chain noise)
     p->k = 15; p->w = 15; p->hpc = 0;           // 15-mers survive 10 % error often enough to seed (20 % of them per read); no HPC: indel errors dominate
     p->bw_ec = 150; p->bw_final = 50;           // chains of noisy reads drift by several per cent between anchors
     p->win_rate_pm = 250; p->k_cap = FSV_K_WIDE; p->accept_err_pm = 300;   // two 10 % reads differ by ~20 %: k = 93 for a full window
@@ -985,19 +986,29 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             FSV_HIP(ctx, hipGetLastError());
             ChainArgs A2 = W.last_chain;
             A2.bw = P.bw_rechain; A2.emit_tasks = 0; A2.pair_list = (const uint32_t *)W.inexact_list.p; A2.n_list_dev = n_list_dev;
-            if (A2.wide_list) FSV_HIP(ctx, hipMemsetAsync(A2.n_wide, 0, 4, ctx->stream));   // (the final pass's own wide pairs are done)
+            // Either direction of a listed pair is chained from its own side, as hifiasm does: with an indel budget the chain DP depends
+            // on the end it starts from (the budget is a rate over the span chained so far; on the reverse strand the two sides start
+            // from opposite ends), and the mirror image of one side's chain can be off by the bases of an indel near a read end.
+            A2.primary_only = 1;
+            TRY(ensure(ctx, W.upair_tab_sw, (size_t)std::max(1u, B.n_upairs) * sizeof(uint4)));
+            hipLaunchKernelGGL(k_pair_tab_swap, dim3(fsv_grid_for(B.n_upairs, 256)), dim3(256), 0, ctx->stream, (const uint4 *)W.upair_tab.p, B.n_upairs, (uint4 *)W.upair_tab_sw.p);
+            FSV_HIP(ctx, hipGetLastError());
             // timed like the other k_chain launches (a profiler counts it too)
             W.kt.begin(ctx, KN_CHAIN, 0);
-            if (short_reads) { TRY(lds_opt_in(ctx, k_chain<true>, chain_lds_bytes(true, A2.amax))); hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A2.amax), ctx->stream, A2); }
-            else { TRY(lds_opt_in(ctx, k_chain<false>, chain_lds_bytes(false, A2.amax))); hipLaunchKernelGGL(k_chain<false>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(false, A2.amax), ctx->stream, A2); }
-            FSV_HIP(ctx, hipGetLastError());
-            if (A2.wide_list) {
-                ChainArgs AW = A2;
-                AW.amax = short_reads ? FSV_AMAX_WIDE : FSV_AMAX_WIDE_LONG; AW.pair_list = nullptr; AW.n_list_dev = nullptr;
-                const uint32_t gridw = std::min<uint32_t>(B.n_upairs, 2u * (uint32_t)ctx->n_cu);
-                if (short_reads) { TRY(lds_opt_in(ctx, k_chain_wide_list<true>, chain_lds_bytes(true, AW.amax))); hipLaunchKernelGGL(k_chain_wide_list<true>, dim3(gridw), dim3(64), chain_lds_bytes(true, AW.amax), ctx->stream, AW); }
-                else { TRY(lds_opt_in(ctx, k_chain_wide_list<false>, chain_lds_bytes(false, AW.amax))); hipLaunchKernelGGL(k_chain_wide_list<false>, dim3(gridw), dim3(64), chain_lds_bytes(false, AW.amax), ctx->stream, AW); }
+            for (int side = 0; side < 2; side++) {
+                if (side == 1) A2.upair_tab = (const uint4 *)W.upair_tab_sw.p;
+                if (A2.wide_list) FSV_HIP(ctx, hipMemsetAsync(A2.n_wide, 0, 4, ctx->stream));   // (the final pass's own wide pairs are done)
+                if (short_reads) { TRY(lds_opt_in(ctx, k_chain<true>, chain_lds_bytes(true, A2.amax))); hipLaunchKernelGGL(k_chain<true>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(true, A2.amax), ctx->stream, A2); }
+                else { TRY(lds_opt_in(ctx, k_chain<false>, chain_lds_bytes(false, A2.amax))); hipLaunchKernelGGL(k_chain<false>, dim3(B.n_upairs), dim3(64), chain_lds_bytes(false, A2.amax), ctx->stream, A2); }
                 FSV_HIP(ctx, hipGetLastError());
+                if (A2.wide_list) {
+                    ChainArgs AW = A2;
+                    AW.amax = short_reads ? FSV_AMAX_WIDE : FSV_AMAX_WIDE_LONG; AW.pair_list = nullptr; AW.n_list_dev = nullptr;
+                    const uint32_t gridw = std::min<uint32_t>(B.n_upairs, 2u * (uint32_t)ctx->n_cu);
+                    if (short_reads) { TRY(lds_opt_in(ctx, k_chain_wide_list<true>, chain_lds_bytes(true, AW.amax))); hipLaunchKernelGGL(k_chain_wide_list<true>, dim3(gridw), dim3(64), chain_lds_bytes(true, AW.amax), ctx->stream, AW); }
+                    else { TRY(lds_opt_in(ctx, k_chain_wide_list<false>, chain_lds_bytes(false, AW.amax))); hipLaunchKernelGGL(k_chain_wide_list<false>, dim3(gridw), dim3(64), chain_lds_bytes(false, AW.amax), ctx->stream, AW); }
+                    FSV_HIP(ctx, hipGetLastError());
+                }
             }
             W.kt.end(ctx);
             hipLaunchKernelGGL(k_accept_inexact, dim3(fsv_grid_for(2ull * B.n_upairs, 256)), dim3(256), 0, ctx->stream, (const uint4 *)W.upair_tab.p,

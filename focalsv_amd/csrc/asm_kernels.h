@@ -381,6 +381,7 @@ struct ChainArgs {
     const uint8_t *thr_tab;      // 376 entries: threshold for a window of that length
     uint32_t n_sets;
     int32_t k_score, min_anchors, min_ovlp, bw, emit_tasks;
+    int32_t primary_only;        // 1 (without tasks only): the slot of (q, t) alone is written -- the overlap of t on q is chained from t's side by a second launch
     unsigned long long *stamps;  // diagnostic (FSV_CHAIN_STAMPS=1): shader cycles per phase summed over the waves, else nullptr
     uint32_t *wide_list, *n_wide; // pairs whose two lists both have more than amax entries (only they can have more than amax anchors) are
                                   // set aside here and chained by k_chain_wide_list with the large tile; nullptr: chain every pair here
@@ -388,6 +389,15 @@ struct ChainArgs {
 
 // The unordered pairs of every set, enumerated once per batch: block b of k_chain reads one 16-byte record instead of
 // searching the set table and inverting the triangular index (a dozen dependent global loads per block).
+// the pair table with the roles of the two reads swapped (the final pass's gapped re-chain chains a pair from either side)
+__global__ void k_pair_tab_swap(const uint4 *__restrict__ tab, uint32_t n_upairs, uint4 *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_upairs) return;
+    const uint4 v = tab[i];
+    out[i] = make_uint4(v.x, (v.y >> 16) | (v.y << 16), v.w, v.z);
+}
+
 __global__ void k_pair_tab(const uint32_t *__restrict__ set_start, const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ upair_base,
                            uint32_t n_sets, uint32_t n_upairs, uint4 *__restrict__ tab, uint32_t *__restrict__ pair_read)
 {
@@ -451,7 +461,7 @@ __device__ __forceinline__ void chain_pair(const ChainArgs &A, unsigned char *s_
     o.align_len = 0; o.err_sum = 0; o.rev = 0; o.is_match = 0; o.exact = 0; o.valid = 0;
     fsv_ovl om = o; // the mirrored overlap (t on q)
     om.q = t; om.t = q;
-#define PUT_BOTH() do { if (lane == 0) { A.ovl[p] = o; A.ovl[pm] = om; } } while (0)
+#define PUT_BOTH() do { if (lane == 0) { A.ovl[p] = o; if (!A.primary_only) A.ovl[pm] = om; } } while (0)
     const bool stamped = A.stamps && (blockIdx.x & 63u) == 0u;   // one block in 64: the atomics must not become the load
     unsigned long long tm = stamped ? __builtin_amdgcn_s_memtime() : 0ull;
 #define CH_MARK(i_) do { if (stamped) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) { atomicAdd(&A.stamps[i_], t_ - tm); atomicAdd(&A.stamps[8 + (i_)], 1ull); } tm = t_; } } while (0)

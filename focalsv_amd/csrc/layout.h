@@ -81,7 +81,7 @@ public:
 
     void build()
     {
-        chimeric(); hit_cut(); hit_flt(); hit_contained();
+        normalize(); chimeric(); hit_cut(); hit_flt(); hit_contained();
         sdel_ = rdel_;
         for (const Hit &h : h_) { Arc t; if (!h.del && hit2arc(h, t) >= 0) arc_.push_back(t); }
         cleanup();
@@ -162,6 +162,22 @@ private:
         rdel_[qn] = 1;
     }
 
+    // normalize_ma_hit_t_single_side_advance (Overlaps.cpp:450-515): the two directions of a pair are made one overlap -- the direction
+    // with the longer query interval stands and the other becomes its mirror image (equal lengths: the lower read's stands); a hit
+    // without a partner is deleted.  (The final pass's gapped re-chain chains either direction from its own side.)
+    void normalize()
+    {
+        for (int i = 0; i < n_; i++)
+            for (int j = src_first_[i]; j < src_first_[i + 1]; j++) {
+                Hit &h = h_[j];
+                if (Hit *r = find_hit(h.tn, h.qn)) {
+                    const bool is_del = h.del || r->del;
+                    const int q0 = h.qe - h.qs, q1 = r->qe - r->qs;
+                    if ((q0 == q1 && h.qn < h.tn) || q0 > q1) { r->qs = h.ts; r->qe = h.te; r->ts = h.qs; r->te = h.qe; r->rev = h.rev; r->el = h.el; }
+                    h.del = r->del = is_del ? 1 : 0;
+                } else h.del = 1;
+            }
+    }
     void chimeric()
     {
         const float shift_rate = (float)(0.001f * 2.0);

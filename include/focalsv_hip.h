@@ -148,8 +148,9 @@ int fsv_bpm_windows(fsv_ctx *ctx, const uint32_t *store, size_t store_words, con
 typedef struct fsv_asm_params {
     int32_t k, w, hpc;        /* minimizer scheme; hifiasm defaults 51, 51, 1 (CommandLines.cpp:109-166) */
     int32_t n_rounds;         /* correction rounds, 3 */
-    int32_t min_ovlp;         /* shortest overlap kept, 500 */
-    int32_t min_anchors;      /* shortest chain kept, 3 */
+    int32_t min_ovlp;         /* shortest overlap kept in a correction round: 1 -- hifiasm keeps every (target, strand) group that shares a minimizer,
+                               * however short (calculate_overlap_region_by_chaining, Hash_Table.cpp:684-745); the ONT / CLR profiles: 500 */
+    int32_t min_anchors;      /* shortest chain kept: 1 (the same); the ONT / CLR profiles: 3 */
     int32_t lookback;         /* chain DP predecessors examined, 64 (= one wavefront) */
     int32_t bw_ec;            /* chain indel budget per mille in correction rounds, 20 (hifiasm 0.02) */
     int32_t bw_final;         /* ... in the final overlap pass, 0 = co-linear anchors only */

@@ -360,6 +360,10 @@ static int ovl_cmp(const void *a, const void *b)
  * b on a is the mirror image of the same chain (hifiasm recomputes it from b's side, anchor.cpp:207-300; mirroring halves the
  * chaining work and both directions agree on the anchors).  On the reverse strand the mirrored coordinates are measured from
  * the other end of both reads and the anchor order flips. */
+/* both_ways (the final pass's gapped re-chain): the overlap of b on a is chained from b's side as hifiasm does -- with an indel
+ * budget the chain DP depends on the end it starts from (the budget is a rate over the span chained so far, and on the reverse
+ * strand the two sides start from opposite ends), so the mirror image can differ by the bases of an indel near a read end */
+static __thread int g_both_ways = 0;
 static void collect_overlaps(const readset *R, const orc_asm_params *P, int bw, orc_mz **uq, int *nuq, orc_ovl **ovl_out,
                              int32_t **cq_out, int32_t **ct_out, int *n_out)
 {
@@ -389,6 +393,18 @@ static void collect_overlaps(const readset *R, const orc_asm_params *P, int bw, 
                     const int src = o.chain_off + o.n_chain - 1 - i;
                     cq[m.chain_off + i] = lent - 1 - ct[src]; ct[m.chain_off + i] = lenq - 1 - cq[src];
                 }
+            }
+            if (g_both_ways) {
+                orc_ovl m2;
+                if (n + 2 > cap) { cap *= 2; ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)cap); }
+                ov[n++] = o;
+                cused += o.n_chain;
+                if (orc_chain_pair(uq[t], nuq[t], lent, uq[q], nuq[q], lenq, P, bw, &m2, cq + cused, ct + cused, chain_cap)) {
+                    m2.q = (uint32_t)t; m2.t = (uint32_t)q; m2.chain_off = cused;
+                    cused += m2.n_chain;
+                    ov[n++] = m2;
+                }
+                continue;
             }
             cused += 2 * o.n_chain;
             if (n + 2 > cap) { cap *= 2; ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)cap); }
@@ -1330,7 +1346,7 @@ typedef struct { int to, to_rev, ovl; } arc_t; /* best successor of an oriented 
 
 void orc_asm_default_params(orc_asm_params *P)
 {
-    P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 500; P->min_anchors = 3; P->lookback = 64;
+    P->k = 51; P->w = 51; P->hpc = 1; P->n_rounds = 3; P->min_ovlp = 1; P->min_anchors = 1; P->lookback = 64;
     P->bw_ec = 20; P->bw_final = 0; P->min_contig_reads = 4; P->partition = 1;
     P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1; P->ins_dag = 1;
     P->min_anchors_final = 1; P->min_ovlp_final = 1; P->graph_layout = 1;
@@ -1368,7 +1384,9 @@ static int final_overlaps(const readset *R, const orc_asm_params *P0, const orc_
         for (i = 0; i < R->n * R->n; i++) slot[i] = -1;
         for (i = 0; i < n_prev; i++) slot[(size_t)prev[i].q * R->n + prev[i].t] = i;
         for (i = 0; i < m; i++) has[(size_t)ov[i].q * R->n + ov[i].t] = 1;
+        g_both_ways = getenv("ORC_ONE_WAY") ? 0 : 1;
         collect_overlaps(R, P, P->bw_rechain, uq, nuq, &ov2, &cq2, &ct2, &n2);
+        g_both_ways = 0;
         ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)(m + n2 + 1));
         for (j = 0; j < n2; j++) {
             const orc_ovl *o = &ov2[j];

@@ -16,8 +16,7 @@
  * (Overlaps.cpp:27087-27350: the four cleaning rounds, bubble popping, the rescue passes) changes the graph, so they are not
  * restated; the complex branch of detect_chimeric_reads (a read whose left and right overlaps meet in fewer than 0.2 % of its
  * length AND some spanning overlap fails a window check there) is taken as "not chimeric": final overlaps are exact or were
- * verified window by window in the last correction round.  normalize_ma_hit_t_single_side_advance and clean_weak_ma_hit_t are
- * no-ops on the symmetric hit lists built here.
+ * verified window by window in the last correction round.  clean_weak_ma_hit_t is a no-op on the hit lists built here.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -77,6 +76,24 @@ static void delete_all_edges(lay_t *L, int qn)
     int i;
     for (i = L->src_first[qn]; i < L->src_first[qn + 1]; i++) { L->h[i].del = 1; delete_single_edge(L, L->h[i].tn, qn); }
     L->rdel[qn] = 1;
+}
+
+/* normalize_ma_hit_t_single_side_advance (Overlaps.cpp:450-515): the two directions of a pair are made one overlap -- the direction
+ * with the longer query interval stands and the other becomes its mirror image (equal lengths: the lower read's stands); a hit
+ * without a partner is deleted.  The final pass's gapped re-chain (oracle/asm.c: collect_overlaps, both ways) chains either direction
+ * from its own side, and with an indel budget the two can differ by the bases of an indel near a read end. */
+static void normalize(lay_t *L)
+{
+    int i, j;
+    for (i = 0; i < L->n; i++)
+        for (j = L->src_first[i]; j < L->src_first[i + 1]; j++) {
+            lhit *h = &L->h[j], *r = find_hit(L, h->tn, h->qn);
+            if (r) {
+                const int is_del = h->del || r->del, q0 = h->qe - h->qs, q1 = r->qe - r->qs;
+                if ((q0 == q1 && h->qn < h->tn) || q0 > q1) { r->qs = h->ts; r->qe = h->te; r->ts = h->qs; r->te = h->qe; r->rev = h->rev; r->el = h->el; }
+                h->del = r->del = (uint8_t)is_del;
+            } else h->del = 1;       /* (hifiasm adds the mirror image and deletes both) */
+        }
 }
 
 /* detect_chimeric_reads: a read whose overlaps from the left end and from the right end do not reach each other */
@@ -460,6 +477,7 @@ int orc_layout_graph(const char *const *seq, const int *len, int n, const orc_ov
         int a = L.src_first[i], b = L.src_first[i + 1], x, y;
         for (x = a + 1; x < b; x++) { lhit t = L.h[x]; for (y = x; y > a && L.h[y - 1].tn > t.tn; y--) L.h[y] = L.h[y - 1]; L.h[y] = t; }
     }
+    normalize(&L);
     chimeric(&L);
     hit_cut(&L);
     hit_flt(&L);
