@@ -375,6 +375,10 @@ __device__ __forceinline__ uint32_t qbase(const uint32_t *__restrict__ store, ui
 // N holds a base hashed from its position (k_pack_ascii): the seeds of an N run then look like random sequence, unique and
 // matching nothing, where minimap2 skips k-mers with an N.
 #define FSV_SC_AMBI 1
+// the mask array starts four words into its buffer; the word in front of it says whether any window of the batch has an N at all
+// (k_pack_ascii sets it): a kernel drops the mask at its start when there is none, and then pays nothing for it
+#define FSV_NM_LEAD 4
+__device__ __forceinline__ const uint32_t *nm_active(const uint32_t *__restrict__ nm) { return (nm && nm[-FSV_NM_LEAD]) ? nm : nullptr; }
 __device__ __forceinline__ uint32_t tbase(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, uint32_t tw, int p)
 {
     if (nm && ((nm[tw + ((uint32_t)p >> 4)] >> ((uint32_t)p & 15u)) & 1u)) return 4u;
@@ -392,12 +396,13 @@ __host__ __device__ __forceinline__ uint32_t n_substitute(uint32_t pos)
 // An event of more than max_cells cells is not handed to the DP: it is listed with qs = -1 - qs, WITHOUT its padding (the box
 // between the two anchors) -- the host has it seeded again (first level) or closed from its corners (k_corner, inside a box).
 template <bool GLOBAL>
-__global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(256) void k_aln_events(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm_all, const uint32_t *__restrict__ word_off,
                                                     const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                     const uint32_t *__restrict__ pair_t, const uint64_t *__restrict__ chain,
                                                     AlnHeader *__restrict__ hdr, AlnEvent *__restrict__ events, AlnEvent *__restrict__ packed,
                                                     uint32_t *__restrict__ n_packed, fsv_aln_params P)
 {
+    const uint32_t *nm = nm_active(nm_all);
     __shared__ uint8_t s_cls[ALN_CHAIN_STRIDE];
     const uint32_t p = blockIdx.x;
     AlnHeader h = hdr[p];
@@ -491,7 +496,8 @@ __global__ __launch_bounds__(256) void k_extract_boxes(const uint32_t *__restric
     uint32_t v = 0;
     for (int j = 0; j < 16 && b0 + j < len; j++) v |= fsv_base_at(src_store, b.src_word, b.src_len, b.rev, b.start + b0 + j) << (2 * j);
     words[w] = v;
-    if (nm_out) {      // the N positions of the side (only a reference window has any; it is never read on the other strand)
+    if (w == 0) nm_out[-FSV_NM_LEAD] = src_nm[-FSV_NM_LEAD];
+    if (src_nm[-FSV_NM_LEAD]) {      // the N positions of the side (only a reference window has any; it is never read on the other strand)
         uint32_t m = 0;
         if (!b.rev) for (int j = 0; j < 16 && b0 + j < len; j++) { const int sp = b.start + b0 + j; m |= ((src_nm[b.src_word + ((uint32_t)sp >> 4)] >> ((uint32_t)sp & 15u)) & 1u) << j; }
         nm_out[w] = m;
@@ -503,11 +509,12 @@ __global__ __launch_bounds__(256) void k_extract_boxes(const uint32_t *__restric
 // deletion (oracle/aln.c:corner_event).  One wavefront per event, 64 positions per step: the running score is a prefix sum,
 // the running best a prefix maximum, the first position where best - score > xdrop ends the run.
 struct CornerTask { uint32_t pair; int32_t qs, ql, ts, tl; };
-__global__ __launch_bounds__(64) void k_corner(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(64) void k_corner(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm_all, const uint32_t *__restrict__ word_off,
                                                const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                                const CornerTask *__restrict__ tasks, int2 *__restrict__ out, fsv_aln_params P)
 {
+    const uint32_t *nm = nm_active(nm_all);
     const CornerTask T = tasks[blockIdx.x];
     const int lane = threadIdx.x;
     const uint32_t qw = word_off[pair_q[T.pair]], tw = word_off[pair_t[T.pair]];
@@ -553,11 +560,12 @@ __global__ __launch_bounds__(64) void k_corner(const uint32_t *__restrict__ stor
 // all gaps of the batch at once (one wavefront per gap, 64 positions per step); the host then applies the shifts in CIGAR
 // order, each bounded by the M run in front of it.
 struct GapQuery { uint32_t slot; int32_t is_ins, off, len, cap; };
-__global__ __launch_bounds__(64) void k_gap_shift(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(64) void k_gap_shift(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm_all, const uint32_t *__restrict__ word_off,
                                                   const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                   const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                                   const GapQuery *__restrict__ gaps, int32_t *__restrict__ max_shift)
 {
+    const uint32_t *nm = nm_active(nm_all);
     const GapQuery g = gaps[blockIdx.x];
     const int lane = threadIdx.x;
     const uint32_t qw = word_off[pair_q[g.slot]], tw = word_off[pair_t[g.slot]];
@@ -699,12 +707,13 @@ __device__ __forceinline__ void nw_backtrack(const uint8_t *__restrict__ bt, int
 // sweep, so its query bases sit in registers; the target bases of the rows the sweep is crossing sit in an LDS ring that the
 // workgroup refills every CH diagonals.  No global load on the per-diagonal critical path.
 template <int QCAP, int NT>
-__global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm_all, const uint32_t *__restrict__ word_off,
                                            const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                            const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                            const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all,
                                            uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
 {
+    const uint32_t *nm = nm_active(nm_all);
     constexpr int C = QCAP / NT;
     constexpr int CH = QCAP >= 1024 ? 256 : 64;
     constexpr int TB = QCAP >= 2048 ? 4096 : 2 * QCAP;   // ring of target bases (power of two >= QCAP + CH)
@@ -747,12 +756,13 @@ __global__ __launch_bounds__(NT) void k_nw(const uint32_t *__restrict__ store, c
 // ring.  With the rows of such an event in ONE wavefront a diagonal costs a single-wave barrier; round 1 sent these events to
 // k_nw<3072, 1024>, where each of their ~2 000 diagonals paid a 16-wave barrier for a few dozen cells (7.3 ms per bench step).
 template <int RCAP, int NT>
-__global__ __launch_bounds__(NT) void k_nw_rows(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(NT) void k_nw_rows(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm_all, const uint32_t *__restrict__ word_off,
                                                 const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                 const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                                 const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all,
                                                 uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
 {
+    const uint32_t *nm = nm_active(nm_all);
     constexpr int C = RCAP / NT;
     constexpr int CH = 64;
     constexpr int QB = 2 * RCAP;        // ring of query bases (power of two >= RCAP + CH)
@@ -789,12 +799,13 @@ __global__ __launch_bounds__(NT) void k_nw_rows(const uint32_t *__restrict__ sto
 }
 
 // Any query length: rolling rows in HBM, bases fetched per cell (events with queries above NW_LDS_Q bases: rare, slow path)
-__global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm, const uint32_t *__restrict__ word_off,
+__global__ __launch_bounds__(256) void k_nw_any(const uint32_t *__restrict__ store, const uint32_t *__restrict__ nm_all, const uint32_t *__restrict__ word_off,
                                                 const int32_t *__restrict__ read_len, const uint32_t *__restrict__ pair_q,
                                                 const uint32_t *__restrict__ pair_t, const AlnHeader *__restrict__ hdr,
                                                 const NwTask *__restrict__ tasks, uint8_t *__restrict__ bt_all, int32_t *__restrict__ rows_all,
                                                 uint32_t *__restrict__ cg_all, uint32_t *__restrict__ cg_n, int32_t *__restrict__ scores, fsv_aln_params P)
 {
+    const uint32_t *nm = nm_active(nm_all);
     __shared__ uint8_t s_bt[NW_TD][NW_TC];
     __shared__ int s_walk[8];
     const NwTask T = tasks[blockIdx.x];
@@ -827,8 +838,7 @@ struct AlnWs {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     AlnWs *sub = nullptr;       // the workspace of the boxes of oversize events (a second, smaller alignment pass)
-    bool has_n = false;         // some reference window of the batch has an N: the kernels get the mask (nullptr otherwise)
-    const uint32_t *nm() const { return has_n ? (const uint32_t *)nmask.p : nullptr; }
+    const uint32_t *nm() const { return (const uint32_t *)nmask.p + FSV_NM_LEAD; }     // the N mask of the store (the kernels drop it when the batch has no N: nm_active)
     std::vector<DevBuf *> all() { return {&store, &nmask, &ascii, &asc_off, &word_off, &len, &wper, &pair_q, &pair_t, &sk_ends, &sk_low, &sk_high, &mz, &mz_off, &mz_cnt, &warn, &chain, &hdr, &events, &ev_packed, &ev_count, &tasks, &bt, &rows, &cg, &cg_n, &scores, &gaps, &gap_shift, &thin, &box_src, &corner, &corner_out}; }
 };
 
@@ -877,8 +887,8 @@ struct Timer {
 };
 
 // packs pairs (query, target) into a store; returns lens / offsets
-// ASCII -> 2-bit store on the device: one thread per output word, 16 source bytes each.  Without nm_out N and anything else -> A, as
-// fsv_pack_reads does on the host; with it (a batch that holds an N) an N gets a base hashed from its position and its mask bit
+// ASCII -> 2-bit store on the device: one thread per output word, 16 source bytes each.  An N (anything but ACGT) gets a base hashed
+// from its position and its bit in the mask word; the word in front of the mask array says whether the batch has any (nm_active)
 __global__ __launch_bounds__(256) void k_pack_ascii(const char *__restrict__ ascii, const uint64_t *__restrict__ asc_off,
                                                     const uint32_t *__restrict__ word_off, const int32_t *__restrict__ read_len,
                                                     uint32_t n_reads, uint32_t total_words, uint32_t *__restrict__ words, uint32_t *__restrict__ nm_out)
@@ -895,11 +905,12 @@ __global__ __launch_bounds__(256) void k_pack_ascii(const char *__restrict__ asc
     for (int j = 0; j < 16 && b0 + j < len; j++) {
         const char c = src[j];
         uint32_t code = (c == 'C' || c == 'c') ? 1u : (c == 'G' || c == 'g') ? 2u : (c == 'T' || c == 't') ? 3u : 0u;
-        if (nm_out && code == 0u && c != 'A' && c != 'a') { code = n_substitute((uint32_t)(b0 + j)); m |= 1u << j; }     // N (anything else): see tbase
+        if (code == 0u && c != 'A' && c != 'a') { code = n_substitute((uint32_t)(b0 + j)); m |= 1u << j; }     // N (anything else): see tbase
         v |= code << (2 * j);
     }
     words[w] = v;
-    if (nm_out) nm_out[w] = m;
+    nm_out[w] = m;
+    if (m) atomicOr(&nm_out[-FSV_NM_LEAD], 1u);      // (rare: a window with an N)
 }
 
 // sequences (already concatenated by the caller in two buffers: reference windows, contigs) -> device 2-bit store
@@ -934,16 +945,11 @@ int pack_pairs(fsv_ctx *ctx, AlnWs &W, const std::vector<const char *> &seq, con
     TRY(upload(ctx, W.len, len));
     TRY(ensure(ctx, W.store, (w + 8) * 4));
     FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.store.p + w, 0, 32, ctx->stream));
-    // does any sequence that comes from the host (the reference windows; contigs handed over as text) hold anything but ACGT?
-    // (13 MB of text per 256 regions: a millisecond of the host's time, off the GPU's path)
-    W.has_n = false;
-    for (uint32_t r = 0; r < n_host && !W.has_n; r++) {
-        const char *sq = seq[r];
-        for (uint64_t i = 0; i < slen[r]; i++) { const char c = (char)(sq[i] & ~0x20); if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { W.has_n = true; break; } }
-    }
-    if (W.has_n) { TRY(ensure(ctx, W.nmask, (w + 8) * 4)); FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.nmask.p + w, 0, 32, ctx->stream)); }
+    TRY(ensure(ctx, W.nmask, (w + 8 + FSV_NM_LEAD) * 4));
+    FSV_HIP(ctx, hipMemsetAsync(W.nmask.p, 0, FSV_NM_LEAD * 4, ctx->stream));      // the "some window has an N" word (set on the device: the host never looks at the text)
+    FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W.nmask.p + FSV_NM_LEAD + w, 0, 32, ctx->stream));
     hipLaunchKernelGGL(k_pack_ascii, dim3(fsv_grid_for(w, 256)), dim3(256), 0, ctx->stream, (const char *)W.ascii.p, (const uint64_t *)W.asc_off.p,
-                       (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, n, (uint32_t)w, (uint32_t *)W.store.p, W.has_n ? (uint32_t *)W.nmask.p : (uint32_t *)nullptr);
+                       (const uint32_t *)W.word_off.p, (const int32_t *)W.len.p, n, (uint32_t)w, (uint32_t *)W.store.p, (uint32_t *)W.nmask.p + FSV_NM_LEAD);
     FSV_HIP(ctx, hipGetLastError());
     return FSV_OK;
 }
@@ -1228,10 +1234,10 @@ int align_pass(fsv_ctx *ctx, AlnWs &W, const PassIn &S, const fsv_aln_params &P,
         TRY(upload(ctx, W2.box_src, src));
         TRY(ensure(ctx, W2.store, (w + 8) * 4));
         FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W2.store.p + w, 0, 32, ctx->stream));
-        W2.has_n = W.has_n;
-        if (W.has_n) { TRY(ensure(ctx, W2.nmask, (w + 8) * 4)); FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W2.nmask.p + w, 0, 32, ctx->stream)); }
+        TRY(ensure(ctx, W2.nmask, (w + 8 + FSV_NM_LEAD) * 4));
+        FSV_HIP(ctx, hipMemsetAsync((uint32_t *)W2.nmask.p + FSV_NM_LEAD + w, 0, 32, ctx->stream));
         hipLaunchKernelGGL(k_extract_boxes, dim3(fsv_grid_for(w, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)W.store.p, W.nm(), (const BoxSrc *)W2.box_src.p,
-                           (const uint32_t *)W2.word_off.p, (const int32_t *)W2.len.p, 2 * nb, (uint32_t)w, (uint32_t *)W2.store.p, W.has_n ? (uint32_t *)W2.nmask.p : (uint32_t *)nullptr);
+                           (const uint32_t *)W2.word_off.p, (const int32_t *)W2.len.p, 2 * nb, (uint32_t)w, (uint32_t *)W2.store.p, (uint32_t *)W2.nmask.p + FSV_NM_LEAD);
         FSV_HIP(ctx, hipGetLastError());
         PassOut O2;
         TRY(align_pass(ctx, W2, S2, P, 1, O2, nullptr));

@@ -54,10 +54,11 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
        CT_MZ_LO = 10, CT_MZ_HI = 11, CT_B_RETRY = 12, CT_B_LIST = 13, CT_DP_SB16 = 14, CT_WIDE = 15,
        CT_MZRAW_LO = 16, CT_MZRAW_HI = 17, CT_BASES_LO = 18, CT_BASES_HI = 19,   // k_uniq's other two sums: CT_MZ + 3 and + 4 as 64-bit words
        CT_DP_FR3 = 20,       // k_path_fr's lists by distance: CT_DP_SB16 (1), CT_DP (2), CT_DP_FR3 (3)
+       CT_LEFT = 21,         // overlaps set aside for the left-extension rescue pass (k_left_rescue)
        CT_SLOT = 22 };      // even: the 64-bit sums stay aligned in every slot
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, bc_idx, bc_rec, bc_win, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, bc_idx, bc_rec, bc_win, left_list, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, upair_tab_sw, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> sk_rec, uq_rec, chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec, bc_bpm_rec, bc_fast_rec, bc_dp_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -72,7 +73,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &bc_idx, &bc_rec, &bc_win, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &upair_tab_sw, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &bc_idx, &bc_rec, &bc_win, &left_list, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &upair_tab_sw, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -774,11 +775,21 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             if (wide_bands)
                 hipLaunchKernelGGL(k_rescue_accept<true>, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
                                    B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)(ct + CT_COLS_LO),
-                                   (uint4 *)W.ovl_c.p, P.k_cap, P.accept_err_pm);
-            else
+                                   (uint4 *)W.ovl_c.p, P.k_cap, P.accept_err_pm, (uint32_t *)nullptr, (uint32_t *)nullptr);
+            else {
+                // the right-extension pass and the verdict in one kernel; an overlap with an unmatched window LEFT of a matched one is set
+                // aside for the left-extension pass (k_left_rescue: it needs the matched window's path first), which then gives its verdict
+                TRY(ensure(ctx, W.left_list, (size_t)B.n_pairs * 4 + 16));
                 hipLaunchKernelGGL(k_rescue_accept<false>, dim3(fsv_grid_for(B.n_pairs, 64)), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p,
                                    B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)(ct + CT_COLS_LO),
+                                   (uint4 *)W.ovl_c.p, P.k_cap, P.accept_err_pm, (uint32_t *)W.left_list.p, ct + CT_LEFT);
+                FSV_HIP(ctx, hipGetLastError());
+                const uint32_t gridl = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 2u * (uint32_t)ctx->n_cu);
+                TRY(ensure(ctx, W.cols, (size_t)gridl * 64 * (FSV_WINDOW + 2) * 3 * sizeof(uint64_t)));
+                hipLaunchKernelGGL(k_left_rescue, dim3(gridl), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p, (const uint32_t *)W.left_list.p,
+                                   (const uint32_t *)(ct + CT_LEFT), (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p,
                                    (uint4 *)W.ovl_c.p, P.k_cap, P.accept_err_pm);
+            }
             FSV_HIP(ctx, hipGetLastError());
             W.kt.end(ctx);
             tv.stop();

@@ -1045,7 +1045,8 @@ __device__ __forceinline__ int double_thr(int pre, int x_len, int k_cap)
 template <bool WIDE>
 __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict__ store, fsv_ovl *__restrict__ ovl, uint32_t n_pairs,
                                                       fsv_wtask *__restrict__ tasks, fsv_wres *__restrict__ res,
-                                                      unsigned long long *__restrict__ stat_cols, uint4 *__restrict__ ovl_c, int k_cap, int accept_err_pm)
+                                                      unsigned long long *__restrict__ stat_cols, uint4 *__restrict__ ovl_c, int k_cap, int accept_err_pm,
+                                                      uint32_t *__restrict__ left_list, uint32_t *__restrict__ n_left)
 {
     const uint32_t p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n_pairs) return;
@@ -1086,6 +1087,18 @@ __global__ __launch_bounds__(64) void k_rescue_accept(const uint32_t *__restrict
             next = r.y_beg + r.end_site - r.extra_begin + 1;
         }
     }
+    if (n_bad && left_list) {
+        // an unmatched window left of a matched one: the left-extension pass (k_left_rescue) decides about this overlap
+        bool left = false;
+        for (int j = 1; j < o.n_win && !left; j++) left = R[j].err >= 0 && R[j - 1].err < 0;
+        if (left) {
+            left_list[atomicAdd(n_left, 1u)] = p;
+            o.is_match = 0; ovl[p] = o;
+            ovl_c[p] = make_uint4((uint32_t)o.x_s, (uint32_t)o.first_win, (uint32_t)o.n_win, 0u);
+            if (cols) atomicAdd(stat_cols, cols);
+            return;
+        }
+    }
     long long tlen = tlen0, terr = terr0;
     if (n_bad) {   // the rescue may have changed results and window lengths never change: only the error sum is taken again
         terr = 0;
@@ -1114,19 +1127,11 @@ __device__ __forceinline__ uint32_t task_ybase(const uint32_t *__restrict__ stor
 struct PathLists {      // task lists and their device-side lengths: 0-2 k_path_fr<1..3>, 3 k_path_sb, 4 k_path_dp<32>, 5 k_path_dp<64>, 6 k_path_wide
     uint32_t *list[7], *cnt[7];
 };
-__global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ store, const fsv_ovl *__restrict__ ovl,
-                                                   const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res, uint32_t n_tasks,
-                                                   fsv_wpath *__restrict__ paths, PathLists L, bool write_clean_ops, const uint32_t *__restrict__ n_dev)
+// try_cigar (Levenshtein_distance.h:465-507): the gap-free placement on the end diagonal K5 reported.  When its mismatches are the
+// window's distance that is the path (generate_cigar then only trims mismatches at the two ends into x-only ops): the record is
+// written and true returned; false: the window needs a walk.  One lane per window, no cross-lane traffic.
+__device__ __forceinline__ bool path_gapfree(const uint32_t *__restrict__ store, const fsv_wtask &t, const fsv_wres &r, fsv_wpath *__restrict__ P, bool write_clean_ops)
 {
-    if (n_dev) n_tasks = min(*n_dev, n_tasks);   // the grid covers the task bound; the count stays on the device (no host round trip), clamped to the bound
-    uint32_t blk;
-    if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
-    const uint32_t tid = blk * blockDim.x + threadIdx.x;
-    if (tid >= n_tasks) return;
-    const fsv_wtask t = tasks[tid];
-    const fsv_wres r = res[tid];
-    fsv_wpath *P = paths + tid;
-    if (r.err < 0 || !ovl[t.ovl].is_match) { P->state = 0; return; }
     const int n = t.x_len;
     const int start = r.end_site - n + 1;
     // mismatch map of the gap-free placement, 16 columns per word; field value 1 == op "mismatch"
@@ -1163,6 +1168,46 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
         }
         ok = (mm == r.err);
     }
+    if (!ok) return false;
+    // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops (3) and
+    // moves the y interval inwards -- the alignment end first, then its start; there are no gaps to shift.
+    int s2 = start, e2 = r.end_site;
+    if (r.err > 0) {
+        for (int i = n - 1; i >= 0 && ((ops32[i >> 4] >> ((i & 15) << 1)) & 3u) == 1u; i--) { ops32[i >> 4] |= 3u << ((i & 15) << 1); e2--; }
+        for (int i = 0; i < n && ((ops32[i >> 4] >> ((i & 15) << 1)) & 3u) == 1u; i++) { ops32[i >> 4] |= 3u << ((i & 15) << 1); s2++; }
+    }
+    P->ry_start = t.y_start - t.k + s2;
+    P->ry_end = t.y_start - t.k + e2;
+    uint32_t flags10 = 0;      // as in path_finish: an op other than a match among the first / last ten
+    if (r.err > 0) {
+        const int a = max(n - 10, 0), wi = a >> 4, sh = (a & 15) << 1;
+        const uint32_t lo = ops32[wi] >> sh, hi = (sh && wi + 1 < 26) ? ops32[wi + 1] << (32 - sh) : 0u;
+        flags10 = ((ops32[0] & 0xfffffu) ? 1u : 0u) | (((lo | hi) & 0xfffffu) ? 2u : 0u);
+    }
+    P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1; P->y_rev = t.y_rev; P->pad = (uint16_t)flags10; P->y_word = t.y_word; P->y_len = t.y_len;
+    // a distance-0 record carries no ops: its consumers (k_consensus, k_het) look at err first and never read them, and in the
+    // later correction rounds nearly every window is one -- 24 bytes out instead of 128
+    if (r.err == 0 && !write_clean_ops) return true;
+    uint2 *dst = reinterpret_cast<uint2 *>(P->ops); // ops sit at byte 24 of the record: 8-byte aligned
+#pragma unroll
+    for (int i = 0; i < 13; i++) dst[i] = make_uint2(ops32[2 * i], ops32[2 * i + 1]);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ store, const fsv_ovl *__restrict__ ovl,
+                                                   const fsv_wtask *__restrict__ tasks, const fsv_wres *__restrict__ res, uint32_t n_tasks,
+                                                   fsv_wpath *__restrict__ paths, PathLists L, bool write_clean_ops, const uint32_t *__restrict__ n_dev)
+{
+    if (n_dev) n_tasks = min(*n_dev, n_tasks);   // the grid covers the task bound; the count stays on the device (no host round trip), clamped to the bound
+    uint32_t blk;
+    if (!xcd_block((n_tasks + 255u) >> 8, blk)) return;
+    const uint32_t tid = blk * blockDim.x + threadIdx.x;
+    if (tid >= n_tasks) return;
+    const fsv_wtask t = tasks[tid];
+    const fsv_wres r = res[tid];
+    fsv_wpath *P = paths + tid;
+    if (r.err < 0 || !ovl[t.ovl].is_match) { P->state = 0; return; }
+    const bool ok = path_gapfree(store, t, r, P, write_clean_ops);
     // Not settled here: queued for one of the walk kernels, each list homogeneous -- first-pass bands (k <= 15) by distance: the walk
     // without the matrix up to 3 (nine in ten; a list per distance), the sub-band matrix up to 7, the general kernel beyond; the doubled thresholds of the
     // rescue pass (k <= 31); bands above 63 rows (k_path_wide).  One atomic instruction per wave: a class's first lane reserves its slots.
@@ -1184,30 +1229,7 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
             const uint32_t at = __shfl(base, leader, 64) + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
             if (cls >= 0) { P->state = 2; list[at] = tid; }
         }
-        if (!ok) return;
     }
-    // gap-free path.  generate_cigar (Correct.cpp:1387-1536) turns mismatches at either end into x-only ops (3) and
-    // moves the y interval inwards -- the alignment end first, then its start; there are no gaps to shift.
-    int s2 = start, e2 = r.end_site;
-    if (r.err > 0) {
-        for (int i = n - 1; i >= 0 && ((ops32[i >> 4] >> ((i & 15) << 1)) & 3u) == 1u; i--) { ops32[i >> 4] |= 3u << ((i & 15) << 1); e2--; }
-        for (int i = 0; i < n && ((ops32[i >> 4] >> ((i & 15) << 1)) & 3u) == 1u; i++) { ops32[i >> 4] |= 3u << ((i & 15) << 1); s2++; }
-    }
-    P->ry_start = t.y_start - t.k + s2;
-    P->ry_end = t.y_start - t.k + e2;
-    uint32_t flags10 = 0;      // as in path_finish: an op other than a match among the first / last ten
-    if (r.err > 0) {
-        const int a = max(n - 10, 0), wi = a >> 4, sh = (a & 15) << 1;
-        const uint32_t lo = ops32[wi] >> sh, hi = (sh && wi + 1 < 26) ? ops32[wi + 1] << (32 - sh) : 0u;
-        flags10 = ((ops32[0] & 0xfffffu) ? 1u : 0u) | (((lo | hi) & 0xfffffu) ? 2u : 0u);
-    }
-    P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1; P->y_rev = t.y_rev; P->pad = (uint16_t)flags10; P->y_word = t.y_word; P->y_len = t.y_len;
-    // a distance-0 record carries no ops: its consumers (k_consensus, k_het) look at err first and never read them, and in the
-    // later correction rounds nearly every window is one -- 24 bytes out instead of 128
-    if (r.err == 0 && !write_clean_ops) return;
-    uint2 *dst = reinterpret_cast<uint2 *>(P->ops); // ops sit at byte 24 of the record: 8-byte aligned
-#pragma unroll
-    for (int i = 0; i < 13; i++) dst[i] = make_uint2(ops32[2 * i], ops32[2 * i + 1]);
 }
 
 // base access through one cached 16-base word (forward position >> 4 is the key)
@@ -1319,34 +1341,21 @@ template <class WordT> struct PathSink {
     }
 };
 
+// Reserve_Banded_BPM_PATH by one lane for one window: the forward pass with every column's {D0, VP, VN} kept in the lane's slice of the
+// HBM scratch, the walk back, generate_cigar and the record (path_finish).  The general K6 kernel's body; k_left_rescue calls it too.
 template <class WordT>
-__global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
-                                                const uint32_t *__restrict__ dp_list, uint32_t list_begin, uint32_t list_end,
-                                                fsv_wpath *__restrict__ paths, WordT *__restrict__ cols, uint32_t stride,
-                                                const uint32_t *__restrict__ n_dev)
+__device__ __forceinline__ void path_general(const uint32_t *__restrict__ store, const fsv_wtask &t, fsv_wpath *__restrict__ P, uint32_t (*s_ops)[64],
+                                             int lane64, WordT *__restrict__ cols_slice)
 {
-    __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
-    const int lane64 = threadIdx.x;
-    if (n_dev) list_end = list_begin + *n_dev;   // the list's length as the kernel before left it: no host round trip
-    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;   // this lane's slice of the scratch, reused for every task it takes
-    // persistent blocks: the grid is sized to what the device holds at once and every block strides through the list, so the
-    // scratch is a few hundred MB whatever the number of windows, and the whole list is one launch
-    for (uint32_t li = list_begin + slot; li < list_end; li += gridDim.x * 64) {
-    const uint32_t tid = dp_list[li];
-    const fsv_wtask t = tasks[tid];
-    fsv_wpath *P = paths + tid;
     const int n = t.x_len, k = t.k, band = 2 * k + 1;
     fsv_wres r;
-    PathSink<WordT> sink{cols + (size_t)blockIdx.x * (FSV_WINDOW + 2) * 3 * 64, 64u, (uint32_t)lane64};
+    PathSink<WordT> sink{cols_slice, 64u, (uint32_t)lane64};
     bpm_run(store, t, r, sink);
-    if (r.err < 0) { P->state = 0; continue; } // cannot happen: K5 matched this window
+    if (r.err < 0) { P->state = 0; return; } // cannot happen: K5 matched this window
 #define COL(c, w) (sink.cols[((c) * 3 + (w)) * 64 + lane64])
     for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
     int end = r.end_site, err = r.err;
     int cur = err, col = n, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
-    // The walk needs columns col and col-1 at every step and moves to col-1 or stays: a step-by-step walk is a chain of
-    // ~n dependent scratch reads.  Instead each lane keeps TC+1 columns around its position in LDS; when any lane of the wave
-    // runs out, every walking lane re-centres its tile -- 3(TC+1) independent loads in flight, one memory latency per ~TC steps.
     {
     // the kernel is instruction-bound (4-5 waves per SIMD keep the issue slots full), so the walk is written for few
     // instructions: WordT-wide bit tests (only band bits are read), the column it leaves behind handed to the next step
@@ -1376,8 +1385,93 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
     if (plen & 15) s_ops[plen >> 4][lane64] = acc;
     }
     path_finish(store, t, P, s_ops, lane64, col, dir, plen, start, end, err);
-    } // next task of this lane
 #undef COL
+}
+
+template <class WordT>
+__global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ store, const fsv_wtask *__restrict__ tasks,
+                                                const uint32_t *__restrict__ dp_list, uint32_t list_begin, uint32_t list_end,
+                                                fsv_wpath *__restrict__ paths, WordT *__restrict__ cols, uint32_t stride,
+                                                const uint32_t *__restrict__ n_dev)
+{
+    __shared__ uint32_t s_ops[28][64];     // per lane: the path being built, 2 bits per op, stored end-to-start (448 ops)
+    const int lane64 = threadIdx.x;
+    if (n_dev) list_end = list_begin + *n_dev;   // the list's length as the kernel before left it: no host round trip
+    const uint32_t slot = blockIdx.x * 64 + threadIdx.x;   // this lane's slice of the scratch, reused for every task it takes
+    // persistent blocks: the grid is sized to what the device holds at once and every block strides through the list, so the
+    // scratch is a few hundred MB whatever the number of windows, and the whole list is one launch
+    for (uint32_t li = list_begin + slot; li < list_end; li += gridDim.x * 64) {
+        const uint32_t tid = dp_list[li];
+        const fsv_wtask t = tasks[tid];
+        path_general<WordT>(store, t, paths + tid, s_ops, lane64, cols + (size_t)blockIdx.x * (FSV_WINDOW + 2) * 3 * 64);
+    }
+    (void)stride;
+}
+
+// ------------------------------------------------------------------------------------------------ k_left_rescue
+// recalcate_window_advance's left pass (Correct.cpp:2745-2905), for the overlaps k_rescue_accept set aside: a matched window whose
+// left neighbour is unmatched gets its path first -- its real start on y -- and the unmatched windows to its left are tried again one
+// after the other, each placed so that it ends right in front of the window to its right, with the doubled threshold and its path at
+// once (the next one needs its start).  Then the overlap is accepted or not, as k_rescue_accept does: a window whose path was
+// computed here counts with its distance after generate_cigar, as in hifiasm.  One lane per listed overlap (they are few: an unmatched
+// window left of a matched one), a persistent grid over the list; oracle/asm.c:align_overlaps (left_rescue) statement for statement.
+__global__ __launch_bounds__(64) void k_left_rescue(const uint32_t *__restrict__ store, fsv_ovl *__restrict__ ovl, const uint32_t *__restrict__ list,
+                                                    const uint32_t *__restrict__ n_list_dev, fsv_wtask *__restrict__ tasks, fsv_wres *__restrict__ res,
+                                                    fsv_wpath *__restrict__ paths, uint64_t *__restrict__ cols, uint4 *__restrict__ ovl_c, int k_cap, int accept_err_pm)
+{
+    __shared__ uint32_t s_ops[28][64];
+    const int lane64 = threadIdx.x;
+    const uint32_t n_list = *n_list_dev;
+    uint64_t *slice = cols + (size_t)blockIdx.x * (FSV_WINDOW + 2) * 3 * 64;
+    for (uint32_t li = blockIdx.x * 64 + threadIdx.x; li < n_list; li += gridDim.x * 64) {
+        const uint32_t p = list[li];
+        fsv_ovl o = ovl[p];
+        fsv_wtask *T = tasks + o.first_win;
+        fsv_wres *R = res + o.first_win;
+        fsv_wpath *PP = paths + o.first_win;
+        long long post = 0;          // sum over the windows whose path was computed here of (distance after generate_cigar - K5's distance)
+        auto window_path = [&](const fsv_wtask &t, const fsv_wres &r, fsv_wpath *P) {
+            if (!path_gapfree(store, t, r, P, true)) path_general<uint64_t>(store, t, P, s_ops, lane64, slice);
+        };
+        for (int j = 1; j < o.n_win; j++) {
+            if (R[j].err < 0 || R[j - 1].err >= 0) continue;
+            const fsv_wtask tj = T[j];
+            const fsv_wres rj = R[j];
+            window_path(tj, rj, PP + j);
+            const uint4 hj = *reinterpret_cast<const uint4 *>(PP + j);
+            if ((hj.w & 0xffu) != 1u) { R[j].err = -1; continue; }       // (a path longer than a record holds: the window is unused, as in window_path)
+            post += (int)(int16_t)(hj.z >> 16) - rj.err;
+            int total_y_end = (int)hj.x - 1;
+            for (int k2 = j - 1; k2 >= 0 && R[k2].err < 0; k2--) {
+                fsv_wtask u = T[k2];
+                u.k = (uint8_t)double_thr(u.k, u.x_len, k_cap);
+                if (total_y_end <= 0) break;
+                u.y_start = total_y_end - (int)u.x_len + 1;
+                fsv_wres r;
+                if (!bpm_window_geometry(u, r, k_cap)) break;
+                if ((u.x_len + 2 * u.k - r.extra_begin - r.extra_end) + u.k < u.x_len) break;
+                bpm_run(store, u, r, BpmNoSink());
+                if (r.err < 0) break;
+                window_path(u, r, PP + k2);
+                const uint4 hk = *reinterpret_cast<const uint4 *>(PP + k2);
+                if ((hk.w & 0xffu) != 1u) break;
+                T[k2] = u; R[k2] = r;
+                post += (int)(int16_t)(hk.z >> 16) - r.err;
+                total_y_end = (int)hk.x - 1;
+            }
+        }
+        int align = 0;
+        long long tlen = 0, terr = post;
+        for (int j = 0; j < o.n_win; j++) {
+            const int e = R[j].err, xl = T[j].x_len;
+            if (e >= 0) { align += xl; terr += e; } else terr += xl;
+            tlen += xl;
+        }
+        o.align_len = align; o.err_sum = (int32_t)terr;
+        o.is_match = ((long long)(o.x_e - o.x_s + 1) * 9 <= (long long)align * 10 && terr * 1000 <= tlen * accept_err_pm) ? 1 : 0;
+        ovl[p] = o;
+        ovl_c[p] = make_uint4((uint32_t)o.x_s, (uint32_t)o.first_win, (uint32_t)o.n_win | (o.is_match ? 0x80000000u : 0u), 0u);
+    }
 }
 
 // ---- K6 for first-pass windows: k <= 15, distance 4 .. FSV_SB_MAXERR (3 and below: k_path_fr further down) ----------------

@@ -1351,7 +1351,7 @@ void orc_asm_default_params(orc_asm_params *P)
     P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1; P->ins_dag = 1;
     P->min_anchors_final = 1; P->min_ovlp_final = 1; P->graph_layout = 1;
     P->junction_cigars = 1;
-    P->left_rescue = 0;   /* restated here, not yet in the HIP path: off so that the two stay bit-identical (it changes none of the golden sets) */
+    P->left_rescue = 1;   /* recalcate_window_advance's left pass (Correct.cpp:2745-2905); the HIP path: k_left_rescue */
 }
 
 /* Overlaps of the corrected reads for the layout (worker_ov_final, Assembly.cpp:1284-1306): exact ones (update_exact_overlaps),

@@ -104,6 +104,7 @@ def ont_params():
     p = default_params()
     p.k, p.w, p.hpc, p.bw_ec, p.bw_final = 15, 15, 0, 150, 50
     p.min_ovlp, p.min_anchors = 500, 3
+    p.left_rescue = 0          # the wide-band path has no left-extension pass
     p.win_rate_pm, p.k_cap, p.accept_err_pm, p.bw_rechain, p.min_contig_reads, p.w_later = 250, 95, 300, 50, 2, 63
     p.partition = 0
     p.second_round = 0

@@ -211,9 +211,10 @@ def test_every_round_equals_hifiasm(ctx, golden_dir, rounds):
 
 @pytest.mark.parametrize("rounds", [1, 2, 3])
 def test_fresh_seed_sets_equal_hifiasm(ctx, golden_dir, rounds):
-    """the 40 read sets of tests/golden/hifiasm_fresh.json (seeds no other golden uses; 30 / 50 / 70 kb windows at 8x - 25x) in one call:
+    """the 80 read sets of tests/golden/hifiasm_fresh.json (seeds no other golden uses; 30 / 50 / 70 kb windows at 6x - 30x) in one call:
     corrected reads equal `hifiasm -r N` md5 for md5 after one, two and three rounds, and the contigs of the three-round run are
-    byte-identical -- two of these sets are where the 500-base overlap minimum and the one-sided final re-chain showed"""
+    byte-identical -- three of these sets are where the 500-base overlap minimum, the one-sided final re-chain and the missing
+    left-extension rescue pass showed"""
     gold = json.load(open(os.path.join(golden_dir, "hifiasm_fresh.json")))["sets"]
     sets = [synth.make_region(g["region"], width=g["width"], depth_per_hap=g["depth"]).reads[g["hap"] - 1] for g in gold]
     for s_, g in zip(sets, gold):

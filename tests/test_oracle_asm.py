@@ -236,9 +236,9 @@ def test_low_coverage_sets_equal_hifiasm(golden_dir, idx):
 
 def _fresh_ids(golden_dir=os.path.join(os.path.dirname(__file__), "golden")):
     gold = json.load(open(os.path.join(golden_dir, "hifiasm_fresh.json")))["sets"]
-    # every sixth set by default plus the two that once differed (7010 / 2 after one round, 7019 / 1 in its contig); all of them with
+    # every tenth set by default plus the three that once differed (7010 / 2 and 8011 / 1 after one round, 7019 / 1 in its contig); all of them with
     # FSV_FULL_GOLDEN=1 and on the GPU side (tests/test_gpu_asm.py)
-    return [i for i, g in enumerate(gold) if os.environ.get("FSV_FULL_GOLDEN") or i % 6 == 0 or (g["region"], g["hap"]) in ((7010, 2), (7019, 1))]
+    return [i for i, g in enumerate(gold) if os.environ.get("FSV_FULL_GOLDEN") or i % 10 == 0 or (g["region"], g["hap"]) in ((7010, 2), (7019, 1), (8011, 1))]
 
 
 @pytest.mark.parametrize("idx", _fresh_ids())

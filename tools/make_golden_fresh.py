@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""Golden data from read sets of seeds no other golden file uses (7000 ...: three window widths, 8x - 25x per haplotype): the corrected
+"""Golden data from read sets of seeds no other golden file uses (7000 ..., 8000 ...: three window widths, 6x - 30x per haplotype): the corrected
 reads of the reference's hifiasm-0.14 (oracle/_ref) after one, two and three correction rounds (-r N --write-ec) and its contigs
--> tests/golden/hifiasm_fresh.json.  Two of these sets showed what the other goldens did not (a 300-base overlap voting at a read's
-end; the two directions of a gapped final overlap differing by an indel near a read end).  Needs /root/reference (oracle/ref.mk)."""
+-> tests/golden/hifiasm_fresh.json.  Three of these sets showed what the other goldens did not (a 300-base overlap voting at a read's
+end; the two directions of a gapped final overlap differing by an indel near a read end; an overlap that only the left-extension
+rescue pass accepts).  Needs /root/reference (oracle/ref.mk)."""
 import hashlib, json, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from focalsv_amd import synth
 HIFIASM = os.path.join(ROOT, "oracle", "_ref", "hifiasm-0.14")
-FIRST, COUNT, DEPTHS, WIDTHS = 7000, 20, (15.0, 10.0, 25.0, 8.0), (30000, 50000, 70000)
+BLOCKS = ((7000, 20, (15.0, 10.0, 25.0, 8.0)), (8000, 20, (12.0, 20.0, 30.0, 6.0)))      # (first seed, count, depths per haplotype)
+WIDTHS = (30000, 50000, 70000)
 
 
 def canon(s):
@@ -35,8 +37,8 @@ def run(reads, rounds, tmp):
 def main():
     out = []
     with tempfile.TemporaryDirectory() as tmp:
-        for i in range(FIRST, FIRST + COUNT):
-            depth, width = DEPTHS[i % len(DEPTHS)], WIDTHS[i % len(WIDTHS)]
+        for i, depths in ((i, d) for first, count, d in BLOCKS for i in range(first, first + count)):
+            depth, width = depths[i % len(depths)], WIDTHS[i % len(WIDTHS)]
             r = synth.make_region(i, width=width, depth_per_hap=depth)
             for h in (1, 2):
                 reads = r.reads[h - 1]
