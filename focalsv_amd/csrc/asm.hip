@@ -60,6 +60,7 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
 struct AsmWs {
     DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, bc_idx, bc_rec, bc_win, left_list, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, upair_tab_sw, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+    int occ_sb = 0, occ_fr[3] = {0, 0, 0}, occ_wide = 0;   // blocks per CU of the persistent K6 kernels (hipOccupancyMaxActiveBlocksPerMultiprocessor: asked once)
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> sk_rec, uq_rec, chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec, bc_bpm_rec, bc_fast_rec, bc_dp_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
     // state of the last run (for fsv_asm_fetch_reads / stats)
@@ -500,8 +501,8 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
     // persistent grids: as many blocks as the device holds at once, each striding through its list, so the column scratch
     // is a fixed few hundred MB whatever the number of windows
     {
-        int per_cu = 0;
-        FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_sb<false>, 64, 0));
+        if (!W.occ_sb) FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&W.occ_sb, k_path_sb<false>, 64, 0));
+        const int per_cu = W.occ_sb;
         const uint32_t grid = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, per_cu) * (uint32_t)ctx->n_cu);
         TRY(ensure(ctx, W.cols_sb, (size_t)grid * FSV_SB_QUADS * 64 * sizeof(uint4)));
         if (getenv("FSV_K6_STAMPS")) {   // diagnostic: where a k_path_sb wave spends its cycles (never in a measured run)
@@ -523,8 +524,8 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
         {
             const bool stamps = getenv("FSV_K6_STAMPS") != nullptr;    // diagnostic, never in a measured run
             auto fr = [&](auto kern, int e, const DevBuf &list, uint32_t *cnt) -> int {
-                int pf = 0;
-                FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, kern, 64, 0));
+                int &pf = W.occ_fr[e - 1];
+                if (!pf || stamps) FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, kern, 64, 0));
                 const uint32_t gridf = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, pf) * (uint32_t)ctx->n_cu);
                 if (stamps) { TRY(ensure(ctx, W.tmp, 64)); FSV_HIP(ctx, hipMemsetAsync(W.tmp.p, 0, 64, ctx->stream)); }
                 hipLaunchKernelGGL(kern, dim3(gridf), dim3(64), 0, ctx->stream, store, tasks, res, (const uint32_t *)list.p, (const uint32_t *)cnt, paths,
@@ -562,8 +563,8 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
         FSV_HIP(ctx, hipGetLastError());
         if (wide_bands) {
             // bands above 63 rows: every gapped window of an ONT-profile batch; 1.15 MB of column scratch per persistent block
-            int pc = 0;
-            FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_path_wide, 64, 0));
+            if (!W.occ_wide) FSV_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&W.occ_wide, k_path_wide, 64, 0));
+            const int pc = W.occ_wide;
             const uint32_t gridw = std::min<uint32_t>(fsv_grid_for(task_cap, 64), (uint32_t)std::max(1, std::min(pc, 12)) * (uint32_t)ctx->n_cu);
             TRY(ensure(ctx, W.cols_wide, (size_t)gridw * FSV_WINDOW * 2 * FSV_WL * 64 * 4));
             hipLaunchKernelGGL(k_path_wide, dim3(gridw), dim3(64), 0, ctx->stream, store, tasks, res,
@@ -784,10 +785,9 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
                                    B.n_pairs, (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (unsigned long long *)(ct + CT_COLS_LO),
                                    (uint4 *)W.ovl_c.p, P.k_cap, P.accept_err_pm, (uint32_t *)W.left_list.p, ct + CT_LEFT);
                 FSV_HIP(ctx, hipGetLastError());
-                const uint32_t gridl = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 2u * (uint32_t)ctx->n_cu);
-                TRY(ensure(ctx, W.cols, (size_t)gridl * 64 * (FSV_WINDOW + 2) * 3 * sizeof(uint64_t)));
+                const uint32_t gridl = std::min<uint32_t>(std::max(1u, B.n_pairs), 8u * (uint32_t)ctx->n_cu);
                 hipLaunchKernelGGL(k_left_rescue, dim3(gridl), dim3(64), 0, ctx->stream, store, (fsv_ovl *)W.ovl.p, (const uint32_t *)W.left_list.p,
-                                   (const uint32_t *)(ct + CT_LEFT), (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (fsv_wpath *)W.paths.p, (uint64_t *)W.cols.p,
+                                   (const uint32_t *)(ct + CT_LEFT), (fsv_wtask *)W.tasks.p, (fsv_wres *)W.res.p, (fsv_wpath *)W.paths.p, (uint64_t *)nullptr,
                                    (uint4 *)W.ovl_c.p, P.k_cap, P.accept_err_pm);
             }
             FSV_HIP(ctx, hipGetLastError());
@@ -1183,6 +1183,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             n_windows2 += n3;
             W.stats.n_junction_cigars += n3;
             W.stats.n_junction_used += c3[CT_B_LIST];
+            if (getenv("FSV_BCIG_DEBUG")) fprintf(stderr, "[fsv] round %d: %u overlaps set aside for the left-extension pass\n", sl, c[CT_LEFT]);
             if (getenv("FSV_BCIG_DEBUG")) fprintf(stderr, "[fsv] round %d: %llu junction cigars, %u accepted but showing what the window cigars show, %u used\n", sl, (unsigned long long)n3, c3[CT_B_RETRY], c3[CT_B_LIST]);
             W.kt.recs[W.bc_bpm_rec[sl]].bytes = n3 * 212ull;
             if ((size_t)sl < W.bc_fast_rec.size()) W.kt.recs[W.bc_fast_rec[sl]].bytes = n3 * (16ull + 196ull) + (n3 - n_dp3) * 128ull;

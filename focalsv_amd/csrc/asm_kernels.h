@@ -1345,14 +1345,16 @@ template <class WordT> struct PathSink {
 // HBM scratch, the walk back, generate_cigar and the record (path_finish).  The general K6 kernel's body; k_left_rescue calls it too.
 template <class WordT>
 __device__ __forceinline__ void path_general(const uint32_t *__restrict__ store, const fsv_wtask &t, fsv_wpath *__restrict__ P, uint32_t (*s_ops)[64],
-                                             int lane64, WordT *__restrict__ cols_slice)
+                                             int lane64, WordT *cols_slice, uint32_t cstride = 64u)
 {
+    // cols_slice: the scratch of this lane's block, word w of column c of lane l at ((c) * 3 + w) * cstride + l (k_path_dp: 64 lanes a
+    // block in HBM; k_left_rescue: one lane a block, in LDS)
     const int n = t.x_len, k = t.k, band = 2 * k + 1;
     fsv_wres r;
-    PathSink<WordT> sink{cols_slice, 64u, (uint32_t)lane64};
+    PathSink<WordT> sink{cols_slice, cstride, cstride == 1u ? 0u : (uint32_t)lane64};
     bpm_run(store, t, r, sink);
     if (r.err < 0) { P->state = 0; return; } // cannot happen: K5 matched this window
-#define COL(c, w) (sink.cols[((c) * 3 + (w)) * 64 + lane64])
+#define COL(c, w) (sink.cols[((c) * 3 + (w)) * (size_t)sink.stride + sink.lane])
     for (int i = 0; i < 28; i++) s_ops[i][lane64] = 0;
     int end = r.end_site, err = r.err;
     int cur = err, col = n, plen = 0, start = end, row = band - (n + 2 * k - end), dir = 0;
@@ -1413,17 +1415,23 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
 // left neighbour is unmatched gets its path first -- its real start on y -- and the unmatched windows to its left are tried again one
 // after the other, each placed so that it ends right in front of the window to its right, with the doubled threshold and its path at
 // once (the next one needs its start).  Then the overlap is accepted or not, as k_rescue_accept does: a window whose path was
-// computed here counts with its distance after generate_cigar, as in hifiasm.  One lane per listed overlap (they are few: an unmatched
-// window left of a matched one), a persistent grid over the list; oracle/asm.c:align_overlaps (left_rescue) statement for statement.
+// computed here counts with its distance after generate_cigar, as in hifiasm.  One block (one working lane) per listed overlap, a
+// persistent grid over the list; oracle/asm.c:align_overlaps (left_rescue) statement for statement.
 __global__ __launch_bounds__(64) void k_left_rescue(const uint32_t *__restrict__ store, fsv_ovl *__restrict__ ovl, const uint32_t *__restrict__ list,
                                                     const uint32_t *__restrict__ n_list_dev, fsv_wtask *__restrict__ tasks, fsv_wres *__restrict__ res,
                                                     fsv_wpath *__restrict__ paths, uint64_t *__restrict__ cols, uint4 *__restrict__ ovl_c, int k_cap, int accept_err_pm)
 {
+    // One lane of a block works, with the column scratch of its window in LDS: the walk back is a chain of dependent reads of that
+    // scratch, column after column -- 1.3 ms for a single window from HBM, whatever the number of overlaps listed (a few thousand in the
+    // first round, a dozen later); 40 us from LDS.  (cols: unused.)
     __shared__ uint32_t s_ops[28][64];
-    const int lane64 = threadIdx.x;
+    __shared__ uint64_t s_cols[(FSV_WINDOW + 2) * 3];
+    if (threadIdx.x != 0) return;
+    const int lane64 = 0;
     const uint32_t n_list = *n_list_dev;
-    uint64_t *slice = cols + (size_t)blockIdx.x * (FSV_WINDOW + 2) * 3 * 64;
-    for (uint32_t li = blockIdx.x * 64 + threadIdx.x; li < n_list; li += gridDim.x * 64) {
+    uint64_t *slice = s_cols;
+    (void)cols;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
         const uint32_t p = list[li];
         fsv_ovl o = ovl[p];
         fsv_wtask *T = tasks + o.first_win;
@@ -1431,7 +1439,7 @@ __global__ __launch_bounds__(64) void k_left_rescue(const uint32_t *__restrict__
         fsv_wpath *PP = paths + o.first_win;
         long long post = 0;          // sum over the windows whose path was computed here of (distance after generate_cigar - K5's distance)
         auto window_path = [&](const fsv_wtask &t, const fsv_wres &r, fsv_wpath *P) {
-            if (!path_gapfree(store, t, r, P, true)) path_general<uint64_t>(store, t, P, s_ops, lane64, slice);
+            if (!path_gapfree(store, t, r, P, true)) path_general<uint64_t>(store, t, P, s_ops, lane64, slice, 1u);
         };
         for (int j = 1; j < o.n_win; j++) {
             if (R[j].err < 0 || R[j - 1].err >= 0) continue;
