@@ -55,10 +55,11 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
        CT_MZRAW_LO = 16, CT_MZRAW_HI = 17, CT_BASES_LO = 18, CT_BASES_HI = 19,   // k_uniq's other two sums: CT_MZ + 3 and + 4 as 64-bit words
        CT_DP_FR3 = 20,       // k_path_fr's lists by distance: CT_DP_SB16 (1), CT_DP (2), CT_DP_FR3 (3)
        CT_LEFT = 21,         // overlaps set aside for the left-extension rescue pass (k_left_rescue)
-       CT_SLOT = 22 };      // even: the 64-bit sums stay aligned in every slot
+       CT_FIX = 22, CT_FIXED = 23,   // fix_boundary's candidates (k_path_fast) and the windows it moved
+       CT_SLOT = 24 };      // even: the 64-bit sums stay aligned in every slot
 
 struct AsmWs {
-    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, bc_idx, bc_rec, bc_win, left_list, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
+    DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, bc_idx, bc_rec, bc_win, left_list, fix_list, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, upair_tab_sw, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
     int occ_sb = 0, occ_fr[3] = {0, 0, 0}, occ_wide = 0;   // blocks per CU of the persistent K6 kernels (hipOccupancyMaxActiveBlocksPerMultiprocessor: asked once)
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
@@ -74,7 +75,7 @@ struct AsmWs {
     std::vector<DevBuf *> all()
     {
         return {&store[0], &store[1], &cols_sb, &contig_all, &word_off, &len, &set_start, &read_set, &pair_base, &mz, &mz_off, &mz_cnt, &ovl, &tasks, &res, &paths,
-                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &bc_idx, &bc_rec, &bc_win, &left_list, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &upair_tab_sw, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
+                &counters, &dp_list, &dp_list2, &dp_list3, &dp_list16, &dp_list_e3, &dp_wide, &dp_xwide, &cols_wide, &set_cols, &site_cnt, &site_rec, &site_off, &site_vec, &site_cursor, &redo, &site_lists, &read_dirty, &cov3, &lb, &sr_store, &brel_off, &tasks2, &res2, &paths2, &idx2, &bc_idx, &bc_rec, &bc_win, &left_list, &fix_list, &tasks3, &res3, &src3, &bnd_flag, &bnd_list, &bnd_patch, &bnd_bytes, &changed, &pair_read, &wide_list, &cols, &tmp, &gwin_off, &gwin_read, &sk_ends, &sk_low, &sk_high, &hits, &hits_packed, &set_hits, &ovl_prev, &exact_flag, &inexact_list, &upair_base, &upair_tab, &upair_tab_sw, &ovl_c, &gwin_tab, &cwin, &cwin_len, &warn, &thr_tab, &pieces, &contig_out, &new_len, &unpack_off};
     }
 };
 
@@ -489,8 +490,11 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
 {
     // pass_kind 0: the round's window tasks, 1: the junction tasks of its second consensus pass, 2: the junction cigars of the partition
     { const size_t rec_ = W.kt.begin(ctx, KN_PATH_FAST, 0); (pass_kind == 0 ? W.fast_rec : pass_kind == 1 ? W.fast2_rec : W.bc_fast_rec).push_back(rec_); }
-    const PathLists lists{{(uint32_t *)W.dp_list16.p, (uint32_t *)W.dp_list.p, (uint32_t *)W.dp_list_e3.p, (uint32_t *)W.dp_list2.p, (uint32_t *)W.dp_list3.p, (uint32_t *)W.dp_wide.p, (uint32_t *)W.dp_xwide.p},
-                          {ct + CT_DP_SB16, ct + CT_DP, ct + CT_DP_FR3, ct + CT_DP_SB, ct + CT_DP_GEN, ct + CT_DP_WIDE, ct + CT_DP_XW}};
+    const bool fix = pass_kind == 0 && !wide_bands;      // fix_boundary: the windows' final cigars only (not the junction alignments)
+    if (fix) TRY(ensure(ctx, W.fix_list, (size_t)task_cap * 4));
+    const PathLists lists{{(uint32_t *)W.dp_list16.p, (uint32_t *)W.dp_list.p, (uint32_t *)W.dp_list_e3.p, (uint32_t *)W.dp_list2.p, (uint32_t *)W.dp_list3.p, (uint32_t *)W.dp_wide.p, (uint32_t *)W.dp_xwide.p,
+                           fix ? (uint32_t *)W.fix_list.p : (uint32_t *)nullptr},
+                          {ct + CT_DP_SB16, ct + CT_DP, ct + CT_DP_FR3, ct + CT_DP_SB, ct + CT_DP_GEN, ct + CT_DP_WIDE, ct + CT_DP_XW, fix ? ct + CT_FIX : (uint32_t *)nullptr}};
     hipLaunchKernelGGL(k_path_fast, dim3((fsv_grid_for(task_cap, 256) + 7u) & ~7u), dim3(256), 0, ctx->stream, store, (const fsv_ovl *)W.ovl.p,
                        tasks, res, task_cap, paths, lists, false, n_tasks_dev);
     FSV_HIP(ctx, hipGetLastError());
@@ -571,6 +575,13 @@ static int path_stage(fsv_ctx *ctx, AsmWs &W, const uint32_t *store, const fsv_w
                                (const uint32_t *)W.dp_xwide.p, (const uint32_t *)(ct + CT_DP_XW), paths, (uint32_t *)W.cols_wide.p, P.k_cap);
             FSV_HIP(ctx, hipGetLastError());
         }
+    }
+    if (fix) {
+        // fix_boundary (Correct.cpp:1676): the few windows whose alignment may touch the edge of its band (k_path_fast listed them)
+        const uint32_t gridf = std::min<uint32_t>(fsv_grid_for(task_cap, 64), 8u * (uint32_t)ctx->n_cu);
+        hipLaunchKernelGGL(k_fix_boundary, dim3(gridf), dim3(64), 0, ctx->stream, store, (const uint32_t *)W.fix_list.p, (const uint32_t *)(ct + CT_FIX),
+                           const_cast<fsv_wtask *>(tasks), const_cast<fsv_wres *>(res), paths, P.k_cap, ct + CT_FIXED);
+        FSV_HIP(ctx, hipGetLastError());
     }
     W.kt.end(ctx);
     return FSV_OK;
@@ -1183,7 +1194,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
             n_windows2 += n3;
             W.stats.n_junction_cigars += n3;
             W.stats.n_junction_used += c3[CT_B_LIST];
-            if (getenv("FSV_BCIG_DEBUG")) fprintf(stderr, "[fsv] round %d: %u overlaps set aside for the left-extension pass\n", sl, c[CT_LEFT]);
+            if (getenv("FSV_BCIG_DEBUG")) fprintf(stderr, "[fsv] round %d: %u overlaps set aside for the left-extension pass; fix_boundary: %u candidates, %u windows moved\n", sl, c[CT_LEFT], c[CT_FIX], c[CT_FIXED]);
             if (getenv("FSV_BCIG_DEBUG")) fprintf(stderr, "[fsv] round %d: %llu junction cigars, %u accepted but showing what the window cigars show, %u used\n", sl, (unsigned long long)n3, c3[CT_B_RETRY], c3[CT_B_LIST]);
             W.kt.recs[W.bc_bpm_rec[sl]].bytes = n3 * 212ull;
             if ((size_t)sl < W.bc_fast_rec.size()) W.kt.recs[W.bc_fast_rec[sl]].bytes = n3 * (16ull + 196ull) + (n3 - n_dp3) * 128ull;

@@ -1124,8 +1124,8 @@ __device__ __forceinline__ uint32_t task_ybase(const uint32_t *__restrict__ stor
 
 // Fast paths of Reserve_Banded_BPM_PATH (Levenshtein_distance.h:516-531): err == 0, or a gap-free placement with
 // exactly err mismatches (try_cigar).  Everything else is queued for one of the walk kernels.
-struct PathLists {      // task lists and their device-side lengths: 0-2 k_path_fr<1..3>, 3 k_path_sb, 4 k_path_dp<32>, 5 k_path_dp<64>, 6 k_path_wide
-    uint32_t *list[7], *cnt[7];
+struct PathLists {      // task lists and their device-side lengths: 0-2 k_path_fr<1..3>, 3 k_path_sb, 4 k_path_dp<32>, 5 k_path_dp<64>, 6 k_path_wide,
+    uint32_t *list[8], *cnt[8];   // 7 (may be null): windows whose alignment may touch the edge of its band (k_fix_boundary looks at them again)
 };
 // try_cigar (Levenshtein_distance.h:465-507): the gap-free placement on the end diagonal K5 reported.  When its mismatches are the
 // window's distance that is the path (generate_cigar then only trims mismatches at the two ends into x-only ops): the record is
@@ -1182,7 +1182,7 @@ __device__ __forceinline__ bool path_gapfree(const uint32_t *__restrict__ store,
     if (r.err > 0) {
         const int a = max(n - 10, 0), wi = a >> 4, sh = (a & 15) << 1;
         const uint32_t lo = ops32[wi] >> sh, hi = (sh && wi + 1 < 26) ? ops32[wi + 1] << (32 - sh) : 0u;
-        flags10 = ((ops32[0] & 0xfffffu) ? 1u : 0u) | (((lo | hi) & 0xfffffu) ? 2u : 0u);
+        flags10 = ((ops32[0] & 0xfffffu) ? 1u : 0u) | (((lo | hi) & 0xfffffu) ? 2u : 0u) | (start == 0 ? 4u : 0u);   // bit 2: the alignment starts in the padded window's first column
     }
     P->path_len = (int16_t)n; P->err = (int16_t)r.err; P->state = 1; P->y_rev = t.y_rev; P->pad = (uint16_t)flags10; P->y_word = t.y_word; P->y_len = t.y_len;
     // a distance-0 record carries no ops: its consumers (k_consensus, k_het) look at err first and never read them, and in the
@@ -1208,6 +1208,10 @@ __global__ __launch_bounds__(256) void k_path_fast(const uint32_t *__restrict__ 
     fsv_wpath *P = paths + tid;
     if (r.err < 0 || !ovl[t.ovl].is_match) { P->state = 0; return; }
     const bool ok = path_gapfree(store, t, r, P, write_clean_ops);
+    // fix_boundary's candidates, from what K5 knows: the alignment ends in the padded window's last column, or could start in its first
+    // one (it starts at end - (n - 1) - (inserted - deleted bases), and the distance bounds that difference)
+    if (L.cnt[7] && r.err > 0 && t.k <= FSV_K_MAX && (r.end_site == (int)t.x_len + 2 * (int)t.k - 1 || r.end_site - ((int)t.x_len - 1) <= r.err))
+        L.list[7][atomicAdd(L.cnt[7], 1u)] = tid;
     // Not settled here: queued for one of the walk kernels, each list homogeneous -- first-pass bands (k <= 15) by distance: the walk
     // without the matrix up to 3 (nine in ten; a list per distance), the sub-band matrix up to 7, the general kernel beyond; the doubled thresholds of the
     // rescue pass (k <= 31); bands above 63 rows (k_path_wide).  One atomic instruction per wave: a class's first lane reserves its slots.
@@ -1267,6 +1271,7 @@ __device__ __forceinline__ void path_finish(const uint32_t *__restrict__ store, 
     // window with more than 41 inserted bases -- leaves the window without a path, as oracle/asm.c:window_path does
     if (plen > FSV_PATH_CAP) { P->state = 0; return; }
     if (dir != 3) start++;
+    const uint32_t raw0 = (err > 0 && start == 0) ? 4u : 0u;      // the alignment starts in the padded window's first column (before generate_cigar moves it): fix_boundary's question
     // generate_cigar: TMP is stored end-to-start
     if (err > 0) {
         int stop = -1;
@@ -1320,7 +1325,7 @@ __device__ __forceinline__ void path_finish(const uint32_t *__restrict__ store, 
     // pad: bit 0 = an op other than a match among the first ten, bit 1 = among the last ten -- what scan_cigar (Correct.cpp:1070) over ten
     // columns from either end asks about (calculate_boundary_cigars :2360; k_bcig_tasks reads the header only)
     const uint32_t tail10 = s_ops[0][lane64] & 0xfffffu;
-    P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1; P->y_rev = t.y_rev; P->pad = (uint16_t)((head10 ? 1u : 0u) | (tail10 ? 2u : 0u)); P->y_word = t.y_word; P->y_len = t.y_len;
+    P->path_len = (int16_t)pl; P->err = (int16_t)err; P->state = 1; P->y_rev = t.y_rev; P->pad = (uint16_t)((head10 ? 1u : 0u) | (tail10 ? 2u : 0u) | raw0); P->y_word = t.y_word; P->y_len = t.y_len;
 }
 #undef TMP
 #undef TMP_SET
@@ -1410,6 +1415,53 @@ __global__ __launch_bounds__(64) void k_path_dp(const uint32_t *__restrict__ sto
     (void)stride;
 }
 
+// ------------------------------------------------------------------------------------------------ fix_boundary
+// fix_boundary (Correct.cpp:1676-1795; for the windows' final cigars :2968 and in the left-extension pass :2858): an alignment that
+// starts in the first column of its padded window, or ends in its last one, may have been cut off by the band -- the window is aligned
+// once more with the band shifted by k towards that side (from the old region's first base / so that the x interval ends at the old
+// alignment's last base), without a hint, and the new alignment stands when it has fewer errors.  t / r / the record at P: the window
+// as K6 left it; they are replaced when the new alignment stands.  One lane, column scratch `cols` with lane stride 1 (LDS).
+// oracle/asm.c:window_path is the same, statement for statement.
+__device__ __forceinline__ void fix_boundary_dev(const uint32_t *__restrict__ store, fsv_wtask &t, fsv_wres &r, fsv_wpath *__restrict__ P, uint32_t (*s_ops)[64],
+                                                 uint64_t *cols, int k_cap)
+{
+    const uint4 h = *reinterpret_cast<const uint4 *>(P);
+    if ((h.w & 0xffu) != 1u || r.err <= 0 || t.k > FSV_K_MAX || (r.extra_begin & 0x4000)) return;     // (bit 14 of extra_begin: moved once already)
+    const int n = t.x_len, k = t.k, wlen = n + 2 * k;
+    const bool raw0 = ((h.w >> 16) & 4u) != 0u;
+    fsv_wtask t2 = t;
+    if (raw0) { if (r.extra_begin != 0) return; t2.y_start = r.y_beg; }
+    else if (r.end_site == wlen - 1) { if (r.extra_end != 0) return; t2.y_start = (r.y_beg + r.end_site) - n + 1; }
+    else return;
+    fsv_wres r2;
+    if (!bpm_window_geometry(t2, r2, k_cap)) return;
+    if (r2.y_beg == r.y_beg) return;
+    bpm_run(store, t2, r2, BpmNoSink());
+    if (r2.err < 0 || r2.err >= r.err) return;
+    path_general<uint64_t>(store, t2, P, s_ops, 0, cols, 1u);
+    r2.extra_begin = (int16_t)(r2.extra_begin | 0x4000);
+    t = t2; r = r2;
+}
+
+// the candidates k_path_fast listed, one block (one working lane, LDS scratch: see k_left_rescue) each
+__global__ __launch_bounds__(64) void k_fix_boundary(const uint32_t *__restrict__ store, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list_dev,
+                                                     fsv_wtask *__restrict__ tasks, fsv_wres *__restrict__ res, fsv_wpath *__restrict__ paths, int k_cap,
+                                                     uint32_t *__restrict__ n_fixed)
+{
+    __shared__ uint32_t s_ops[28][64];
+    __shared__ uint64_t s_cols[(FSV_WINDOW + 2) * 3];
+    if (threadIdx.x != 0) return;
+    const uint32_t n_list = *n_list_dev;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t tid = list[li];
+        fsv_wtask t = tasks[tid];
+        fsv_wres r = res[tid];
+        const int y0 = t.y_start;
+        fix_boundary_dev(store, t, r, paths + tid, s_ops, s_cols, k_cap);
+        if (t.y_start != y0) { tasks[tid] = t; res[tid] = r; if (n_fixed) atomicAdd(n_fixed, 1u); }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ k_left_rescue
 // recalcate_window_advance's left pass (Correct.cpp:2745-2905), for the overlaps k_rescue_accept set aside: a matched window whose
 // left neighbour is unmatched gets its path first -- its real start on y -- and the unmatched windows to its left are tried again one
@@ -1438,17 +1490,21 @@ __global__ __launch_bounds__(64) void k_left_rescue(const uint32_t *__restrict__
         fsv_wres *R = res + o.first_win;
         fsv_wpath *PP = paths + o.first_win;
         long long post = 0;          // sum over the windows whose path was computed here of (distance after generate_cigar - K5's distance)
-        auto window_path = [&](const fsv_wtask &t, const fsv_wres &r, fsv_wpath *P) {
+        auto window_path = [&](fsv_wtask &t, fsv_wres &r, fsv_wpath *P) {
             if (!path_gapfree(store, t, r, P, true)) path_general<uint64_t>(store, t, P, s_ops, lane64, slice, 1u);
+            fix_boundary_dev(store, t, r, P, s_ops, slice, k_cap);
         };
         for (int j = 1; j < o.n_win; j++) {
             if (R[j].err < 0 || R[j - 1].err >= 0) continue;
-            const fsv_wtask tj = T[j];
-            const fsv_wres rj = R[j];
+            fsv_wtask tj = T[j];
+            fsv_wres rj = R[j];
+            const int raw_err_j = rj.err;
             window_path(tj, rj, PP + j);
+            if (tj.y_start != T[j].y_start) { T[j] = tj; R[j] = rj; }      // (fix_boundary moved the window)
             const uint4 hj = *reinterpret_cast<const uint4 *>(PP + j);
             if ((hj.w & 0xffu) != 1u) { R[j].err = -1; continue; }       // (a path longer than a record holds: the window is unused, as in window_path)
             post += (int)(int16_t)(hj.z >> 16) - rj.err;
+            (void)raw_err_j;
             int total_y_end = (int)hj.x - 1;
             for (int k2 = j - 1; k2 >= 0 && R[k2].err < 0; k2--) {
                 fsv_wtask u = T[k2];

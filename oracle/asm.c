@@ -245,6 +245,9 @@ static int window_verify(const char *x, const char *y, int ylen, int rev, orc_wi
 /* absolute strand coordinate of padded column c */
 static inline int win_abs(const orc_win *w, int c) { return w->y_start - w->k + c; }
 
+/* fix_boundary applies to the windows' final cigars and to the left-extension pass, not to the junction alignments */
+static __thread int g_fix_boundary = 0;
+
 /* ---------------------------------------------------------------- S6: path of one matched window */
 /* Fills w->path (start-to-end ops), w->path_len, w->ry_start / w->ry_end (absolute, inclusive), w->err (after gap shifting). */
 static void window_path(const char *x, const char *y, int ylen, int rev, orc_win *w, char *ybuf, uint64_t *cols, uint8_t *tmp,
@@ -262,6 +265,32 @@ static void window_path(const char *x, const char *y, int ylen, int rev, orc_win
         end = k <= ORC_K_MAX ? orc_bpm_path(ybuf, wlen, x + w->x_start, n, k, &e2, &start, &plen, tmp, cols)
                              : orc_bpm_path_wide(ybuf, wlen, x + w->x_start, n, k, &e2, &start, &plen, tmp, cols);
         err = e2;
+    }
+    /* fix_boundary (Correct.cpp:1676-1795; called for the windows' final cigars :2968 and in the left-extension pass :2858): an alignment
+     * that starts in the first column of its padded window, or ends in its last one, may have been cut off by the band -- the window
+     * is aligned once more with the band shifted by k towards that side (from the old region's first base / so that the x interval
+     * ends at the old alignment's last base), without a hint, and the new alignment stands when it has fewer errors */
+    if (g_fix_boundary && err > 0 && k <= ORC_K_MAX && (start == 0 || end == wlen - 1)) {
+        orc_win t2 = *w;
+        int ok = 0;
+        if (start == 0) { if (w->extra_begin == 0) { t2.y_start = w->y_beg; ok = 1; } }
+        else if (w->extra_end == 0) { t2.y_start = (w->y_beg + end) - n + 1; ok = 1; }     /* (total_y_start + local_y_end: extra_begin is not taken off, as in the reference) */
+        if (ok && t2.y_start >= 0 && ylen > t2.y_start && !(ylen - t2.y_start + 2 * k + ORC_K_MAX < wlen)) {
+            const int win2 = t2.y_start - k, yb2 = win2 < 0 ? 0 : win2;
+            if (yb2 != w->y_beg) {
+                char ybuf2[ORC_WINDOW + 2 * ORC_K_MAX + 8];
+                static __thread uint8_t tmp2[2 * ORC_WINDOW + 4 * ORC_K_WIDE + 16];
+                int e2, start2 = 0, plen2 = 0, end2, olen2 = wlen < ylen - win2 ? wlen : ylen - win2;
+                for (j = 0; j < wlen; j++) { int p = win2 + j; ybuf2[j] = (p < 0 || p >= ylen) ? 'N' : ybase(y, ylen, rev, p); }
+                end2 = orc_bpm_path(ybuf2, wlen, x + w->x_start, n, k, &e2, &start2, &plen2, tmp2, cols);
+                if (getenv("ORC_DEBUG_FIX")) fprintf(stderr, "FIX x_start %d n %d k %d start %d end %d err %d -> err %d%s\n", w->x_start, n, k, start, end, err, e2, e2 >= 0 && e2 < err ? " adopted" : "");
+                if (e2 >= 0 && e2 < err) {
+                    w->y_start = t2.y_start; w->y_beg = yb2; w->extra_begin = (int16_t)(win2 < 0 ? -win2 : 0); w->extra_end = (int16_t)(wlen - olen2);
+                    w->end_site = end2; end = end2; err = e2; start = start2; plen = plen2;
+                    memcpy(tmp, tmp2, (size_t)plen2); memcpy(ybuf, ybuf2, (size_t)wlen);
+                }
+            }
+        }
     }
     if (err > 0) nrun = orc_generate_cigar(tmp, plen, n, x + w->x_start, ybuf, &start, &end, &err, rl, ro);
     else { nrun = 1; rl[0] = n; ro[0] = 0; }
@@ -439,6 +468,7 @@ static void free_sketch(const readset *R, orc_mz **uq, int *nuq)
  * Returns the window array (owned by caller); ov[].first_win/n_win index into it. */
 static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ovl *ov, int n_ov, const int32_t *cq, const int32_t *ct, int *n_win_out)
 {
+    const int fix_saved_ = (g_fix_boundary = P->fix_boundary, 0);
     int i, j, total = 0, wi;
     orc_win *W;
     char ybuf[ORC_WINDOW + 2 * ORC_K_WIDE + 8];
@@ -539,6 +569,7 @@ static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ov
             if (w->err >= 0 && !w->pad[0]) window_path(x, y, ylen, o->rev, w, ybuf, cols, tmp, rl, ro);
         }
     }
+    g_fix_boundary = fix_saved_;
     (void)wi;
     *n_win_out = total;
     return W;
@@ -1351,6 +1382,7 @@ void orc_asm_default_params(orc_asm_params *P)
     P->win_rate_pm = 40; P->k_cap = ORC_K_MAX; P->accept_err_pm = 30; P->bw_rechain = 1; P->w_later = 0; P->second_round = 1; P->ins_dag = 1;
     P->min_anchors_final = 1; P->min_ovlp_final = 1; P->graph_layout = 1;
     P->junction_cigars = 1;
+    P->fix_boundary = 1;
     P->left_rescue = 1;   /* recalcate_window_advance's left pass (Correct.cpp:2745-2905); the HIP path: k_left_rescue */
 }
 

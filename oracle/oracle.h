@@ -45,6 +45,7 @@ typedef struct {
     int32_t left_rescue;      /* 1: the rescue pass also walks left from a matched window (recalcate_window_advance, Correct.cpp:2745-2905) */
     int32_t junction_cigars;  /* 1: the haplotype partition reads the columns beside a window junction off the re-aligned junction cigar
                                  (calculate_boundary_cigars, Correct.cpp:2310; markSNP_advance :5054) */
+    int32_t fix_boundary;     /* 1: a window whose alignment touches the edge of its band is aligned once more with the band shifted (fix_boundary, Correct.cpp:1676) */
 } orc_asm_params;
 
 typedef struct {

@@ -90,7 +90,7 @@ def sketch(seq: str, w=51, k=51, hpc=1):
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "partition",
                                          "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "second_round", "ins_dag",
-                                         "min_anchors_final", "min_ovlp_final", "graph_layout", "left_rescue", "junction_cigars")]
+                                         "min_anchors_final", "min_ovlp_final", "graph_layout", "left_rescue", "junction_cigars", "fix_boundary")]
 
 
 def default_params():
@@ -105,6 +105,7 @@ def ont_params():
     p.k, p.w, p.hpc, p.bw_ec, p.bw_final = 15, 15, 0, 150, 50
     p.min_ovlp, p.min_anchors = 500, 3
     p.left_rescue = 0          # the wide-band path has no left-extension pass
+    p.fix_boundary = 0
     p.win_rate_pm, p.k_cap, p.accept_err_pm, p.bw_rechain, p.min_contig_reads, p.w_later = 250, 95, 300, 50, 2, 63
     p.partition = 0
     p.second_round = 0
