@@ -61,6 +61,7 @@ enum { CT_TASKS = 0, CT_OVERFLOW = 1, CT_DP = 2, CT_INEXACT = 3, CT_COLS_LO = 4,
 struct AsmWs {
     DevBuf store[2], cols_sb, contig_all, word_off, len, set_start, read_set, pair_base, mz, mz_off, mz_cnt, ovl, tasks, res, paths, counters, dp_list, dp_list2, dp_list3, dp_list16, dp_list_e3, dp_wide, dp_xwide, cols_wide, set_cols, site_cnt, site_rec, site_off, site_vec, site_cursor, redo, site_lists, read_dirty, cov3, lb, sr_store, brel_off, tasks2, res2, paths2, idx2, bc_idx, bc_rec, bc_win, left_list, fix_list, tasks3, res3, src3, bnd_flag, bnd_list, bnd_patch, bnd_bytes, changed, pair_read, wide_list,
         cols, tmp, gwin_off, gwin_read, sk_ends, sk_low, sk_high, hits, hits_packed, set_hits, ovl_prev, exact_flag, inexact_list, upair_base, upair_tab, upair_tab_sw, ovl_c, gwin_tab, cwin, cwin_len, warn, thr_tab, pieces, contig_out, new_len, unpack_off;
+    std::vector<uint32_t> h_store;   // the corrected reads of the sets whose layout compares bases (kept between calls: no 96 MB zero-fill a step)
     int occ_sb = 0, occ_fr[3] = {0, 0, 0}, occ_wide = 0;   // blocks per CU of the persistent K6 kernels (hipOccupancyMaxActiveBlocksPerMultiprocessor: asked once)
     ChainArgs last_chain;   // arguments of the last k_chain launch (the final pass re-chains a few pairs with another bandwidth)
     std::vector<size_t> sk_rec, uq_rec, chain_rec, bpm_rec, rescue_rec, fast_rec, dp_rec, cons_rec, bnd_rec, bpm2_rec, fast2_rec, dp2_rec, bndc_rec, bc_bpm_rec, bc_fast_rec, bc_dp_rec;   // KTimes records of the k_chain launches of this batch (their byte counts are filled in at the end)
@@ -1073,15 +1074,22 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
 
     // the unitig polishing compares reads base for base where they are joined by an inexact overlap (low coverage only): the
     // corrected reads then come to the host too, 2 bits a base (24 MB for 256 regions)
-    std::vector<uint32_t> h_store;
+    // (only the reads of the sets that hold an inexact overlap: a handful of sets, ~200 KB each.  Since the correction rounds keep
+    // overlaps of any length a 256-region batch nearly always has one somewhere, and the whole store -- 96 MB into a freshly
+    // zero-filled vector -- cost 17 ms a step)
+    std::vector<uint32_t> &h_store = W.h_store;
+    bool any_inexact = false;
     if (P.graph_layout && hraw) {
-        bool any_inexact = false;
-        for (uint32_t i = 0; i < hit_first[B.n_sets] && !any_inexact; i++) any_inexact = !(hraw[i].slot >> 31);
-        if (any_inexact) {
-            h_store.resize((size_t)G.word_off[B.n_reads] + 1);
-            FSV_HIP(ctx, hipMemcpyAsync(h_store.data(), store, (size_t)G.word_off[B.n_reads] * 4, hipMemcpyDeviceToHost, ctx->stream));
-            FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t s2 = 0; s2 < B.n_sets; s2++) {
+            bool inexact = false;
+            for (uint32_t i = hit_first[s2]; i < hit_first[s2 + 1] && !inexact; i++) inexact = !(hraw[i].slot >> 31);
+            if (!inexact) continue;
+            if (!any_inexact && h_store.size() < (size_t)G.word_off[B.n_reads] + 1) h_store.resize((size_t)G.word_off[B.n_reads] + 1);
+            any_inexact = true;
+            const uint32_t w0 = G.word_off[B.set_start[s2]], w1 = G.word_off[B.set_start[s2 + 1]];
+            if (w1 > w0) FSV_HIP(ctx, hipMemcpyAsync(h_store.data() + w0, store + w0, (size_t)(w1 - w0) * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
+        if (any_inexact) FSV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const uint8_t *set_flags = sets->set_flags;
     // layout per set (host), then stitch on the device
@@ -1103,7 +1111,7 @@ static int assemble_chunk(fsv_ctx *ctx, const fsv_readsets *sets, const fsv_asm_
                 const bool unphased = set_flags && (set_flags[s] & FSV_SET_UNPHASED);
                 if (P.graph_layout && !unphased) {
                     // the layout as hifiasm makes it (layout.h)
-                    fsv_layout::ReadBases rb; rb.words = h_store.empty() ? nullptr : h_store.data(); rb.word_off = G.word_off.data() + r0; rb.len = len.data() + r0;
+                    fsv_layout::ReadBases rb; rb.words = any_inexact ? h_store.data() : nullptr; rb.word_off = G.word_off.data() + r0; rb.len = len.data() + r0;
                     fsv_layout::Graph g(len.data() + r0, (int)ns, rb);
                     std::vector<fsv_layout::Hit> hs(nh_s);
                     for (uint32_t i = 0; i < nh_s; i++) {
