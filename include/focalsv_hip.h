@@ -25,8 +25,9 @@
  * Read store layout (hifiasm K0, Process_Read.h:108-137, restated for HBM):
  * bases are 2-bit codes A=0 C=1 G=2 T=3, 16 per little-endian uint32 word,
  * base i of a read in bits [2*(i%16), 2*(i%16)+1] of word (word_off + i/16).
- * Every read starts on a word boundary.  'N' is stored as A (hifiasm keeps an
- * N side list; the FocalSV read FASTAs come from BAM records and carry none).
+ * Every read starts on a word boundary.  In a READ 'N' is stored as A (hifiasm keeps an
+ * N side list; the FocalSV read FASTAs come from BAM records and carry none); the aligner's
+ * reference windows keep their N (fsv_align_batch).
  */
 #ifndef FOCALSV_HIP_H
 #define FOCALSV_HIP_H
@@ -324,7 +325,9 @@ typedef struct fsv_alns {
  * (rev differs), and the record it interrupts is cut in two around it: the split rule pairs records of one strand only (:286),
  * so an inversion yields no INS / DEL call, as with minimap2's reverse-strand supplementary alignment.
  * contig_seq == NULL (contig_off ignored): align the n_contigs contigs of the last fsv_assemble_batch on this context straight
- * from device memory, in their output order -- the device-resident hand-off between the two boundaries. */
+ * from device memory, in their output order -- the device-resident hand-off between the two boundaries.
+ * Reference windows may hold N (anything but ACGT / acgt): an N pairs with nothing, costs 1 in the alignment score (minimap2's sc_ambi)
+ * and does not seed; the alignment runs through a short run of N as 'M'. */
 int fsv_align_batch(fsv_ctx *ctx, const char *contig_seq, const uint64_t *contig_off, uint32_t n_contigs,
                     const uint32_t *contig_ref, const char *ref_seq, const uint64_t *ref_off, uint32_t n_refs,
                     const fsv_aln_params *params, fsv_alns *out);
