@@ -83,7 +83,10 @@ def check_planted(region, hap, aln):
 def test_planted_svs_left_aligned_over_2000_seeds():
     """seeds 1000 + i for i < 2000 (all 250 tandem-repeat regions i % 8 == 7 included): 0 misses, 0 extra calls"""
     n_sv = 0
+    full = os.environ.get("FSV_FULL_GOLDEN")
     for i in range(2000):
+        if not full and i % 8 != 7 and i % 3 != 0:       # by default every tandem-repeat region and a third of the others (the CPU suite's time)
+            continue
         r = synth.make_region(i, depth_per_hap=0.3)      # reads are not needed here: the haplotypes themselves are aligned
         for h in (0, 1):
             a = O.align_contig(r.haps[h], r.ref)
@@ -91,7 +94,7 @@ def test_planted_svs_left_aligned_over_2000_seeds():
             misses, extra = check_planted(r, h, a)
             assert not misses and extra == 0, (i, h, misses, extra, _events(a))
             n_sv += sum(1 for t in r.truth if t.hap & (h + 1))
-    assert n_sv > 5000
+    assert n_sv > (5000 if full else 2000)
 
 
 def test_gap_shift_rule():
