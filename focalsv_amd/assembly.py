@@ -127,6 +127,13 @@ def assembly(out_dir: str, cpu: int = 10, threads: int = 8, data_type: int = 0, 
         finally:
             if own:
                 ctx.close()
+        # the noisy-read profiles hold 4 096 minimizers per read (k = w = 15: about 32 kb) and 4 096 anchors per pair; a longer read keeps
+        # its windows but loses the anchors beyond that (set status bits 1 / 2): say how many reads of a set that concerns
+        LONG = 32000
+        for f, rs in zip(fas, sets):
+            n_long = sum(1 for r_ in rs if len(r_) > LONG)
+            if n_long:
+                logger.warning(f"{f}: {n_long} of {len(rs)} reads are longer than {LONG} bases: their overlaps are seeded from their first 4 096 minimizers only")
         for f, (contigs, st) in zip(fas, per_set):
             d = f[:-3] + "_flye"
             os.makedirs(d, exist_ok=True)

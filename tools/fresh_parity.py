@@ -38,7 +38,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         for i in range(first, first + count):
             depth = depths[i % len(depths)]
-            width = (30000, 50000, 70000)[i % 3]
+            width = tuple(int(x) for x in os.environ.get("FRESH_WIDTHS", "30000,50000,70000").split(","))[i % 3]
             r = synth.make_region(i, width=width, depth_per_hap=depth)
             for h in (1, 2):
                 reads = r.reads[h - 1]
