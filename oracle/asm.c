@@ -428,7 +428,17 @@ static void collect_overlaps(const readset *R, const orc_asm_params *P, int bw, 
                 if (n + 2 > cap) { cap *= 2; ov = (orc_ovl *)realloc(ov, sizeof(orc_ovl) * (size_t)cap); }
                 ov[n++] = o;
                 cused += o.n_chain;
+                if (getenv("ORC_DEBUG_CHAIN")) {
+                    int dq = -1, dt = -1, z;
+                    sscanf(getenv("ORC_DEBUG_CHAIN"), "%d,%d", &dq, &dt);
+                    if (dq == q && dt == t) { fprintf(stderr, "CHAIN %d->%d rev %d x [%d,%d] y [%d,%d] n %d:", q, t, o.rev, o.x_s, o.x_e, o.y_s, o.y_e, o.n_chain); for (z = 0; z < o.n_chain; z++) fprintf(stderr, " (%d,%d)", cq[o.chain_off + z], ct[o.chain_off + z]); fprintf(stderr, "\n"); }
+                }
                 if (orc_chain_pair(uq[t], nuq[t], lent, uq[q], nuq[q], lenq, P, bw, &m2, cq + cused, ct + cused, chain_cap)) {
+                    if (getenv("ORC_DEBUG_CHAIN")) {
+                        int dq = -1, dt = -1, z;
+                        sscanf(getenv("ORC_DEBUG_CHAIN"), "%d,%d", &dq, &dt);
+                        if (dq == t && dt == q) { fprintf(stderr, "CHAIN %d->%d rev %d x [%d,%d] y [%d,%d] n %d:", t, q, m2.rev, m2.x_s, m2.x_e, m2.y_s, m2.y_e, m2.n_chain); for (z = 0; z < m2.n_chain; z++) fprintf(stderr, " (%d,%d)", cq[cused + z], ct[cused + z]); fprintf(stderr, "\n"); }
+                    }
                     m2.q = (uint32_t)t; m2.t = (uint32_t)q; m2.chain_off = cused;
                     cused += m2.n_chain;
                     ov[n++] = m2;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Golden data from read sets of seeds no other golden file uses (7000 ..., 8000 ...: three window widths, 6x - 30x per haplotype): the corrected
+"""Golden data from read sets of seeds no other golden file uses (7000 ..., 8000 ..., 9000 ...: 14 - 100 kb windows, 6x - 40x per haplotype): the corrected
 reads of the reference's hifiasm-0.14 (oracle/_ref) after one, two and three correction rounds (-r N --write-ec) and its contigs
 -> tests/golden/hifiasm_fresh.json.  Three of these sets showed what the other goldens did not (a 300-base overlap voting at a read's
 end; the two directions of a gapped final overlap differing by an indel near a read end; an overlap that only the left-extension
@@ -9,8 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from focalsv_amd import synth
 HIFIASM = os.path.join(ROOT, "oracle", "_ref", "hifiasm-0.14")
-BLOCKS = ((7000, 20, (15.0, 10.0, 25.0, 8.0)), (8000, 20, (12.0, 20.0, 30.0, 6.0)))      # (first seed, count, depths per haplotype)
-WIDTHS = (30000, 50000, 70000)
+BLOCKS = ((7000, 20, (15.0, 10.0, 25.0, 8.0), (30000, 50000, 70000)), (8000, 20, (12.0, 20.0, 30.0, 6.0), (30000, 50000, 70000)),
+          (9000, 18, (40.0, 9.0, 18.0, 7.0), (14000, 26000, 100000)))      # (first seed, count, depths per haplotype, window widths)
 
 
 def canon(s):
@@ -37,8 +37,8 @@ def run(reads, rounds, tmp):
 def main():
     out = []
     with tempfile.TemporaryDirectory() as tmp:
-        for i, depths in ((i, d) for first, count, d in BLOCKS for i in range(first, first + count)):
-            depth, width = depths[i % len(depths)], WIDTHS[i % len(WIDTHS)]
+        for i, depths, widths in ((i, d, w) for first, count, d, w in BLOCKS for i in range(first, first + count)):
+            depth, width = depths[i % len(depths)], widths[i % len(widths)]
             r = synth.make_region(i, width=width, depth_per_hap=depth)
             for h in (1, 2):
                 reads = r.reads[h - 1]
