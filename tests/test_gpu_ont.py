@@ -128,3 +128,32 @@ def test_clr_profile_planted_truth():
     tp, fp, fn, gt_ok = pipeline.match_truth(calls, truth, bp_tol=20, len_tol=0.02, left_shift_ok=2000)
     assert tp >= len(truth) - 1 and fp <= 1 and gt_ok >= tp - 1, (tp, fp, fn, gt_ok, len(truth))
     assert pipeline.match_truth(calls, truth, bp_tol=1, len_tol=0.0)[0] >= len(truth) * 3 // 4
+
+
+def test_reads_of_70_kb_and_more_assemble():
+    """an ONT-profile batch with a read of 65 536 bases or more takes k_chain's long layout with the 4 096-anchor tile --
+    98 KB of dynamic LDS, which needs the opt-in (hipFuncSetAttribute) the kernel now gets: the launch used to be refused and the whole
+    batch came back FSV_EHIP.  A 110 kb stretch, 10 % error, reads of 70-90 kb among reads of 10-30 kb: one contig within 0.2 % of the
+    stretch's length that shares 19 in 20 of its 24-mers.  Not compared with the oracle: a read above ~32 kb loses the minimizers beyond
+    its first 4 096 on the GPU (set status bit FSV_W_MZ_TRUNC, asserted here), which the oracle does not model -- the supported range of
+    the noisy-read profiles is reads up to ~32 kb"""
+    import numpy as np
+    from focalsv_amd.readsets import pack_sets
+    rng = np.random.default_rng(4711)
+    hap = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 110000)]
+    reads = synth._sample_reads(rng, hap, 3.0, 70000, 90000, 0.10) + synth._sample_reads(rng, hap, 8.0, 10000, 30000, 0.10)
+    assert max(len(r) for r in reads) >= 70000 and set(b"".join(reads)) <= set(b"ACGT")
+    with _lib.Context(0) as ctx:
+        b = pack_sets([reads])
+        d = ctx.upload(b.words)
+        try:
+            contigs, cset, cnr, status = ctx.assemble_batch(d, b.word_off, b.read_len, b.set_start, ctx.ont_asm_params())
+        finally:
+            ctx.dev_free(d)
+    assert int(status[0]) & ~(_lib.W_MZ_TRUNC | _lib.W_ANCHOR_TRUNC) == 0 and int(status[0]) & _lib.W_MZ_TRUNC
+    assert len(contigs) == 1 and abs(len(contigs[0]) - len(hap)) <= len(hap) // 500, [len(c) for c in contigs]
+    h = hap.tobytes()
+    c = bytes(contigs[0])
+    kmers = {c[i:i + 24] for i in range(len(c) - 23)} | {synth.revcomp(c)[i:i + 24] for i in range(len(c) - 23)}
+    probes = [h[i:i + 24] for i in range(1000, len(h) - 1000, 97)]
+    assert sum(p in kmers for p in probes) >= 0.95 * len(probes)
