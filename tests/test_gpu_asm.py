@@ -301,6 +301,24 @@ def test_unphased_sets_give_both_haplotypes(ctx, golden_dir):
         assert got == exp
 
 
+def test_fresh_unphased_sets_equal_hifiasm016(ctx, golden_dir):
+    """the 48 mixed sets of regions 100 .. 147 (seeds taken as they come) in one fsv_assemble_batch call, flagged FSV_SET_UNPHASED: both
+    contigs byte-identical to the bp.hap1 / bp.hap2 contigs of the reference's hifiasm-0.16.1 (tests/golden/hifiasm016_unphased.json) --
+    but for the sets of KNOWN_UNPHASED_DEVIATIONS, where one haplotype comes out in two pieces"""
+    from tests.test_oracle_asm import check_unphased_set
+    gold = [g for g in json.load(open(os.path.join(golden_dir, "hifiasm016_unphased.json")))["sets"] if g["region"] >= 100]
+    assert len(gold) == 48
+    sets = []
+    for g in gold:
+        r = synth.make_region(g["region"])
+        sets.append(r.reads[0] + r.reads[1])
+        assert hashlib.md5(b"\n".join(sets[-1])).hexdigest() == g["reads_md5"]
+    contigs, cset, status, reads, b = gpu_assemble(ctx, sets, None, [1] * len(sets))
+    assert (status == 0).all()
+    for si, g in enumerate(gold):
+        check_unphased_set(g, [c for c, cs in zip(contigs, cset) if cs == si])
+
+
 def test_repeat_rich_sets_equal_hifiasm(ctx, golden_dir):
     """the 36 read sets with interspersed repeats of tests/golden/hifiasm_repeats.json through fsv_assemble_batch in one call:
     corrected reads md5 for md5 the reference's hifiasm --write-ec reads, contigs identical -- the set in which hifiasm collapses a

@@ -15,7 +15,9 @@ def canon(s):
 
 def main():
     out = []
-    for region, mode in [(i, "mixed") for i in (0, 1, 2, 3, 5, 7, 8, 12, 22, 38)] + [(0, "hp1"), (7, "hp2")]:
+    # the first twelve are the sets of round 2; regions 100 .. 147 are a run of seeds taken as they come (round 3: whatever they show
+    # -- tests/test_oracle_asm.py lists the ones that differ)
+    for region, mode in [(i, "mixed") for i in (0, 1, 2, 3, 5, 7, 8, 12, 22, 38)] + [(0, "hp1"), (7, "hp2")] + [(i, "mixed") for i in range(100, 148)]:
         r = synth.make_region(region)
         reads = r.reads[0] + r.reads[1] if mode == "mixed" else r.reads[0 if mode == "hp1" else 1]
         with tempfile.TemporaryDirectory() as tmp:
