@@ -564,7 +564,13 @@ static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ov
                 fprintf(stderr, "  (win of pos: %d)\n", dp / ORC_WINDOW - o->x_s / ORC_WINDOW);
             }
         }
-        /* accept: 0.9 coverage filter, then error rate <= 0.03 with unmatched windows charged in full */
+        /* accept: 0.9 coverage filter, then error rate <= 0.03 with unmatched windows charged in full.
+         * NOT RESTATED: non_trim_error_rate (Correct.cpp:725-845) charges an unmatched window that lies beside a matched one less than its
+         * length -- it extends the neighbours' alignments into the window from the left and from the right (verify_sub_window :675,
+         * Reserve_Banded_BPM_Extension Levenshtein_distance.h:63, doubled threshold) and charges their errors plus the bases neither reaches.
+         * In a phased set no overlap's verdict hangs on it (all 204 golden sets agree without it); in an unphased set it decides whether an overlap across a
+         * heterozygous indel of 100-200 bases is accepted: round 1 of 5 of the 48 mixed sets (KNOWN_MIXED_READ_DEVIATIONS in the
+         * tests; rounds 2 and 3 agree again). */
         o->is_match = 0;
         for (j = 0; j < o->n_win; j++) {
             orc_win *w = &W[o->first_win + j];
@@ -1364,7 +1370,9 @@ static void correction_round(readset *R, const orc_asm_params *P, int w, int do_
     char **nseq = (char **)malloc(sizeof(char *) * (size_t)R->n);
     int *nlen = (int *)malloc(sizeof(int) * (size_t)R->n);
     sketch_set(R, P, w, &uq, &nuq);
+    g_both_ways = getenv("ORC_EC_BOTH_WAYS") ? 1 : 0;   /* experiment switch: chain the correction rounds' overlaps from both sides too (changes none of the golden sets) */
     collect_overlaps(R, P, P->bw_ec, uq, nuq, &ov, &cq, &ct, &n_ov);
+    g_both_ways = 0;
     W = align_overlaps(R, P, ov, n_ov, cq, ct, &n_win);
     if (P->partition) for (q = 0; q < R->n; q++) partition_read(R, P, q, ov, n_ov, W); /* every read of every set, phased or not, as hifiasm */
     for (q = 0; q < R->n; q++) {
