@@ -245,6 +245,45 @@ static int window_verify(const char *x, const char *y, int ylen, int rev, orc_wi
 /* absolute strand coordinate of padded column c */
 static inline int win_abs(const orc_win *w, int c) { return w->y_start - w->k + c; }
 
+/* non_trim_error_rate's charge for the unmatched window j of an overlap (Correct.cpp:745-838): the alignment of the window before it is
+ * extended into it from the left, that of the window after it from the right (verify_sub_window :675-722: the doubled threshold,
+ * Reserve_Banded_BPM_Extension, for the right side on the reversed strings); charged are the two distances and the bases neither reaches.
+ * Returns the running total (the reference adds to a long long, through float arithmetic in one branch). */
+static long unmatched_charge(const char *x, const char *y, int ylen, int rev, const orc_win *W, int n_win, int j, const orc_asm_params *P,
+                             char *ybuf, long terr)
+{
+    const orc_win *w = &W[j];
+    const int n = w->x_len, thr = orc_double_thr_p(P, w->k, n), wlen = n + 2 * thr;
+    int yb[2] = {-1, -1}, al[2] = {0, 0}, er[2] = {0, 0}, d, c;
+    static __thread char xr[ORC_WINDOW + 8], yr[ORC_WINDOW + 2 * ORC_K_WIDE + 8];
+    if (w->y_beg < 0) return terr + n;                               /* (w_list[i].y_start == -1: the window lies outside y) */
+    if (thr > ORC_K_MAX) return terr + n;                            /* (wide-band profiles: not restated) */
+    if (j > 0 && W[j - 1].err >= 0) yb[0] = W[j - 1].ry_end + 1;
+    if (j + 1 < n_win && W[j + 1].err >= 0) yb[1] = W[j + 1].ry_start - n;
+    if (yb[0] < 0 && yb[1] < 0) yb[0] = yb[1] = w->y_beg + w->k - w->extra_begin;
+    if (yb[0] < 0) yb[0] = yb[1];
+    if (yb[1] < 0) yb[1] = yb[0];
+    for (d = 0; d < 2; d++) {
+        const int win0 = yb[d] - thr;
+        int e, pe, te;
+        if (yb[d] < 0 || ylen <= yb[d] || ylen - yb[d] + 2 * thr + P->k_cap < wlen) continue;    /* determine_overlap_region */
+        for (c = 0; c < wlen; c++) { const int p = win0 + c; ybuf[c] = (p < 0 || p >= ylen) ? 'N' : ybase(y, ylen, rev, p); }
+        if (d == 0) te = orc_bpm_extension(ybuf, x + w->x_start, n, thr, &e, &pe);
+        else {
+            for (c = 0; c < wlen; c++) yr[c] = ybuf[wlen - 1 - c];
+            for (c = 0; c < n; c++) xr[c] = x[w->x_start + n - 1 - c];
+            te = orc_bpm_extension(yr, xr, n, thr, &e, &pe);
+        }
+        if (te >= 0) { al[d] = te + 1; er[d] = e; }
+    }
+    if (al[0] && al[1]) {
+        if (al[0] + al[1] <= n) return terr + er[0] + er[1] + (n - al[0] - al[1]);
+        { const float rate = (float)n / (float)(al[0] + al[1]); return (long)((float)terr + (float)(unsigned)(er[0] + er[1]) * rate); }
+    }
+    if (!al[0] && !al[1]) return terr + n;
+    return al[0] ? terr + er[0] + (n - al[0]) : terr + er[1] + (n - al[1]);
+}
+
 /* fix_boundary applies to the windows' final cigars and to the left-extension pass, not to the junction alignments */
 static __thread int g_fix_boundary = 0;
 
@@ -572,10 +611,19 @@ static orc_win *align_overlaps(const readset *R, const orc_asm_params *P, orc_ov
          * heterozygous indel of 100-200 bases is accepted: round 1 of 5 of the 48 mixed sets (KNOWN_MIXED_READ_DEVIATIONS in the
          * tests; rounds 2 and 3 agree again). */
         o->is_match = 0;
+        if (P->partial_charge && (int64_t)(o->x_e - o->x_s + 1) * 9 <= (int64_t)o->align_len * 10) {
+            /* the reference has the matched windows' cigars (and the errors / ends they give) before it sums up (Correct.cpp:2920-3003) */
+            for (j = 0; j < o->n_win; j++) {
+                orc_win *w = &W[o->first_win + j];
+                if (w->err >= 0 && !w->pad[0]) { window_path(x, y, ylen, o->rev, w, ybuf, cols, tmp, rl, ro); w->pad[0] = 1; }
+            }
+        }
         for (j = 0; j < o->n_win; j++) {
             orc_win *w = &W[o->first_win + j];
             tlen += w->x_len;
-            terr += w->err >= 0 ? w->err : w->x_len;
+            if (w->err >= 0) terr += w->err;
+            else if (!P->partial_charge) terr += w->x_len;
+            else terr = unmatched_charge(x, y, ylen, o->rev, W + o->first_win, o->n_win, j, P, ybuf, terr);
         }
         o->err_sum = (int32_t)terr;
         if ((int64_t)(o->x_e - o->x_s + 1) * 9 <= (int64_t)o->align_len * 10 && terr * 1000 <= tlen * P->accept_err_pm) o->is_match = 1;
@@ -1401,6 +1449,7 @@ void orc_asm_default_params(orc_asm_params *P)
     P->min_anchors_final = 1; P->min_ovlp_final = 1; P->graph_layout = 1;
     P->junction_cigars = 1;
     P->fix_boundary = 1;
+    P->partial_charge = getenv("ORC_PARTIAL_CHARGE") ? 1 : 0;   /* (the env switch: to run any test with it) */
     P->left_rescue = 1;   /* recalcate_window_advance's left pass (Correct.cpp:2745-2905); the HIP path: k_left_rescue */
 }
 

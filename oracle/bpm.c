@@ -103,6 +103,28 @@ int orc_bpm(const char *y, int m, const char *x, int n, int k, int *err)
     return bpm_pick_end(&s, n, m, k, err);
 }
 
+/* Reserve_Banded_BPM_Extension (Levenshtein_distance.h:63-205): K5's recurrence, and after every column the best band cell within k
+ * (get_error :14-61 -- bpm_pick_end with 2k rows below the diagonal); the extension ends at the last column that has one.  Returns that
+ * column (0-based, -1: none), *err its distance, *p_end the y offset it ends at.  y must hold n + 2k bases. */
+int orc_bpm_extension(const char *y, const char *x, int n, int k, int *err, int *p_end)
+{
+    bpm_t s;
+    int i, t_end = -1;
+    *err = -1; *p_end = -1;
+    bpm_init(&s, y, k);
+    for (i = 0; i < n; i++) {
+        int e, site;
+        if (!bpm_column(&s, base_code(x[i]))) {
+            s.err++;
+            if (s.err - 2 * k > k) return t_end;
+        }
+        site = bpm_pick_end(&s, i + 1, i + 1 + 2 * k, k, &e);
+        if (e >= 0) { t_end = i; *p_end = site; *err = e; }
+        if (i + 1 < n) bpm_slide(&s, y[i + 1 + 2 * k], k);
+    }
+    return t_end;
+}
+
 /* K6.  Same recurrence, keeping {D0,VP,VN,HP,HN} per column, then the walk back.
  * path[] is written end-to-start with ops 0 match, 1 mismatch, 2 "up" (a y base
  * with no x partner), 3 "left" (an x base with no y partner).

@@ -46,6 +46,8 @@ typedef struct {
     int32_t junction_cigars;  /* 1: the haplotype partition reads the columns beside a window junction off the re-aligned junction cigar
                                  (calculate_boundary_cigars, Correct.cpp:2310; markSNP_advance :5054) */
     int32_t fix_boundary;     /* 1: a window whose alignment touches the edge of its band is aligned once more with the band shifted (fix_boundary, Correct.cpp:1676) */
+    int32_t partial_charge;   /* 1: an unmatched window beside a matched one is charged what two extension alignments leave uncovered (non_trim_error_rate,
+                               * Correct.cpp:725-845) instead of its length.  ORACLE ONLY so far (the HIP path charges the length): default 0 */
 } orc_asm_params;
 
 typedef struct {
@@ -122,6 +124,7 @@ int orc_align_contig_multi(const char *contig, int lenq, const char *ref, int le
                            uint32_t *cigar, int cigar_cap, int max_rec);
 int orc_sketch(const char *s, int len, int w, int k, int hpc, orc_mz *out, int cap);
 int orc_bpm(const char *y, int m, const char *x, int n, int k, int *err);
+int orc_bpm_extension(const char *y, const char *x, int n, int k, int *err, int *p_end);
 int orc_bpm_wide(const char *y, int m, const char *x, int n, int k, int *err);
 int orc_bpm_path_wide(const char *y, int m, const char *x, int n, int k, int *err, int *start_site, int *path_len, uint8_t *path, uint64_t *cols);
 int orc_banded_dp_plain(const char *y, int m, const char *x, int n, int k, uint8_t *ends);

@@ -44,6 +44,11 @@ int main() {
             unsigned int err;
             int site = Reserve_Banded_BPM((char*)y.c_str(), (int)y.size(), (char*)x.c_str(), (int)x.size(), (unsigned short)k, &err);
             printf("%d %d\n", site, (int)err);
+        } else if (cmd == "ext") {      // alignment_extension (Levenshtein_distance.h:224): direction 0 forward, 1 from the right end
+            int k, dir; std::string x, y; is >> k >> dir >> x >> y;
+            unsigned int err; int p_end = -1, t_end = -1, aligned = 0;
+            alignment_extension((char*)y.c_str(), (int)y.size(), (char*)x.c_str(), (int)x.size(), (unsigned short)k, dir, &err, &p_end, &t_end, &aligned);
+            printf("%d %d %d %d\n", aligned, (int)err, p_end, t_end);
         } else if (cmd == "path") {
             int k; std::string x, y; is >> k >> x >> y;
             unsigned int err; int start = -1, plen = 0;

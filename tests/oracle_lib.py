@@ -27,6 +27,18 @@ def bpm(x: str, y: str, k: int):
     return site, err.value
 
 
+def bpm_extension(x: str, y: str, k: int, direction: int = 0):
+    """alignment_extension (Levenshtein_distance.h:224): (bases of x covered, distance there, p_end, t_end) as the reference returns them;
+    direction 1 extends from the right end (both strings reversed, ends converted back)"""
+    err, pe = C.c_int(0), C.c_int(0)
+    if direction:
+        x, y = x[::-1], y[::-1]
+    te = lib().orc_bpm_extension(y.encode(), x.encode(), len(x), k, C.byref(err), C.byref(pe))
+    if te < 0:
+        return 0, -1, -1, -1
+    return (te + 1, err.value, pe.value, te) if not direction else (te + 1, err.value, len(y) - pe.value, len(x) - te)
+
+
 def bpm_wide(x: str, y: str, k: int):
     err = C.c_int(0)
     site = lib().orc_bpm_wide(y.encode(), len(y), x.encode(), len(x), k, C.byref(err))
@@ -90,7 +102,7 @@ def sketch(seq: str, w=51, k=51, hpc=1):
 class AsmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("k", "w", "hpc", "n_rounds", "min_ovlp", "min_anchors", "lookback", "bw_ec", "bw_final", "min_contig_reads", "partition",
                                          "win_rate_pm", "k_cap", "accept_err_pm", "bw_rechain", "w_later", "second_round", "ins_dag",
-                                         "min_anchors_final", "min_ovlp_final", "graph_layout", "left_rescue", "junction_cigars", "fix_boundary")]
+                                         "min_anchors_final", "min_ovlp_final", "graph_layout", "left_rescue", "junction_cigars", "fix_boundary", "partial_charge")]
 
 
 def default_params():

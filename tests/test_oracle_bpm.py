@@ -16,6 +16,16 @@ def test_k5_matches_reference_golden(golden_dir):
             assert site == c["end_site"], c
 
 
+def test_extension_matches_reference_golden(golden_dir):
+    """orc_bpm_extension against the reference's alignment_extension (tools/make_golden_bpm_ext.py: 400 windows, both directions, where
+    an insertion / deletion / unrelated sequence begins some way in): how far the window aligns within the threshold and at what cost --
+    what non_trim_error_rate charges an unmatched window (orc_asm_params.partial_charge)"""
+    cases = json.load(open(os.path.join(golden_dir, "bpm_ext.json")))["cases"]
+    assert len(cases) == 400
+    for c in cases:
+        assert O.bpm_extension(c["x"], c["y"], c["k"], c["dir"]) == (c["aligned"], c["err"], c["p_end"], c["t_end"]), c
+
+
 def test_k5_survey_known_answer():
     # SURVEY.md 8(c): end_site=21 err=1
     assert O.bpm("ACGTACGTTGCAAGCTTAGC", "NNNACGTACGTGCAAGCTTAGCANNN", 3) == (21, 1)
