@@ -85,7 +85,7 @@ def test_planted_svs_left_aligned_over_2000_seeds():
     n_sv = 0
     full = os.environ.get("FSV_FULL_GOLDEN")
     for i in range(2000):
-        if not full and i % 8 != 7 and i % 3 != 0:       # by default every tandem-repeat region and a third of the others (the CPU suite's time)
+        if not full and (i % 16 != 7 if i % 8 == 7 else i % 6 != 0):   # by default every second tandem-repeat region and a sixth of the others (the CPU suite's time)
             continue
         r = synth.make_region(i, depth_per_hap=0.3)      # reads are not needed here: the haplotypes themselves are aligned
         for h in (0, 1):
@@ -94,7 +94,7 @@ def test_planted_svs_left_aligned_over_2000_seeds():
             misses, extra = check_planted(r, h, a)
             assert not misses and extra == 0, (i, h, misses, extra, _events(a))
             n_sv += sum(1 for t in r.truth if t.hap & (h + 1))
-    assert n_sv > (5000 if full else 2000)
+    assert n_sv > (5000 if full else 1000)
 
 
 def test_gap_shift_rule():
